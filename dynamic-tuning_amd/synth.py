@@ -1,0 +1,136 @@
+"""Deterministic synthetic weights / inputs for the DyT ViT-B/16 hot path.
+
+There is no network on the build or GPU boxes, so checkpoints (the timm IN-21K
+``.pth`` that ``main_image.py:219-247`` loads) cannot be fetched.  Everything that
+needs weights -- parity tests, golden fixtures, ``bench.py`` -- gets them from this
+recipe instead.  The generator is numpy's PCG64 + ziggurat ``standard_normal`` (plain
+C double arithmetic, no SIMD-dependent paths), so the SAME bits come out in the build
+container and on the GPU box; torch's own CPU ``randn`` is avoided on purpose.
+
+State-dict keys and shapes are exactly the reference's (SURVEY.md section 8b;
+``models/vision_transformer_IN21K.py:272-320`` and ``models/dynamic_adapter.py:61,105-107``).
+"""
+import zlib
+
+import numpy as np
+import torch
+
+DEPTH = 12
+DIM = 768
+HEADS = 12
+MLP_HIDDEN = 3072
+NUM_PATCHES = 196
+NUM_TOKENS = 197
+
+
+def param_shapes(num_classes=100, ffn_num=64, depth=DEPTH):
+    """Ordered ``name -> shape`` for the reference model's ``state_dict()``."""
+    shapes = {
+        "cls_token": (1, 1, DIM),
+        "pos_embed": (1, NUM_TOKENS, DIM),
+        "patch_embed.proj.weight": (DIM, 3, 16, 16),
+        "patch_embed.proj.bias": (DIM,),
+    }
+    for i in range(depth):
+        p = "blocks.%d." % i
+        shapes[p + "norm1.weight"] = (DIM,)
+        shapes[p + "norm1.bias"] = (DIM,)
+        shapes[p + "attn.qkv.weight"] = (3 * DIM, DIM)
+        shapes[p + "attn.qkv.bias"] = (3 * DIM,)
+        shapes[p + "attn.proj.weight"] = (DIM, DIM)
+        shapes[p + "attn.proj.bias"] = (DIM,)
+        shapes[p + "norm2.weight"] = (DIM,)
+        shapes[p + "norm2.bias"] = (DIM,)
+        shapes[p + "mlp.fc1.weight"] = (MLP_HIDDEN, DIM)
+        shapes[p + "mlp.fc1.bias"] = (MLP_HIDDEN,)
+        shapes[p + "mlp.fc2.weight"] = (DIM, MLP_HIDDEN)
+        shapes[p + "mlp.fc2.bias"] = (DIM,)
+        shapes[p + "adaptmlp.down_proj.weight"] = (ffn_num, DIM)
+        shapes[p + "adaptmlp.down_proj.bias"] = (ffn_num,)
+        shapes[p + "adaptmlp.up_proj.weight"] = (DIM, ffn_num)
+        shapes[p + "adaptmlp.up_proj.bias"] = (DIM,)
+        shapes[p + "mlp_token_select.mlp_head.weight"] = (1, DIM)
+        shapes[p + "mlp_token_select.mlp_head.bias"] = (1,)
+    shapes["norm.weight"] = (DIM,)
+    shapes["norm.bias"] = (DIM,)
+    shapes["head.weight"] = (num_classes, DIM)
+    shapes["head.bias"] = (num_classes,)
+    return shapes
+
+
+def is_trainable(name):
+    """Freeze rule of ``main_image.py:250-256``: adapters, gates and the head train."""
+    return ("adaptmlp." in name) or ("mlp_token_select." in name) or name.startswith("head.")
+
+
+def _rng(name, seed):
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def _normal(name, shape, seed, std, mean=0.0):
+    a = _rng(name, seed).standard_normal(size=shape) * std + mean
+    return torch.from_numpy(a.astype(np.float32))
+
+
+def make_state_dict(num_classes=100, ffn_num=64, seed=0, kind="test", depth=DEPTH,
+                    gate_bias=0.0):
+    """Synthetic weights.
+
+    kind="bench": what the reference's own init gives (trunc-normal(0.02) linears with
+        zero biases, LN weight 1 / bias 0, ``pos_embed ~ 0.02 N``, ``cls ~ 1e-6 N``;
+        ``models/vision_transformer_IN21K.py:285,321-332``) except ``up_proj ~ N(0,0.02)``
+        (the reference zero-inits it, ``dynamic_adapter.py:112-117``, which would leave the
+        adapter path idle) and the gate bias set to ``gate_bias`` (keep-ratio calibration,
+        SURVEY.md section 8d).
+    kind="test": additionally randomises every bias and LayerNorm affine so that no term
+        of the forward/backward is multiplied by an exact 0 or 1 in the parity tests.
+    """
+    sd = {}
+    test = kind == "test"
+    for name, shape in param_shapes(num_classes, ffn_num, depth).items():
+        if name == "cls_token":
+            t = _normal(name, shape, seed, 0.02 if test else 1e-6)
+        elif name == "pos_embed":
+            t = _normal(name, shape, seed, 0.02)
+        elif ".norm" in name or name.startswith("norm."):
+            if name.endswith("weight"):
+                t = _normal(name, shape, seed, 0.1, 1.0) if test else torch.ones(shape)
+            else:
+                t = _normal(name, shape, seed, 0.1) if test else torch.zeros(shape)
+        elif name.endswith("mlp_token_select.mlp_head.bias"):
+            t = torch.full(shape, float(gate_bias))
+            if test:
+                t = t + _normal(name, shape, seed, 0.1)
+        elif name.endswith("bias"):
+            t = _normal(name, shape, seed, 0.02) if test else torch.zeros(shape)
+        elif name == "patch_embed.proj.weight":
+            t = _normal(name, shape, seed, 0.02)
+        elif name == "head.weight":
+            t = _normal(name, shape, seed, 0.02 if test else 0.01)
+        else:
+            t = _normal(name, shape, seed, 0.02)
+        sd[name] = t.contiguous()
+    return sd
+
+
+def make_batch(batch, num_classes=100, seed=0):
+    """Images ``N(0,1)`` [B,3,224,224] fp32 and int64 targets."""
+    x = _normal("images", (batch, 3, 224, 224), seed, 1.0)
+    y = _rng("targets", seed + 1).integers(0, num_classes, size=(batch,))
+    return x, torch.from_numpy(y.astype(np.int64))
+
+
+def make_noise(batch, depth=DEPTH, seed=2, passes=2):
+    """Gumbel draws ``g1, g2 = -log(Exp(1))`` shaped [passes, depth, B, 196] each
+    (what ``dynamic_adapter.py:30-39`` draws per block and per pass)."""
+    r = _rng("gumbel", seed)
+    e = r.standard_exponential(size=(2, passes, depth, batch, NUM_PATCHES))
+    g = -np.log(e)
+    return (torch.from_numpy(g[0].astype(np.float32)), torch.from_numpy(g[1].astype(np.float32)))
+
+
+def make_dropout_masks(batch, ffn_num=64, depth=DEPTH, seed=3, p=0.1, passes=2):
+    """Bernoulli(1-p) keep masks for the adapter dropout, uint8 [passes, depth, B*197, r]."""
+    r = _rng("dropout", seed)
+    u = r.random(size=(passes, depth, batch * NUM_TOKENS, ffn_num))
+    return torch.from_numpy((u >= p).astype(np.uint8))

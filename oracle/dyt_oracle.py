@@ -1,0 +1,247 @@
+"""CPU oracle for the DyT ViT-B/16 fine-tune hot path -- TEST INFRASTRUCTURE ONLY.
+
+A torch-fp32 restatement of the reference's algorithm for the path BASELINE.json's
+``north_star`` names.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this file; the product (``dynamic-tuning_amd/``) never
+does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real reference from
+``/root/reference`` (behind stand-ins for the absent third-party packages timm/easydict)
+in the build container, runs its model, its ``AdaLoss`` and its own
+``engine_finetune.train_one_epoch`` / ``evaluate`` on seeded inputs with recorded Gumbel
+noise and dropout masks, and commits the results as ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function below against those vectors.
+The reference itself holds no tests or golden vectors for this path.
+
+Third-party arithmetic restated here because it is not under /root/reference:
+timm==0.9.12 ``PatchEmbed`` (Conv2d k=s=16 + flatten + transpose) and ``Mlp``
+(fc1 -> exact-erf GELU -> fc2), torch ``LayerNorm`` / ``scaled_dot_product_attention`` /
+``AdamW``.  Every function cites the reference file:line it follows (paths relative to
+/root/reference).
+
+Floating point: everything is fp32 on CPU, exactly like the reference's CPU path
+(``torch.cuda.amp.autocast`` is a no-op there).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+DEPTH, DIM, HEADS, HEAD_DIM, NTOK = 12, 768, 12, 64, 197
+LN_EPS = 1e-6  # models/vision_transformer_IN21K.py:262
+
+
+def patch_embed(sd, x):
+    """timm PatchEmbed as used at models/vision_transformer_IN21K.py:272-278,344."""
+    y = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=16)
+    return y.flatten(2).transpose(1, 2)
+
+
+def embed(sd, x):
+    """cls/pos prologue, models/vision_transformer_IN21K.py:344-352 (all dropouts are p=0)."""
+    t = patch_embed(sd, x)
+    t = torch.cat((sd["cls_token"].expand(t.shape[0], -1, -1), t), dim=1)
+    return t + sd["pos_embed"]
+
+
+def layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
+
+
+def attention(sd, p, x):
+    """Attention.forward, models/vision_transformer_IN21K.py:54-75 (explicit-softmax branch
+    :66-70; the fused SDPA branch :60-64 computes the same function)."""
+    B, N, C = x.shape
+    qkv = F.linear(x, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, HEADS, HEAD_DIM).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.unbind(0)
+    q = q * (HEAD_DIM ** -0.5)
+    a = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+
+
+def gumbel_sigmoid(logits, g1, g2, tau=5.0, threshold=0.5, training=True):
+    """_gumbel_sigmoid, models/dynamic_adapter.py:25-54, with the two Gumbel draws
+    (:30-39) passed in instead of drawn.  Returns (straight-through select, y_soft)."""
+    if training:
+        y_soft = ((logits + g1 - g2) / tau).sigmoid()  # :41-42
+    else:
+        y_soft = logits.sigmoid()  # :44
+    y_hard = torch.zeros_like(logits).masked_fill(y_soft > threshold, 1.0)  # :47-50
+    return y_hard - y_soft.detach() + y_soft, y_soft  # :51
+
+
+def token_select(sd, p, x, g1, g2, training, tau=5.0, threshold=0.5):
+    """TokenSelect.forward, models/dynamic_adapter.py:70-77."""
+    logits = F.linear(x[:, 1:, :], sd[p + "mlp_token_select.mlp_head.weight"],
+                      sd[p + "mlp_token_select.mlp_head.bias"])  # :72
+    sel, _ = gumbel_sigmoid(logits, g1, g2, tau, threshold, training)
+    sel = torch.cat([sel.new_ones(x.shape[0], 1, 1), sel], dim=1)  # :75
+    return sel, logits
+
+
+def adapter(sd, p, x, scale, keep_mask=None, drop_p=0.1):
+    """Adapter.forward with layernorm option "none" and add_residual=False,
+    models/dynamic_adapter.py:120-140.  ``keep_mask`` (0/1, same shape as the bottleneck
+    activation) replaces the Bernoulli draw of F.dropout (:127); None = eval / p=0."""
+    down = F.relu(F.linear(x, sd[p + "adaptmlp.down_proj.weight"], sd[p + "adaptmlp.down_proj.bias"]))
+    if keep_mask is not None:
+        down = down * keep_mask.to(down.dtype) * (1.0 / (1.0 - drop_p))
+    up = F.linear(down, sd[p + "adaptmlp.up_proj.weight"], sd[p + "adaptmlp.up_proj.bias"])
+    return up * scale  # :130
+
+
+def mlp(sd, p, x):
+    """timm Mlp as used at models/vision_transformer_IN21K.py:124-129,159: fc2(gelu_erf(fc1 x))."""
+    h = F.gelu(F.linear(x, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="masked",
+          tau=5.0, threshold=0.5, drop_p=0.1):
+    """Block.forward, models/vision_transformer_IN21K.py:144-165.
+
+    mode="masked":   the reference's training semantics -- MLP on every token, multiplied by
+                     the straight-through mask (:159-162).
+    mode="compact":  forward value identical, but the MLP output of dropped tokens is treated
+                     as never computed, so the gate gradient <dL/dx', h> exists only for kept
+                     tokens ("compact" training mode).
+    mode="gather":   real gather / scatter like models/model_speed_test.py:274-310
+                     (forward-only use; same values as "masked").
+    """
+    p = "blocks.%d." % i
+    x = x + attention(sd, p, layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))  # :148
+    sel, logits = token_select(sd, p, x, g1, g2, training, tau, threshold)  # :150-152
+    adapt = adapter(sd, p, x, scale, keep_mask, drop_p)  # :157
+    if complete_model or mode != "gather":
+        h = mlp(sd, p, layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))  # :159
+        if not complete_model:
+            if mode == "compact":
+                h = h * sel.detach()
+            h = sel * h  # :161-162
+    else:
+        B, N, C = x.shape
+        flat = x.reshape(B * N, C)
+        idx = sel.reshape(-1).nonzero()[:, 0]  # model_speed_test.py:300
+        hk = mlp(sd, p, layer_norm(flat[idx], sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+        h = torch.zeros_like(flat)
+        h[idx] = hk  # :302-304
+        h = h.reshape(B, N, C)
+    return x + h + adapt, sel, logits  # :163
+
+
+def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=False,
+            training=True, mode="masked", tau=5.0, threshold=0.5, drop_p=0.1, depth=DEPTH,
+            return_blocks=False):
+    """VisionTransformer.forward, models/vision_transformer_IN21K.py:343-385.
+
+    g1, g2: [depth, B, 196] Gumbel draws (None in eval); keep_masks: [depth, B*197, r]
+    uint8/bool adapter-dropout keep masks or None.
+    Returns logits [B,C] and {"token_select","token_logits"} each [B,depth,196,1]."""
+    B = x.shape[0]
+    t = embed(sd, x)
+    sels, logs, xs = [], [], [t]
+    for i in range(depth):
+        a = g1[i].reshape(B, NTOK - 1, 1) if (training and g1 is not None) else 0.0
+        b = g2[i].reshape(B, NTOK - 1, 1) if (training and g2 is not None) else 0.0
+        km = None
+        if training and keep_masks is not None:
+            km = keep_masks[i].reshape(B, NTOK, -1)
+        t, sel, lg = block(sd, i, t, a, b, km, scale, complete_model, training, mode,
+                           tau, threshold, drop_p)
+        sels.append(sel)
+        logs.append(lg)
+        xs.append(t)
+    ts = torch.stack(sels, dim=1)[:, :, 1:, :]  # :367 (drop the cls column)
+    tl = torch.stack(logs, dim=1)  # :368
+    t = layer_norm(t, sd["norm.weight"], sd["norm.bias"])  # :370
+    logits = F.linear(t[:, 0], sd["head.weight"], sd["head.bias"])  # :375-380 (cls pooling)
+    out = dict(token_select=ts, token_logits=tl)
+    if return_blocks:
+        out["blocks"] = xs
+    return logits, out
+
+
+def ada_loss(logits, token_sel, y, token_target_ratio=0.5, token_loss_ratio=2.0,
+             token_minimal=0.0, token_minimal_weight=0.0):
+    """AdaLoss.forward / _get_token_loss, models/losses.py:48-84."""
+    base = F.cross_entropy(logits, y)
+    tok = ((token_sel.mean() - token_target_ratio) ** 2).mean()  # :69-72
+    if token_minimal_weight > 0:
+        tok = tok + token_minimal_weight * (token_minimal - token_sel.mean(-1)).clamp(min=0.).sum()  # :74-78
+    return base + token_loss_ratio * tok, dict(base_loss=base, token_loss=token_loss_ratio * tok)
+
+
+def step_loss(sd, x, y, g1, g2, keep_masks, scale=0.1, mode="masked", token_target_ratio=0.5,
+              token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0, depth=DEPTH,
+              drop_p=0.1):
+    """Loss of one fine-tune step, engine_finetune.py:47-65: student + teacher forward,
+    KL(student || teacher.detach()), teacher CE, AdaLoss(student).
+
+    g1/g2: [2, depth, B, 196] (pass 0 = student, 1 = teacher; the teacher pass also draws
+    gate noise although its mask is discarded, :152,161); keep_masks [2, depth, B*197, r]."""
+    km = (None, None) if keep_masks is None else (keep_masks[0], keep_masks[1])
+    out_s, tok = forward(sd, x, g1[0], g2[0], km[0], scale, False, True, mode, depth=depth, drop_p=drop_p)
+    out_t, _ = forward(sd, x, g1[1], g2[1], km[1], scale, True, True, mode, depth=depth, drop_p=drop_p)
+    kl = F.kl_div(F.log_softmax(out_s, dim=-1), F.log_softmax(out_t.detach(), dim=-1),
+                  reduction="batchmean", log_target=True)  # :52-57
+    teacher = F.cross_entropy(out_t, y)  # :60
+    loss, d = ada_loss(out_s, tok["token_select"], y, token_target_ratio, token_loss_ratio,
+                       token_minimal, token_minimal_weight)  # :61-62
+    loss = loss + teacher + kl  # :63
+    d = dict(d, teacher_loss=teacher, distillation_loss=kl, loss=loss)
+    return loss, d, (out_s, out_t, tok)
+
+
+def trainable_names(sd):
+    """Freeze rule, main_image.py:250-256."""
+    return [k for k in sd if ("adaptmlp." in k) or ("mlp_token_select." in k) or k.startswith("head.")]
+
+
+def step_grads(sd, x, y, g1, g2, keep_masks, **kw):
+    """Loss components and gradients of every trainable tensor for one step."""
+    names = trainable_names(sd)
+    leaf = {k: (v.detach().clone().requires_grad_(True) if k in names else v.detach()) for k, v in sd.items()}
+    loss, d, outs = step_loss(leaf, x, y, g1, g2, keep_masks, **kw)
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names])
+    return {k: v.detach() for k, v in d.items()}, dict(zip(names, grads)), outs
+
+
+def adamw_update(p, g, m, v, step, lr, wd=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.AdamW single-tensor update (decoupled decay on every trainable tensor,
+    main_image.py:285).  ``step`` is 1-based.  Returns new (p, m, v)."""
+    p = p * (1.0 - lr * wd)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+def lr_at(epoch_float, lr, min_lr, warmup_epochs, epochs):
+    """util/lr_sched.py:9-21 (per-iteration warm-up + half cosine)."""
+    if epoch_float < warmup_epochs:
+        return lr * epoch_float / warmup_epochs
+    return min_lr + (lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * (epoch_float - warmup_epochs) / (epochs - warmup_epochs)))
+
+
+def accuracy(output, target, topk=(1,)):
+    """util/metrics.py:4-11."""
+    maxk = min(max(topk), output.size()[1])
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand_as(pred.t()))
+    return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100. / target.size(0) for k in topk]
+
+
+def train_step(sd, opt_state, x, y, g1, g2, keep_masks, lr, wd=0.01, **kw):
+    """One full step on CPU: losses, grads, AdamW on the trainable tensors (in place in ``sd``).
+    ``opt_state``: dict name -> (m, v), plus "step".  Used as bench.py's cpu_baseline."""
+    d, grads, _ = step_grads(sd, x, y, g1, g2, keep_masks, **kw)
+    opt_state["step"] = opt_state.get("step", 0) + 1
+    for k, g in grads.items():
+        m, v = opt_state.get(k, (torch.zeros_like(g), torch.zeros_like(g)))
+        sd[k], m, v = adamw_update(sd[k], g, m, v, opt_state["step"], lr, wd)
+        opt_state[k] = (m, v)
+    return d

@@ -1,0 +1,144 @@
+"""Pins oracle/dyt_oracle.py to the golden vectors captured from the real reference
+(tests/golden/make_golden.py).  CPU only; runs in the build container and on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import dyt_oracle as O
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def state(g):
+    return synth.make_state_dict(int(g["meta_num_classes"]), int(g["meta_ffn_num"]), seed=int(g["meta_seed"]),
+                                 kind="test", gate_bias=float(g["meta_gate_bias"]))
+
+
+@pytest.fixture(scope="module")
+def step64(golden_dir):
+    g = load(golden_dir, "step_r64.npz")
+    B, C, r = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = state(g)
+    x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    keep = synth.make_dropout_masks(B, r, seed=int(g["meta_seed"]) + 3)
+    g1, g2 = torch.from_numpy(g["s0_g1"]), torch.from_numpy(g["s0_g2"])
+    torch.set_num_threads(8)
+    d, grads, outs = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="masked",
+                                  token_target_ratio=float(g["meta_target_ratio"]))
+    return g, sd, d, grads, outs, (x, y, g1, g2, keep)
+
+
+def test_forward_logits_and_masks(step64):
+    g, sd, d, grads, (ls, lt, tok), _ = step64
+    assert np.abs(ls.detach().numpy() - g["s0_logits_student"]).max() < 2e-5
+    assert np.abs(lt.detach().numpy() - g["s0_logits_teacher"]).max() < 2e-5
+    assert np.abs(tok["token_logits"].detach().numpy() - g["s0_token_logits"]).max() < 2e-5
+    # masks bit-exact (min |z| margin of this fixture is 1.2e-4 >> fp32 round-off of the logits)
+    assert float(g["s0_min_gate_margin"]) > 1e-5
+    assert np.array_equal(tok["token_select"].detach().numpy().astype(np.uint8), g["s0_token_select"])
+
+
+def test_block_outputs(step64):
+    g, sd, _, _, _, (x, y, g1, g2, keep) = step64
+    with torch.no_grad():
+        _, o = O.forward(sd, x, g1[0], g2[0], keep[0], float(g["meta_scale"]), False, True, return_blocks=True)
+        _, ot = O.forward(sd, x, g1[1], g2[1], keep[1], float(g["meta_scale"]), True, True, return_blocks=True)
+    sub = g["sub_tokens"].tolist()
+    for name, blocks in (("s0_blocks_student", o["blocks"]), ("s0_blocks_teacher", ot["blocks"])):
+        for i in range(12):
+            err = np.abs(blocks[i + 1][:, sub].numpy() - g[name][i]).max()
+            assert err < 5e-5, (name, i, err)
+
+
+def test_loss_components(step64):
+    g, _, d, _, _, _ = step64
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(float(d[k]) - float(g["s0_stat_" + k])) < 1e-5 * max(1.0, abs(float(g["s0_stat_" + k]))), k
+
+
+def test_trainable_grads(step64):
+    g, _, _, grads, _, _ = step64
+    assert len(grads) == 74
+    for n, gr in grads.items():
+        ref_norm = float(g["s0_gradnorm/" + n])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-9, n
+        key = "s0_grad/" + n
+        if key in g:
+            assert np.abs(gr.numpy() - g[key]).max() <= 1e-4 * np.abs(g[key]).max() + 1e-9, n
+
+
+def test_adamw_step(step64):
+    g, sd, _, grads, _, _ = step64
+    for n, gr in grads.items():
+        key = "s0_param_after/" + n
+        if key not in g:
+            continue
+        # pin the AdamW arithmetic itself on the reference's own gradient ...
+        gref = torch.from_numpy(g["s0_grad/" + n])
+        p, _, _ = O.adamw_update(sd[n], gref, torch.zeros_like(gr), torch.zeros_like(gr), 1,
+                                 float(g["meta_lr"]), float(g["meta_wd"]))
+        assert np.abs(p.numpy() - g[key]).max() < 1e-7, n
+        # ... and end to end on the oracle's gradient (elements with |g| ~ eps=1e-8 amplify
+        # round-off of g into the normalised update m/(sqrt(v)+eps): allow 1 % of lr)
+        p, _, _ = O.adamw_update(sd[n], gr, torch.zeros_like(gr), torch.zeros_like(gr), 1,
+                                 float(g["meta_lr"]), float(g["meta_wd"]))
+        err = np.abs(p.numpy() - g[key])
+        big = np.abs(gref.numpy()) > 1e-6
+        assert err[big].max(initial=0.0) < 1e-5 and err.max() < 2.1 * float(g["meta_lr"]), n
+
+
+def test_two_steps_vtab_shape(golden_dir):
+    """r=8 / scale 1 / wd 1e-4 (main_vtab.py) + AdaLoss minimal-token term, two AdamW steps."""
+    g = load(golden_dir, "step_r8.npz")
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    sd = state(g)
+    opt = {}
+    for s in range(2):
+        x, y = synth.make_batch(B, C, seed=seed + 10 * s)
+        keep = synth.make_dropout_masks(B, r, seed=seed + 3 + 10 * s)
+        g1, g2 = torch.from_numpy(g["s%d_g1" % s]), torch.from_numpy(g["s%d_g2" % s])
+        d = O.train_step(sd, opt, x, y, g1, g2, keep, lr=float(g["meta_lr"]), wd=float(g["meta_wd"]),
+                         scale=float(g["meta_scale"]), token_target_ratio=float(g["meta_target_ratio"]),
+                         token_minimal=float(g["meta_token_minimal"]),
+                         token_minimal_weight=float(g["meta_token_minimal_weight"]))
+        for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+            ref = float(g["s%d_stat_%s" % (s, k)])
+            assert abs(float(d[k]) - ref) < 2e-5 * max(1.0, abs(ref)), (s, k, float(d[k]), ref)
+        for n in O.trainable_names(sd):
+            key = "s%d_param_after/%s" % (s, n)
+            if key in g:
+                err = np.abs(sd[n].detach().numpy() - g[key])
+                big = np.abs(g["s%d_grad/%s" % (s, n)]) > 1e-6
+                assert err[big].max(initial=0.0) < 5e-5 and err.max() < 4.2 * float(g["meta_lr"]), (s, n)
+
+
+def test_eval_and_gather_equivalence(golden_dir):
+    g = load(golden_dir, "eval_r64.npz")
+    B, C, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_seed"])
+    sd = state(g)
+    x, y = synth.make_batch(B, C, seed=seed)
+    with torch.no_grad():
+        lm, tm = O.forward(sd, x, scale=float(g["meta_scale"]), training=False, mode="masked")
+        lg, tg = O.forward(sd, x, scale=float(g["meta_scale"]), training=False, mode="gather")
+    assert np.abs(lm.numpy() - g["logits"]).max() < 2e-5
+    assert np.abs(lg.numpy() - g["logits_gathered"]).max() < 2e-5
+    assert np.abs(lm.numpy() - lg.numpy()).max() < 1e-5  # the reference's two implementations agree
+    assert np.array_equal(tm["token_select"].numpy().astype(np.uint8), g["token_select"])
+    assert abs(float(O.accuracy(lm, y, topk=(1, 5))[0]) - float(g["metric"])) < 1e-6
+
+
+def test_compact_mode_semantics(step64):
+    """compact mode: same forward values, gate gradient only from kept tokens."""
+    g, sd, d, grads, outs, (x, y, g1, g2, keep) = step64
+    d2, grads2, outs2 = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="compact",
+                                     token_target_ratio=float(g["meta_target_ratio"]))
+    assert torch.equal(outs[0], outs2[0]) and abs(float(d["loss"]) - float(d2["loss"])) < 1e-6
+    n = "blocks.5.mlp_token_select.mlp_head.weight"
+    assert (grads[n] - grads2[n]).norm() > 1e-3 * grads[n].norm()  # the gate gradient differs...
+    n = "head.weight"
+    assert (grads[n] - grads2[n]).norm() < 1e-5 * grads[n].norm()  # ...the head gradient does not
