@@ -1,0 +1,123 @@
+"""ctypes binding of libdyt_hip.so (C ABI: include/dyt_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load this
+module raises, and every model forward / step goes through it.  PyTorch is used only for
+device memory, streams and torch.distributed.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
+
+PREC_FP32, PREC_BF16 = 0, 1
+F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS = 1, 2, 4, 8, 16
+
+# enum dyt_param (include/dyt_hip.h)
+(P_CLS, P_POS, P_PE_W, P_PE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_PROJ_W, P_PROJ_B, P_LN2_W, P_LN2_B,
+ P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_NORM_W, P_NORM_B, P_AD_DOWN_W, P_AD_DOWN_B, P_AD_UP_W, P_AD_UP_B,
+ P_GATE_W, P_GATE_B, P_HEAD_W, P_HEAD_B, P_COUNT) = range(27)
+
+# reference state_dict key suffix -> param id  
+GLOBAL_KEYS = {
+    "cls_token": P_CLS, "pos_embed": P_POS, "patch_embed.proj.weight": P_PE_W, "patch_embed.proj.bias": P_PE_B,
+    "norm.weight": P_NORM_W, "norm.bias": P_NORM_B, "head.weight": P_HEAD_W, "head.bias": P_HEAD_B,
+}
+BLOCK_KEYS = {
+    "norm1.weight": P_LN1_W, "norm1.bias": P_LN1_B, "attn.qkv.weight": P_QKV_W, "attn.qkv.bias": P_QKV_B,
+    "attn.proj.weight": P_PROJ_W, "attn.proj.bias": P_PROJ_B, "norm2.weight": P_LN2_W, "norm2.bias": P_LN2_B,
+    "mlp.fc1.weight": P_FC1_W, "mlp.fc1.bias": P_FC1_B, "mlp.fc2.weight": P_FC2_W, "mlp.fc2.bias": P_FC2_B,
+    "adaptmlp.down_proj.weight": P_AD_DOWN_W, "adaptmlp.down_proj.bias": P_AD_DOWN_B,
+    "adaptmlp.up_proj.weight": P_AD_UP_W, "adaptmlp.up_proj.bias": P_AD_UP_B,
+    "mlp_token_select.mlp_head.weight": P_GATE_W, "mlp_token_select.mlp_head.bias": P_GATE_B,
+}
+
+
+def key_to_param(name):
+    """'blocks.3.attn.qkv.weight' -> (P_QKV_W, 3); global keys -> (id, 0)."""
+    if name in GLOBAL_KEYS:
+        return GLOBAL_KEYS[name], 0
+    if name.startswith("blocks."):
+        _, idx, rest = name.split(".", 2)
+        if rest in BLOCK_KEYS:
+            return BLOCK_KEYS[rest], int(idx)
+    raise KeyError("not a DyT ViT parameter: %s" % name)
+
+
+def is_trainable_param(pid):
+    return pid >= P_AD_DOWN_W
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("num_classes", ctypes.c_int32), ("ffn_num", ctypes.c_int32), ("depth", ctypes.c_int32),
+                ("precision", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("slots", ctypes.c_int32),
+                ("adapter_scale", ctypes.c_float), ("adapter_dropout", ctypes.c_float), ("tau", ctypes.c_float),
+                ("threshold", ctypes.c_float)]
+
+
+class DyTError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i, _i64, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
+
+# every symbol include/dyt_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dyt_last_error": (ctypes.c_char_p, []),
+    "dyt_version": (_i, []),
+    "dyt_ctx_create": (_i, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
+    "dyt_ctx_destroy": (_i, [_vp]),
+    "dyt_ctx_bytes": (_i, [_vp, ctypes.POINTER(_i64)]),
+    "dyt_set_frozen": (_i, [_vp, _i, _i, _vp, _vp]),
+    "dyt_trainable_numel": (_i, [_vp, ctypes.POINTER(_i64)]),
+    "dyt_trainable_offset": (_i, [_vp, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dyt_forward": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "dyt_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dyt_loss": (_i, [_vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "dyt_adamw": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "dyt_step_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _u64, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
+                              _vp, _vp]),
+    "dyt_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "dyt_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dyt_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "dyt_gate_compact": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dyt_profile_enable": (_i, [_vp, _i]),
+    "dyt_profile_read": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
+                              ctypes.POINTER(ctypes.c_double)]),
+}
+
+
+def lib():
+    """Load libdyt_hip.so (once).  Raises DyTError when it is absent -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DyTError("%s not found: build it with `make -C dynamic-tuning_amd/csrc` "
+                           "(or __graft_entry__.build()); the DyT path has no fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DyTError("libdyt_hip: %s (code %d)" % (lib().dyt_last_error().decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libdyt_hip needs contiguous device tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,557 @@
+// Multi-head self-attention for the DyT ViT-B/16 path: N = 197 tokens, 12 heads x 64.
+// Replaces Attention.forward's F.scaled_dot_product_attention / explicit softmax
+// (models/vision_transformer_IN21K.py:60-70 of the reference) and its autograd backward.
+//
+// N = 197 is small: K and V of one (image, head) are 25 KB in bf16 and live in LDS for the
+// whole workgroup; a wave keeps the complete 32 x 224 score block of its query tile in
+// registers, so no online-softmax rescaling is needed (197 is padded to 224 = 7 x 32 and the
+// pad keys are masked to -inf).
+//
+// fast path (bf16, v_mfma_f32_32x32x16_bf16).  Layout tricks, all addressing-only:
+//   * scores are computed TRANSPOSED, S^T = K Q^T, so each lane owns one query column: the row
+//     max / row sum are in-lane reductions plus a single cross-half shuffle;
+//   * the MFMA C/D layout of that tile (lane <-> query, registers <-> keys) is already the
+//     B-operand layout of the next MFMA (O^T = V^T P^T) up to a fixed permutation of the k
+//     index; the A operand (V^T from an LDS-transposed copy) is fetched with the SAME
+//     permutation, so P never moves between lanes;
+//   * the same holds for every product of the backward pass (two kernels: dQ per query tile,
+//     dK/dV per key tile -- no atomics, deterministic).
+// exact path (fp32 vector ALU): one thread per query / key row -- the parity mode.
+#include "kernels.h"
+
+namespace dyt {
+
+constexpr int NPAD = 224;   // 7 tiles of 32
+constexpr int RLD = 72;     // bf16 per row of a row-major [224][64] LDS image (144 B: conflict-free b128 fragment reads)
+constexpr int TLD = 228;    // bf16 per row of a transposed [64][224] LDS image (456 B = 8 x odd: conflict-free b64 reads)
+constexpr int ROW_IMG = NPAD * RLD * 2;  // 32256 B
+constexpr int TR_IMG = HD * TLD * 2;     // 29184 B
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+    return z;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)v[base + i];
+    return o;
+}
+__device__ __forceinline__ bf16x8 join44(const bf16* p) {  // p[0..3] and p[8..11]
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 8);
+    bf16x8 o = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return o;
+}
+
+// stage a [197][64] matrix (row stride `ld` elements in global) into a row-major and/or a
+// transposed LDS image; rows >= 197 are zero.
+template <int NTHREADS>
+__device__ __forceinline__ void stage_rows(const bf16* __restrict__ src, int ld, bf16* rowimg, bf16* trimg, int tid) {
+    for (int t = tid; t < (NPAD / 2) * 8; t += NTHREADS) {
+        const int pr = t >> 3, c = t & 7, r0 = pr * 2;
+        bf16x8 a = zero8(), b = zero8();
+        if (r0 < NT) a = *reinterpret_cast<const bf16x8*>(src + (size_t)r0 * ld + c * 8);
+        if (r0 + 1 < NT) b = *reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + 1) * ld + c * 8);
+        if (rowimg) {
+            *reinterpret_cast<bf16x8*>(rowimg + r0 * RLD + c * 8) = a;
+            *reinterpret_cast<bf16x8*>(rowimg + (r0 + 1) * RLD + c * 8) = b;
+        }
+        if (trimg) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                bf16x2 pv = {a[i], b[i]};
+                *reinterpret_cast<bf16x2*>(trimg + (c * 8 + i) * TLD + r0) = pv;
+            }
+        }
+    }
+}
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------
+// forward, bf16
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                            const bf16* __restrict__ v, bf16* __restrict__ out,
+                                                            float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ks = reinterpret_cast<bf16*>(smem);
+    bf16* Vt = reinterpret_cast<bf16*>(smem + ROW_IMG);
+    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
+    const bf16* qb = q + (size_t)bh * NT * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_rows<256>(k + (size_t)bh * NT * HD, HD, Ks, nullptr, tid);
+    stage_rows<256>(v + (size_t)bh * NT * HD, HD, nullptr, Vt, tid);
+    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5;
+
+#pragma unroll 1
+    for (int qt = wave; qt < 7; qt += 4) {
+        const int qrow = qt * 32 + l31;
+        const int qr = min(qrow, NT - 1);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + qr * HD + ks * 16 + hi * 8);
+        f32x16 st[7];
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                st[kt] = MFMA32(a, qf[ks], st[kt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // st[kt][r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*hi][q = l31]; mask the pad keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 192 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= NT) st[6][r] = -INFINITY;
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, st[kt][r]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(st[kt][r] - m);
+                st[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = m + __logf(sum);
+
+        f32x16 o[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8 pf = pack8(st[kt], half * 8);
+                const int keybase = kt * 32 + half * 16 + 4 * hi;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 vf = join44(Vt + (dt * 32 + l31) * TLD + keybase);
+                    o[dt] = MFMA32(vf, pf, o[dt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (qrow < NT) {
+            const float inv = 1.0f / sum;
+            bf16* op = out + ((size_t)b * NT + qrow) * D + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store4(op + dt * 32 + 8 * g + 4 * hi, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
+                           o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, bf16: dQ (+ delta = rowsum(dO * O)) per query tile
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                               const bf16* __restrict__ v, const bf16* __restrict__ o,
+                                                               const bf16* __restrict__ dout,
+                                                               const float* __restrict__ lse, float* __restrict__ delta,
+                                                               bf16* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ks = reinterpret_cast<bf16*>(smem);
+    bf16* Vs = reinterpret_cast<bf16*>(smem + ROW_IMG);
+    bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG);
+    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
+    const bf16* qb = q + (size_t)bh * NT * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_rows<256>(k + (size_t)bh * NT * HD, HD, Ks, Kt, tid);
+    stage_rows<256>(v + (size_t)bh * NT * HD, HD, Vs, nullptr, tid);
+    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5;
+
+#pragma unroll 1
+    for (int qt = wave; qt < 7; qt += 4) {
+        const int qrow = qt * 32 + l31;
+        const int qr = min(qrow, NT - 1);
+        const size_t trow = ((size_t)b * NT + qr) * D + h * HD;
+        bf16x8 qf[4], dof[4];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qb + qr * HD + ks * 16 + hi * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dout + trow + ks * 16 + hi * 8);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + trow + ks * 16 + hi * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dl += (float)dof[ks][i] * (float)of[i];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        const float L = lse[(size_t)bh * NT + qr];
+        if (hi == 0 && qrow < NT) delta[(size_t)bh * NT + qrow] = dl;
+
+        f32x16 dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll 1
+        for (int kt = 0; kt < 7; ++kt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                s = MFMA32(ka, qf[ks], s);      // S^T[key][q]
+                dp = MFMA32(va, dof[ks], dp);   // dP^T[key][q]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float p = key < NT ? __expf(s[r] - L) : 0.f;
+                s[r] = p * (dp[r] - dl);        // dS^T
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8 dsf = pack8(s, half * 8);
+                const int keybase = kt * 32 + half * 16 + 4 * hi;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 kf = join44(Kt + (dt * 32 + l31) * TLD + keybase);
+                    dq[dt] = MFMA32(kf, dsf, dq[dt]);  // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+                }
+            }
+        }
+        if (qrow < NT) {
+            bf16* op = dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store4(op + dt * 32 + 8 * g + 4 * hi, dq[dt][4 * g] * 0.125f, dq[dt][4 * g + 1] * 0.125f,
+                           dq[dt][4 * g + 2] * 0.125f, dq[dt][4 * g + 3] * 0.125f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, bf16: dK, dV per key tile (8 waves, waves 0..6 own one 32-key tile each)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                                const bf16* __restrict__ v,
+                                                                const bf16* __restrict__ dout,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ delta,
+                                                                bf16* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Qs = reinterpret_cast<bf16*>(smem);
+    bf16* dOs = reinterpret_cast<bf16*>(smem + ROW_IMG);
+    bf16* Qt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG);
+    bf16* dOt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG + TR_IMG);
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * ROW_IMG + 2 * TR_IMG);
+    float* del_s = lse_s + NPAD;
+    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_rows<512>(q + (size_t)bh * NT * HD, HD, Qs, Qt, tid);
+    stage_rows<512>(dout + (size_t)b * NT * D + h * HD, D, dOs, dOt, tid);
+    if (tid < NPAD) {
+        lse_s[tid] = tid < NT ? lse[(size_t)bh * NT + tid] : 0.f;
+        del_s[tid] = tid < NT ? delta[(size_t)bh * NT + tid] : 0.f;
+    }
+    __syncthreads();
+    if (wave >= 7) return;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kt = wave;
+    const int key = kt * 32 + l31;
+    const int kr = min(key, NT - 1);
+    const bf16* kb = k + ((size_t)bh * NT + kr) * HD;
+    const bf16* vb = v + ((size_t)bh * NT + kr) * HD;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(kb + ks * 16 + hi * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vb + ks * 16 + hi * 8);
+    }
+    f32x16 aK[2], aV[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
+
+#pragma unroll 1
+    for (int qt = 0; qt < 7; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
+            const bf16x8 da = *reinterpret_cast<const bf16x8*>(dOs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
+            s = MFMA32(qa, kf[ks], s);     // S[q][key]   (rows q in registers, column key = lane)
+            dp = MFMA32(da, vf[ks], dp);   // dP[q][key]
+        }
+        f32x16 p;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q0 = qt * 32 + 8 * g + 4 * hi;
+            const float4 L4 = *reinterpret_cast<const float4*>(lse_s + q0);
+            const float4 D4 = *reinterpret_cast<const float4*>(del_s + q0);
+            const float Ls[4] = {L4.x, L4.y, L4.z, L4.w};
+            const float Ds[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const bool ok = (q0 + e < NT) && (key < NT);
+                const float pv = ok ? __expf(s[r] - Ls[e]) : 0.f;
+                p[r] = pv;
+                s[r] = pv * (dp[r] - Ds[e]);  // dS
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16x8 pf = pack8(p, half * 8);
+            const bf16x8 dsf = pack8(s, half * 8);
+            const int qbase = qt * 32 + half * 16 + 4 * hi;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 dot = join44(dOt + (dt * 32 + l31) * TLD + qbase);
+                const bf16x8 qtf = join44(Qt + (dt * 32 + l31) * TLD + qbase);
+                aV[dt] = MFMA32(dot, pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                aK[dt] = MFMA32(qtf, dsf, aK[dt]);  // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            }
+        }
+    }
+    if (key < NT) {
+        bf16* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hi;
+                store4(op + D + d, aK[dt][4 * g], aK[dt][4 * g + 1], aK[dt][4 * g + 2], aK[dt][4 * g + 3]);
+                store4(op + 2 * D + d, aV[dt][4 * g], aV[dt][4 * g + 1], aV[dt][4 * g + 2], aV[dt][4 * g + 3]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// exact fp32 kernels (vector ALU)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, float* __restrict__ out,
+                                                           float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + NT * HD;
+    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
+    const int tid = threadIdx.x;
+    const float4* k4 = reinterpret_cast<const float4*>(k + (size_t)bh * NT * HD);
+    const float4* v4 = reinterpret_cast<const float4*>(v + (size_t)bh * NT * HD);
+    for (int t = tid; t < NT * HD / 4; t += 256) {
+        reinterpret_cast<float4*>(Ks)[t] = k4[t];
+        reinterpret_cast<float4*>(Vs)[t] = v4[t];
+    }
+    __syncthreads();
+    if (tid >= NT) return;
+    float qv[HD];
+    const float* qp = q + ((size_t)bh * NT + tid) * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qv[d] = qp[d];
+    float m = -INFINITY;
+    for (int j = 0; j < NT; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s = fmaf(qv[d], Ks[j * HD + d], s);
+        m = fmaxf(m, s);
+    }
+    float l = 0.f, ov[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) ov[d] = 0.f;
+    for (int j = 0; j < NT; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s = fmaf(qv[d], Ks[j * HD + d], s);
+        const float p = expf(s - m);
+        l += p;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) ov[d] = fmaf(p, Vs[j * HD + d], ov[d]);
+    }
+    const float inv = 1.0f / l;
+    float* op = out + ((size_t)b * NT + tid) * D + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = ov[d] * inv;
+    lse[(size_t)bh * NT + tid] = m + logf(l);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ o,
+                                                              const float* __restrict__ dout,
+                                                              const float* __restrict__ lse, float* __restrict__ delta,
+                                                              float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + NT * HD;
+    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
+    const int tid = threadIdx.x;
+    const float4* k4 = reinterpret_cast<const float4*>(k + (size_t)bh * NT * HD);
+    const float4* v4 = reinterpret_cast<const float4*>(v + (size_t)bh * NT * HD);
+    for (int t = tid; t < NT * HD / 4; t += 256) {
+        reinterpret_cast<float4*>(Ks)[t] = k4[t];
+        reinterpret_cast<float4*>(Vs)[t] = v4[t];
+    }
+    __syncthreads();
+    if (tid >= NT) return;
+    float qv[HD], dov[HD], dq[HD];
+    const float* qp = q + ((size_t)bh * NT + tid) * HD;
+    const size_t trow = ((size_t)b * NT + tid) * D + h * HD;
+    float dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        qv[d] = qp[d];
+        dov[d] = dout[trow + d];
+        dl = fmaf(dov[d], o[trow + d], dl);
+        dq[d] = 0.f;
+    }
+    const float L = lse[(size_t)bh * NT + tid];
+    delta[(size_t)bh * NT + tid] = dl;
+    for (int j = 0; j < NT; ++j) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            s = fmaf(qv[d], Ks[j * HD + d], s);
+            dp = fmaf(dov[d], Vs[j * HD + d], dp);
+        }
+        const float ds = expf(s - L) * (dp - dl);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[j * HD + d], dq[d]);
+    }
+    float* op = dqkv + ((size_t)b * NT + tid) * (3 * D) + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = dq[d] * 0.125f;
+}
+
+// two threads per key (each owns 32 of the 64 channels)
+__global__ __launch_bounds__(512) void attn_bwd_dkv_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v,
+                                                               const float* __restrict__ dout,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Qs = reinterpret_cast<float*>(smem);
+    float* dOs = Qs + NT * HD;
+    float* lse_s = dOs + NT * HD;
+    float* del_s = lse_s + NT;
+    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < NT * HD / 4; t += 512) {
+        const int row = t >> 4, c4 = t & 15;
+        reinterpret_cast<float4*>(Qs)[t] = reinterpret_cast<const float4*>(q + (size_t)bh * NT * HD)[t];
+        reinterpret_cast<float4*>(dOs)[t] =
+            *reinterpret_cast<const float4*>(dout + ((size_t)b * NT + row) * D + h * HD + c4 * 4);
+    }
+    if (tid < NT) {
+        lse_s[tid] = lse[(size_t)bh * NT + tid];
+        del_s[tid] = delta[(size_t)bh * NT + tid];
+    }
+    __syncthreads();
+    const int j = tid >> 1, hf = tid & 1;
+    const int jj = min(j, NT - 1);
+    float kv[32], vv[32], dk[32], dv[32];
+    const float* kp = k + ((size_t)bh * NT + jj) * HD + hf * 32;
+    const float* vp = v + ((size_t)bh * NT + jj) * HD + hf * 32;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { kv[d] = kp[d]; vv[d] = vp[d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < NT; ++i) {
+        const float* qi = Qs + i * HD + hf * 32;
+        const float* di = dOs + i * HD + hf * 32;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            s = fmaf(qi[d], kv[d], s);
+            dp = fmaf(di[d], vv[d], dp);
+        }
+        s += __shfl_xor(s, 1, 64);
+        dp += __shfl_xor(dp, 1, 64);
+        const float p = expf(s - lse_s[i]);
+        const float ds = p * (dp - del_s[i]);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            dv[d] = fmaf(p, di[d], dv[d]);
+            dk[d] = fmaf(ds, qi[d], dk[d]);
+        }
+    }
+    if (j < NT) {
+        float* op = dqkv + ((size_t)b * NT + j) * (3 * D) + h * HD + hf * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { op[D + d] = dk[d]; op[2 * D + d] = dv[d]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static int set_lds(const void* f, size_t bytes) {
+    DYT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
+                    hipStream_t s) {
+    const int grid = batch * NH;
+    if (precision == 0) {
+        const size_t lds = 2 * NT * HD * sizeof(float);
+        static bool once = false;
+        if (!once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; once = true; }
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid), dim3(256), lds, s, (const float*)q, (const float*)k,
+                           (const float*)v, (float*)out, lse);
+    } else {
+        const size_t lds = ROW_IMG + TR_IMG;
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(grid), dim3(256), lds, s, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (bf16*)out, lse);
+    }
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s) {
+    const int grid = batch * NH;
+    if (precision == 0) {
+        const size_t lds1 = 2 * NT * HD * sizeof(float);
+        const size_t lds2 = (2 * NT * HD + 2 * NT) * sizeof(float);
+        static bool once = false;
+        if (!once) {
+            if (set_lds((const void*)attn_bwd_dq_f32_kernel, lds1)) return -2;
+            if (set_lds((const void*)attn_bwd_dkv_f32_kernel, lds2)) return -2;
+            once = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3(grid), dim3(256), lds1, s, (const float*)q, (const float*)k,
+                           (const float*)v, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3(grid), dim3(512), lds2, s, (const float*)q, (const float*)k,
+                           (const float*)v, (const float*)dout, lse, delta, (float*)dqkv);
+    } else {
+        const size_t lds1 = 2 * ROW_IMG + TR_IMG;
+        const size_t lds2 = 2 * ROW_IMG + 2 * TR_IMG + 2 * NPAD * sizeof(float);
+        static bool once = false;
+        if (!once) {
+            if (set_lds((const void*)attn_bwd_dq_bf16_kernel, lds1)) return -2;
+            if (set_lds((const void*)attn_bwd_dkv_bf16_kernel, lds2)) return -2;
+            once = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(grid), dim3(256), lds1, s, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(grid), dim3(512), lds2, s, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dqkv);
+    }
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dyt

@@ -1,0 +1,95 @@
+// Internal shared definitions for libdyt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dyt {
+
+constexpr int D = 768;        // embed dim
+constexpr int NH = 12;        // heads
+constexpr int HD = 64;        // head dim
+constexpr int NT = 197;       // tokens per image (cls + 196 patches)
+constexpr int NP = 196;       // patch tokens
+constexpr int DM = 3072;      // MLP hidden
+constexpr int RP = 64;        // adapter bottleneck padded to one MFMA N-tile
+constexpr float LN_EPS = 1e-6f;
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <class T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// store 4 consecutive values
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
+    bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+// sigmoid exactly as 1/(1+exp(-x)) in fp32 (the form the reference's y_soft > 0.5 test sees)
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- Philox4x32-10 counter RNG (on-device Gumbel/logistic noise and dropout) ----
+struct Philox {
+    uint32_t c[4];
+    __device__ __forceinline__ Philox(uint64_t seed, uint64_t subseq, uint64_t offset) {
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        c[0] = (uint32_t)offset; c[1] = (uint32_t)(offset >> 32);
+        c[2] = (uint32_t)subseq; c[3] = (uint32_t)(subseq >> 32);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+            uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+            uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+            c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+    }
+    // uniform in (0,1)
+    __device__ __forceinline__ float u01(int i) const { return ((c[i] >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+};
+
+// error plumbing (host)
+void set_error(const char* fmt, ...);
+#define DYT_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            dyt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                   \
+        }                                                                                \
+    } while (0)
+
+}  // namespace dyt

@@ -1,0 +1,418 @@
+// Dense contractions of the DyT hot path for gfx950.
+//
+//   C[M,N] = A[M,K] @ W[N,K]^T  (+ fused epilogue)
+//
+// fast path  : bf16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//              128x128x64 (or 128x64x64) tile, 4 waves (2x2), operands staged HBM->LDS by
+//              LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring, one barrier per K step.
+//              LDS image per operand: [row][8 x 16B chunks], chunk slot XOR-swizzled with
+//              (row & 7) on the SOURCE address (the DMA destination is lane-linear), and the
+//              same XOR on the ds_read_b128 -- conflict-free for the 16x16x32 fragment read.
+//              The MFMA is issued with the W fragment as the A operand so that every lane ends
+//              up with 4 CONSECUTIVE output columns of one row (8/16-byte epilogue stores).
+// exact path : fp32 operands on the vector ALU (64x64x16 tile) -- the parity mode.
+//
+// Reference ops replaced: nn.Linear of Attention.qkv / .proj (models/vision_transformer_IN21K.py:56,73),
+// timm Mlp fc1/fc2 (:124-129,159), Adapter.down_proj/up_proj (models/dynamic_adapter.py:124-128),
+// PatchEmbed's Conv2d (:272-278) and their autograd dgrads.
+#include "kernels.h"
+
+namespace dyt {
+
+// ------------------------------------------------------------------------------------------
+// epilogues: operator()(row, col, v[4]) handles 4 consecutive columns of one output row
+// ------------------------------------------------------------------------------------------
+struct EpiBiasF32 {
+    const float* bias; float* out; int ld;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        if (bias) { b0 = bias[col]; b1 = bias[col + 1]; b2 = bias[col + 2]; b3 = bias[col + 3]; }
+        store4(out + (size_t)row * ld + col, a[0] + b0, a[1] + b1, a[2] + b2, a[3] + b3);
+    }
+};
+
+template <class AT>
+struct EpiQKV {
+    const float* bias; AT* q; AT* k; AT* v;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const int which = col / D;
+        const int c = col - which * D;
+        const int h = c >> 6, d = c & 63;
+        const int b = row / NT, n = row - b * NT;
+        const float s = which == 0 ? 0.125f : 1.0f;  // head_dim ** -0.5, exact in every dtype
+        AT* base = which == 0 ? q : (which == 1 ? k : v);
+        AT* dst = base + ((((size_t)b * NH + h) * NT + n) << 6) + d;
+        store4(dst, (a[0] + bias[col]) * s, (a[1] + bias[col + 1]) * s, (a[2] + bias[col + 2]) * s,
+               (a[3] + bias[col + 3]) * s);
+    }
+};
+
+template <class AT>
+struct EpiBiasResid {
+    const float* bias; const float* resid; float* out; AT* out_at; int ld;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const size_t o = (size_t)row * ld + col;
+        float r[4];
+        load4(resid + o, r);
+        const float v0 = a[0] + bias[col] + r[0], v1 = a[1] + bias[col + 1] + r[1];
+        const float v2 = a[2] + bias[col + 2] + r[2], v3 = a[3] + bias[col + 3] + r[3];
+        store4(out + o, v0, v1, v2, v3);
+        if (out_at) store4(out_at + o, v0, v1, v2, v3);
+    }
+};
+
+template <class AT>
+struct EpiFc1 {
+    const float* bias; AT* h; AT* z; int ld;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const size_t o = (size_t)row * ld + col;
+        const float z0 = a[0] + bias[col], z1 = a[1] + bias[col + 1], z2 = a[2] + bias[col + 2],
+                    z3 = a[3] + bias[col + 3];
+        if (z) store4(z + o, z0, z1, z2, z3);
+        store4(h + o, gelu_erf(z0), gelu_erf(z1), gelu_erf(z2), gelu_erf(z3));
+    }
+};
+
+struct EpiFc2 {
+    const float* bias; float* x; const int* row_map; const float* row_mask; float* h_out;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const int dst = row_map ? row_map[row] : row;
+        const float h0 = a[0] + bias[col], h1 = a[1] + bias[col + 1], h2 = a[2] + bias[col + 2],
+                    h3 = a[3] + bias[col + 3];
+        if (h_out) store4(h_out + (size_t)row * D + col, h0, h1, h2, h3);
+        const float m = row_mask ? row_mask[dst] : 1.0f;
+        float* p = x + (size_t)dst * D + col;
+        float r[4];
+        load4(p, r);
+        store4(p, r[0] + m * h0, r[1] + m * h1, r[2] + m * h2, r[3] + m * h3);
+    }
+};
+
+template <class AT>
+struct EpiGeluBwd {
+    const AT* z; AT* out; int ld;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const size_t o = (size_t)row * ld + col;
+        float zz[4];
+        load4(z + o, zz);
+        store4(out + o, a[0] * gelu_erf_grad(zz[0]), a[1] * gelu_erf_grad(zz[1]), a[2] * gelu_erf_grad(zz[2]),
+               a[3] * gelu_erf_grad(zz[3]));
+    }
+};
+
+struct EpiStoreF32 {
+    float* out; int ld; int accumulate;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        float* p = out + (size_t)row * ld + col;
+        if (accumulate) {
+            float r[4];
+            load4(p, r);
+            store4(p, r[0] + a[0], r[1] + a[1], r[2] + a[2], r[3] + a[3]);
+        } else {
+            store4(p, a[0], a[1], a[2], a[3]);
+        }
+    }
+};
+
+template <class AT>
+struct EpiStoreAT {
+    AT* out; int ld;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        store4(out + (size_t)row * ld + col, a[0], a[1], a[2], a[3]);
+    }
+};
+
+template <class AT>
+struct EpiAdDown {
+    const float* bias;  // padded to RP
+    AT* out;            // [M, RP]
+    const uint8_t* keep; int r; float inv_keep; float drop_p; uint64_t seed, subseq;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[i] + bias[col + i], 0.0f);
+        if (drop_p > 0.f) {
+            if (keep) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = (col + i < r && keep[(size_t)row * r + col + i]) ? v[i] * inv_keep : 0.0f;
+            } else {
+                Philox ph(seed, subseq, (uint64_t)row * (RP / 4) + (col >> 2));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ph.u01(i) >= drop_p ? v[i] * inv_keep : 0.0f;
+            }
+        }
+        store4(out + (size_t)row * RP + col, v[0], v[1], v[2], v[3]);
+    }
+};
+
+struct EpiAdUp {
+    const float* bias; const float* u; float* out; float scale;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const size_t o = (size_t)row * D + col;
+        float r[4];
+        load4(u + o, r);
+        store4(out + o, r[0] + scale * (a[0] + bias[col]), r[1] + scale * (a[1] + bias[col + 1]),
+               r[2] + scale * (a[2] + bias[col + 2]), r[3] + scale * (a[3] + bias[col + 3]));
+    }
+};
+
+template <class AT>
+struct EpiAdDgradUp {
+    const AT* dact; AT* out; float scale; float inv_keep;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const size_t o = (size_t)row * RP + col;
+        float d[4];
+        load4(dact + o, d);
+        const float s = scale * inv_keep;
+        store4(out + o, d[0] != 0.f ? a[0] * s : 0.f, d[1] != 0.f ? a[1] * s : 0.f, d[2] != 0.f ? a[2] * s : 0.f,
+               d[3] != 0.f ? a[3] * s : 0.f);
+    }
+};
+
+struct EpiEmbed {
+    const float* bias; const float* pos; float* x0;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const int b = row / NP, p = row - b * NP;
+        const size_t o = ((size_t)b * NT + 1 + p) * D + col;
+        const float* ps = pos + (size_t)(1 + p) * D + col;
+        store4(x0 + o, a[0] + bias[col] + ps[0], a[1] + bias[col + 1] + ps[1], a[2] + bias[col + 2] + ps[2],
+               a[3] + bias[col + 3] + ps[3]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, class Epi>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                           int M, int N, int K, const int* __restrict__ m_dev,
+                                                           Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // 1 KiB (8 rows) per wave-instruction
+
+    const int Mv = m_dev ? min(*m_dev, M) : M;
+    // XCD-aware block remap (bijective): consecutive logical tiles share an A row panel and
+    // should land on the same XCD's L2; hardware places block b on XCD b % 8.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int tiles_n = N / BN;
+    const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= Mv) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- staging: lane -> (row-in-8, 16B slot); source chunk = slot ^ row ----
+    const int lrow = lane >> 3, slot = lane & 7, chunk = slot ^ lrow;
+    const bf16* a_src[A_INSTR];
+    const bf16* b_src[B_INSTR];
+#pragma unroll
+    for (int t = 0; t < A_INSTR; ++t) {
+        const int row = (t * 4 + wave) * 8 + lrow;
+        const int grow = min(m0 + row, Mv - 1);
+        a_src[t] = A + (size_t)grow * K + chunk * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < B_INSTR; ++t) {
+        const int row = (t * 4 + wave) * 8 + lrow;
+        b_src[t] = W + (size_t)(n0 + row) * K + chunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int t = 0; t < A_INSTR; ++t)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[t] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(base + (t * 4 + wave) * 1024),
+                                             16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < B_INSTR; ++t)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[t] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (t * 4 + wave) * 1024),
+                                             16, 0, 0);
+    };
+
+    // ---- fragment read offsets: row = tilebase + (lane & 15), chunk = ks*4 + (lane >> 4) ----
+    const int frow = lane & 15;
+    const int fslot0 = ((lane >> 4)) ^ (lane & 7);
+    const int fslot1 = (4 + (lane >> 4)) ^ (lane & 7);
+    const int a_off = (wm * WM + frow) * 128;
+    const int b_off = A_BYTES + (wn * WN + frow) * 128;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* base = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+            bf16x8 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: acc[i][j][e] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + e] ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WM + i * 16 + frow;
+        if (row < Mv) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epi(row, col, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 exact kernel (vector ALU): 64x64x16 tile, 256 threads, 4x4 outputs per thread
+// ------------------------------------------------------------------------------------------
+template <class Epi>
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                          int M, int N, int K, const int* __restrict__ m_dev,
+                                                          Epi epi) {
+    constexpr int BM = 64, BN = 64, BK = 16;
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Ws[BK][BN + 4];
+    const int Mv = m_dev ? min(*m_dev, M) : M;
+    const int tiles_n = N / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= Mv) return;
+    const int tid = threadIdx.x;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row, k offset
+    const int ty = tid >> 4, tx = tid & 15;
+    const float* ap = A + (size_t)min(m0 + lr, Mv - 1) * K + lk;
+    const float* wp = W + (size_t)(n0 + lr) * K + lk;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + k0);
+        const float4 wv = *reinterpret_cast<const float4*>(wp + k0);
+        __syncthreads();
+        As[lk + 0][lr] = av.x; As[lk + 1][lr] = av.y; As[lk + 2][lr] = av.z; As[lk + 3][lr] = av.w;
+        Ws[lk + 0][lr] = wv.x; Ws[lk + 1][lr] = wv.y; Ws[lk + 2][lr] = wv.z; Ws[lk + 3][lr] = wv.w;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+            const float4 w4 = *reinterpret_cast<const float4*>(&Ws[k][tx * 4]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + ty * 4 + i;
+        if (row < Mv) epi(row, n0 + tx * 4, acc[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------
+template <class Epi>
+static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
+    const bf16* A = static_cast<const bf16*>(a.A);
+    const bf16* W = static_cast<const bf16*>(a.W);
+    if (a.N % 128 == 0) {
+        constexpr int BM = 128, BN = 128;
+        const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+        const size_t lds = 2 * (BM + BN) * 64 * 2;
+        auto kern = gemm_bf16_nt_kernel<BM, BN, Epi>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, epi);
+    } else if (a.N % 64 == 0) {
+        constexpr int BM = 128, BN = 64;
+        const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+        const size_t lds = 2 * (BM + BN) * 64 * 2;
+        auto kern = gemm_bf16_nt_kernel<BM, BN, Epi>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, epi);
+    } else {
+        set_error("gemm_bf16: N=%d must be a multiple of 64", a.N);
+        return -1;
+    }
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <class Epi>
+static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    if (a.K % 16 != 0 || a.N % 64 != 0 || a.M <= 0) {
+        set_error("gemm_f32: N=%d %% 64, K=%d %% 16 required, M=%d", a.N, a.K, a.M);
+        return -1;
+    }
+    const int grid = ((a.M + 63) / 64) * (a.N / 64);
+    hipLaunchKernelGGL((gemm_f32_nt_kernel<Epi>), dim3(grid), dim3(256), 0, s, static_cast<const float*>(a.A),
+                       static_cast<const float*>(a.W), a.M, a.N, a.K, a.m_dev, epi);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <class AT, class Epi>
+static int run(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    if constexpr (sizeof(AT) == 2) return run_bf16(a, epi, s);
+    else return run_f32(a, epi, s);
+}
+
+template <class AT>
+static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
+    switch (kind) {
+        case EPI_BIAS_F32: return run<AT>(a, EpiBiasF32{a.bias, a.out_f32, a.N}, s);
+        case EPI_QKV:
+            return run<AT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
+        case EPI_BIAS_RESID:
+            return run<AT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
+        case EPI_FC1: return run<AT>(a, EpiFc1<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
+        case EPI_FC2: return run<AT>(a, EpiFc2{a.bias, a.out_f32, a.row_map, a.row_mask, a.h_out}, s);
+        case EPI_GELU_BWD: return run<AT>(a, EpiGeluBwd<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.N}, s);
+        case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
+        case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
+        case EPI_AD_DOWN:
+            return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq}, s);
+        case EPI_AD_UP: return run<AT>(a, EpiAdUp{a.bias, a.resid, a.out_f32, a.scale}, s);
+        case EPI_AD_DGRAD_UP:
+            return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
+        case EPI_EMBED: return run<AT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
+    }
+    set_error("gemm: unknown epilogue %d", (int)kind);
+    return -1;
+}
+
+int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
+    return precision == 0 ? dispatch<float>(kind, a, s) : dispatch<bf16>(kind, a, s);
+}
+
+}  // namespace dyt

@@ -1,0 +1,194 @@
+// Host-callable kernel launchers of libdyt_hip.so (internal API between translation units).
+#pragma once
+#include "dyt_common.h"
+
+namespace dyt {
+
+// ------------------------------------------------------------------------------------------
+// GEMM family: C[M,N] = A[M,K] @ W[N,K]^T with a fused epilogue.  A and W are K-contiguous
+// (nn.Linear layout); dgrad uses a pre-transposed copy of the frozen weight, so every dense
+// contraction on the path is this one "NT" form.
+// ------------------------------------------------------------------------------------------
+enum EpiKind {
+    EPI_BIAS_F32 = 0,   // out_f32 = acc + bias                                   (generic nn.Linear)
+    EPI_QKV,            // +bias, q*0.125, scatter to q/k/v [B,12,197,64]          (Attention.qkv)
+    EPI_BIAS_RESID,     // out_f32 = acc + bias + resid ; optional AT copy          (Attention.proj + residual)
+    EPI_FC1,            // z = acc + bias -> out_at2 (optional) ; gelu(z) -> out_at (Mlp.fc1 + GELU)
+    EPI_FC2,            // h = acc + bias ; x[row_map[r]] += mask*h ; optional h save (Mlp.fc2 + scatter + residual)
+    EPI_GELU_BWD,       // out_at = acc * gelu'(z)                                  (dgrad through fc2, GELU)
+    EPI_STORE_F32,      // out_f32 (+)= acc
+    EPI_STORE_AT,       // out_at = acc
+    EPI_AD_DOWN,        // out_at = dropout(relu(acc + bias))                       (Adapter.down_proj)
+    EPI_AD_UP,          // out_f32 = resid + scale*(acc + bias)                     (Adapter.up_proj * scale + residual)
+    EPI_AD_DGRAD_UP,    // out_at = acc * scale * relu'/dropout mask                (dgrad through up_proj)
+    EPI_EMBED,          // x0[b*197+1+p] = acc + bias + pos[1+p]                    (PatchEmbed + pos_embed)
+};
+
+struct GemmArgs {
+    const void* A = nullptr;      // [M,K]  AT
+    const void* W = nullptr;      // [N,K]  AT
+    int M = 0, N = 0, K = 0;
+    const int* m_dev = nullptr;   // device-side count of valid rows (<= M), or null
+    const float* bias = nullptr;
+    float* out_f32 = nullptr;
+    void* out_at = nullptr;
+    void* out_at2 = nullptr;
+    void* out_at3 = nullptr;
+    const float* resid = nullptr;
+    const void* aux_at = nullptr;     // z (GELU_BWD) / d_act (AD_DGRAD_UP)
+    const int* row_map = nullptr;     // FC2 scatter: compact row -> token row
+    const float* row_mask = nullptr;  // FC2 masked-dense: per-token mask
+    float* h_out = nullptr;           // FC2: save h (fp32)
+    const uint8_t* keep = nullptr;    // AD_DOWN injected keep mask [M, r]
+    const float* pos = nullptr;       // EMBED
+    int r = 0;                        // adapter rank (columns >= r of the padded bottleneck are dead)
+    float scale = 1.f;
+    float inv_keep = 1.f;             // 1/(1-p) when training, else 1
+    float drop_p = 0.f;               // >0 : apply dropout (Philox when keep == null)
+    uint64_t seed = 0, subseq = 0;
+    int accumulate = 0;
+    double flops() const { return 2.0 * M * (double)N * K; }
+};
+
+int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// attention (N = 197, d = 64, 12 heads); q pre-scaled by 1/8 in the QKV epilogue
+// ------------------------------------------------------------------------------------------
+// q,k,v: [B*12][197][64] AT ; out: [B*197][768] AT ; lse: [B*12][197] f32
+int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
+                    int batch, hipStream_t s);
+// dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
+int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
+                    const void* dout, const float* lse, float* delta, void* dqkv, int batch, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// row-wise / small kernels
+// ------------------------------------------------------------------------------------------
+// LayerNorm over 768 channels, one wave per row; stats[row] = {mean, rstd}
+int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats,
+                  int rows, hipStream_t s);
+int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s);
+// dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
+int launch_ln_bwd(const float* dy, const float* x, const float2* stats, const float* w, const float* base,
+                  float* dx_out, int rows, hipStream_t s);
+
+struct GateArgs {
+    const float* u;          // [B*197,768] residual stream after attention
+    const float* w;          // [768]
+    const float* b;          // [1]
+    const float* g1;         // [B,196] or null
+    const float* g2;         // [B,196] or null
+    int batch;
+    int training;
+    float tau, threshold;
+    uint64_t seed, subseq;   // Philox stream when training && !g1
+    float* soft;             // [B*197] y_soft per token (cls slot unused) -- saved for backward
+    float* maskf;            // [B*197] hard mask per token as float (cls = 1)
+    float* out_select;       // user tensor [B,depth,196] (pointer already offset to this layer) or null
+    float* out_logits;       // idem
+    int out_stride;          // depth*196
+    int* keep_local;         // [B,197] kept token ids per image, ascending
+    int* counts;             // [B]
+};
+int launch_gate(const GateArgs& a, hipStream_t s);
+// offsets[b] = exclusive prefix of counts, total[0] = sum
+int launch_scan(const int* counts, int* offsets, int* total, int batch, hipStream_t s);
+// LN2 of the kept rows into the compact A operand; row_src[dst]=src token row, dst_of[src]=dst or -1
+int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
+                     const int* counts, const int* offsets, const float* maskf, void* out, float2* stats,
+                     int* row_src, int* dst_of, int batch, hipStream_t s);
+
+int launch_im2col(int precision, const float* images, void* out, int batch, hipStream_t s);
+int launch_cls_rows(const float* cls, const float* pos, float* x0, int batch, hipStream_t s);
+// fp32 -> AT copy (n elements)
+int launch_convert(int precision, const float* src, void* dst, int64_t n, hipStream_t s);
+// dst[c][r] = src[r][c]  (rows x cols fp32 -> AT, transposed), optional zero padding of dst rows/cols
+int launch_transpose_convert(int precision, const float* src, void* dst, int rows, int cols, int dst_rows,
+                             int dst_cols, hipStream_t s);
+// dst[dst_rows][dst_cols] (zero padded) = src[rows][cols]
+int launch_pad_convert(int precision, const float* src, void* dst, int rows, int cols, int dst_rows,
+                       int dst_cols, hipStream_t s);
+
+// head: final LayerNorm on the cls rows + Linear(768, C)
+int launch_head_fwd(const float* x, const float* nw, const float* nb, const float* hw, const float* hb,
+                    float* cls_n, float2* stats, float* logits, int batch, int C, hipStream_t s);
+// g (all rows) = 0 except cls rows = LNbwd(dlogits @ Wh); dWh += dlogits^T cls_n ; dbh += colsum(dlogits)
+int launch_head_bwd(const float* dlogits, const float* x, const float* cls_n, const float2* stats,
+                    const float* nw, const float* hw, float* g, float* dWh, float* dbh, int batch, int C,
+                    hipStream_t s);
+
+struct LossArgs {
+    const float* logits_s; const float* logits_t; const int64_t* targets;
+    const int* counts;      // [depth*B] kept tokens per (layer,image) incl. cls, student pass
+    int batch, C, depth;
+    float target_ratio, loss_ratio, token_minimal, token_minimal_weight;
+    float* dlogits_s; float* dlogits_t; float* out_losses; float* dtok;
+};
+int launch_loss(const LossArgs& a, hipStream_t s);
+
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                 float eps, float wd, float bc1, float bc2, float gscale, hipStream_t s);
+
+// backward prep for one block: g_at = AT(g) ; dH[dst_of[t]] = AT(g[t] * mask) ;
+// dmask[token] = <g[token], h[r]> for kept rows (0 elsewhere)
+struct BwdPrepArgs {
+    const float* g;         // [M,768]
+    const float* h;         // [K,768] saved MLP output (null: no gate gradient, e.g. teacher pass)
+    const int* dst_of;      // [M] token -> compact row (-1 = dropped), or null (dense: identity)
+    const float* row_mask;  // masked-dense mode: per token mask (dH = mask*g), else null
+    void* g_at;             // [M,768] AT (null when AT == float: g itself is used)
+    void* dH;               // [K,768] AT (null when dense and unmasked: g_at / g is used)
+    float* dmask;           // [M] (zero-filled by the kernel for rows it does not own)
+    int M;
+};
+int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s);
+
+// per-token tail of a block's backward:
+//   du[t] = du[t] + LN2bwd(dA2[dst_of[t]]) (kept tokens) + dlogit[t]*wg ; du_at = AT(du)
+//   dlogit = (dmask[t] + dm_ext) * s(1-s)/tau + dtoken_logits ; partial dwg / dbg per block of rows
+struct TokBwdArgs {
+    float* du;                 // [M,768] in/out (holds g + adapter dgrad on entry)
+    const float* dA2;          // [K,768] gradient w.r.t. LN2 output (null: skip MLP part)
+    const int* dst_of;         // [M] compact row of a token or -1 ; null = identity (dense)
+    const float* u;            // [M,768]
+    const float2* stats2;      // [M]
+    const float* ln2_w;
+    const float* gate_w;       // [768] (null: no gate backward, e.g. teacher pass)
+    const float* soft;         // [M] y_soft
+    const float* maskf;        // [M]
+    const float* dmask;        // [M] <g,h>
+    const float* dtoken_select;  // user gradient (pointer offset to this layer, stride out_stride) or null
+    const float* dtoken_logits;  // idem or null
+    const float* dtok;           // device float[3] uniform terms or null
+    int out_stride;
+    int training;              // eval: y_soft = sigmoid(logit), same derivative form with tau = 1
+    float tau;
+    void* du_at;               // AT copy of du (null when AT == float or not needed)
+    float* partial;            // [nblocks][769] dwg / dbg partials
+    int M;
+    int write_du;              // 0 for block 0 (du itself is not needed)
+};
+int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
+// out[i] += alpha * sum_p partial[p*stride + i], i < n
+int launch_reduce_partials(const float* partial, int nparts, int stride, float* out, int n, float alpha,
+                           hipStream_t s);
+
+// wgrad: C[c][j] = sum_m X[m][c] * Y[m][j] (X [M,768] AT, Y [M,64] AT) via per-chunk partials;
+//   out_w[c*sc + j*sj] += alpha * C[c][j]  (j < r) ;  out_xsum[c] += alpha_x * sum_m X[m][c] (optional)
+struct WgradArgs {
+    const void* X; const void* Y; int M; int r;
+    float* partial;            // scratch [nchunks][768][80]
+    float* out_w; int sc, sj; float alpha;
+    float* out_xsum; float alpha_x;
+};
+int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s);
+// out[j] += alpha * sum_m Y[m][j], j < r  (Y [M,64] AT)
+int launch_colsum64(int precision, const void* Y, int M, int r, float* out, float alpha, hipStream_t s);
+
+int launch_fill_f32(float* p, float v, int64_t n, hipStream_t s);
+int launch_iota(int* p, int n, hipStream_t s);
+
+inline size_t at_size(int precision) { return precision == 0 ? 4 : 2; }
+
+}  // namespace dyt

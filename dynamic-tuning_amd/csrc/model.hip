@@ -1,0 +1,815 @@
+// libdyt_hip.so: context, whole-model forward / backward orchestration and the C ABI
+// declared in include/dyt_hip.h.  Host side only enqueues kernels on the caller's stream: no
+// host<->device synchronisation, no allocation after dyt_ctx_create, kept-token counts stay on
+// the device (GEMM grids are sized for the dense case and tiles beyond the device-side row count
+// exit immediately), so a step is graph-capturable.
+//
+// Mirrors (paths relative to the reference root):
+//   VisionTransformer.forward_features/forward_head  models/vision_transformer_IN21K.py:343-385
+//   Block.forward                                    models/vision_transformer_IN21K.py:144-165
+//   compacted MLP                                    models/model_speed_test.py:274-310
+//   step body                                        engine_finetune.py:47-79
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dyt_hip.h"
+#include "kernels.h"
+
+namespace dyt {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// small kernels private to this file
+// ------------------------------------------------------------------------------------------
+// Per-step refresh of the adapter weights in the layouts / dtype the GEMMs want:
+//   down_w  [RP,768] (rows >= r zero)      forward down-projection (N = RP, K = 768)
+//   down_wT [768,RP]                       dgrad through down_proj (N = 768, K = RP)
+//   up_w    [768,RP] (cols >= r zero)      forward up-projection   (N = 768, K = RP)
+//   up_wT   [RP,768]                       dgrad through up_proj   (N = RP, K = 768)
+//   down_b  [RP] fp32
+template <class AT>
+__global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t layer_stride, int64_t off_dw, int64_t off_db,
+                                     int64_t off_uw, int r, AT* __restrict__ down_w, AT* __restrict__ down_wT,
+                                     AT* __restrict__ up_w, AT* __restrict__ up_wT, float* __restrict__ down_b) {
+    const int l = blockIdx.y;
+    const float* base = flat + (int64_t)l * layer_stride;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    constexpr int SZ = RP * D;
+    if (idx >= SZ) return;
+    {   // idx -> (j, c) of [RP,768]
+        const int j = idx / D, c = idx - j * D;
+        const float dw = j < r ? base[off_dw + (int64_t)j * D + c] : 0.f;   // down_proj.weight [r,768]
+        const float uw = j < r ? base[off_uw + (int64_t)c * r + j] : 0.f;   // up_proj.weight [768,r]
+        down_w[(size_t)l * SZ + idx] = from_f32<AT>(dw);
+        up_wT[(size_t)l * SZ + idx] = from_f32<AT>(uw);
+    }
+    {   // idx -> (c, j) of [768,RP]
+        const int c = idx / RP, j = idx - c * RP;
+        const float dw = j < r ? base[off_dw + (int64_t)j * D + c] : 0.f;
+        const float uw = j < r ? base[off_uw + (int64_t)c * r + j] : 0.f;
+        down_wT[(size_t)l * SZ + idx] = from_f32<AT>(dw);
+        up_w[(size_t)l * SZ + idx] = from_f32<AT>(uw);
+    }
+    if (idx < RP) down_b[l * RP + idx] = idx < r ? base[off_db + idx] : 0.f;
+}
+
+template <class AT>
+__global__ void qkv_split_kernel(const float* __restrict__ qkv, AT* __restrict__ q, AT* __restrict__ k, AT* __restrict__ v,
+                                 int batch) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)batch * NT * 3 * D) return;
+    const int col = (int)(idx % (3 * D));
+    const size_t row = idx / (3 * D);
+    const int b = (int)(row / NT), n = (int)(row % NT);
+    const int which = col / D, c = col % D, h = c >> 6, d = c & 63;
+    const float val = qkv[idx] * (which == 0 ? 0.125f : 1.0f);
+    AT* dst = which == 0 ? q : (which == 1 ? k : v);
+    dst[(((size_t)b * NH + h) * NT + n) * HD + d] = from_f32<AT>(val);
+}
+template <class AT>
+__global__ void to_f32_kernel(const AT* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = to_f32(src[i]);
+}
+
+}  // namespace dyt
+
+using namespace dyt;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct LayerW {  // frozen, library-owned
+    float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;
+    void *qkv_w, *qkv_wT, *proj_w, *proj_wT, *fc1_w, *fc1_wT, *fc2_w, *fc2_wT;
+};
+struct LayerS {  // saved activations of one pass
+    float2 *st1, *st2;
+    void *q, *k, *v, *attn_o, *u_at, *z, *d_act;
+    float *lse, *u, *soft, *maskf, *h;
+    int *keep_local, *offsets, *total, *row_src, *dst_of;
+};
+struct Slot {
+    std::vector<LayerS> L;
+    std::vector<float*> xs;  // depth+1 residual-stream snapshots
+    int* counts = nullptr;   // [depth*B]
+    float* cls_n = nullptr;
+    float2* head_stats = nullptr;
+    int batch = 0, flags = 0;
+    bool valid = false;
+    const float* trainable = nullptr;  // flat trainable buffer the saved pass was computed with
+};
+struct ProfRec { int cat; double flops; hipEvent_t a, b; };
+
+struct dyt_ctx {
+    dyt_config cfg;
+    int prec;
+    size_t at;  // bytes per activation element
+    char* arena = nullptr;
+    size_t arena_size = 0, arena_used = 0;
+    // frozen
+    float *cls, *pos, *pe_b, *norm_w, *norm_b;
+    void* pe_w;
+    std::vector<LayerW> W;
+    // per-step AT copies of the adapters (all layers contiguous)
+    void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
+    float* ad_down_b;
+    // trainable flat layout
+    int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
+    std::vector<Slot> slots;
+    // transients
+    void *xn, *h1, *g_at, *dH, *dZ, *ddz, *du_at, *dO, *dqkv;
+    float *g, *dA2, *dxn, *delta, *dmask, *tok_partial, *wg_partial;
+    float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <class T>
+static T* carve(dyt_ctx* c, size_t count, bool dry) {
+    const size_t bytes = align_up(count * sizeof(T), 256);
+    T* p = dry ? nullptr : reinterpret_cast<T*>(c->arena + c->arena_used);
+    c->arena_used += bytes;
+    return p;
+}
+static void* carve_at(dyt_ctx* c, size_t count, bool dry) {
+    const size_t bytes = align_up(count * c->at, 256);
+    void* p = dry ? nullptr : c->arena + c->arena_used;
+    c->arena_used += bytes;
+    return p;
+}
+
+static void layout(dyt_ctx* c, bool dry) {
+    const dyt_config& cf = c->cfg;
+    const size_t B = cf.max_batch, M = B * NT, depth = cf.depth, C = cf.num_classes;
+    c->arena_used = 0;
+    c->cls = carve<float>(c, D, dry);
+    c->pos = carve<float>(c, NT * D, dry);
+    c->pe_b = carve<float>(c, D, dry);
+    c->norm_w = carve<float>(c, D, dry);
+    c->norm_b = carve<float>(c, D, dry);
+    c->pe_w = carve_at(c, (size_t)D * D, dry);
+    c->W.resize(depth);
+    for (size_t l = 0; l < depth; ++l) {
+        LayerW& w = c->W[l];
+        w.ln1_w = carve<float>(c, D, dry); w.ln1_b = carve<float>(c, D, dry);
+        w.ln2_w = carve<float>(c, D, dry); w.ln2_b = carve<float>(c, D, dry);
+        w.qkv_b = carve<float>(c, 3 * D, dry); w.proj_b = carve<float>(c, D, dry);
+        w.fc1_b = carve<float>(c, DM, dry); w.fc2_b = carve<float>(c, D, dry);
+        w.qkv_w = carve_at(c, (size_t)3 * D * D, dry); w.qkv_wT = carve_at(c, (size_t)3 * D * D, dry);
+        w.proj_w = carve_at(c, (size_t)D * D, dry); w.proj_wT = carve_at(c, (size_t)D * D, dry);
+        w.fc1_w = carve_at(c, (size_t)DM * D, dry); w.fc1_wT = carve_at(c, (size_t)DM * D, dry);
+        w.fc2_w = carve_at(c, (size_t)DM * D, dry); w.fc2_wT = carve_at(c, (size_t)DM * D, dry);
+    }
+    c->ad_down_w = carve_at(c, depth * RP * D, dry);
+    c->ad_down_wT = carve_at(c, depth * RP * D, dry);
+    c->ad_up_w = carve_at(c, depth * RP * D, dry);
+    c->ad_up_wT = carve_at(c, depth * RP * D, dry);
+    c->ad_down_b = carve<float>(c, depth * RP, dry);
+    c->slots.resize(cf.slots);
+    for (int s = 0; s < cf.slots; ++s) {
+        Slot& S = c->slots[s];
+        S.L.resize(depth);
+        S.xs.resize(depth + 1);
+        for (size_t l = 0; l <= depth; ++l) S.xs[l] = carve<float>(c, M * D, dry);
+        S.counts = carve<int>(c, depth * B, dry);
+        S.cls_n = carve<float>(c, B * D, dry);
+        S.head_stats = carve<float2>(c, B, dry);
+        for (size_t l = 0; l < depth; ++l) {
+            LayerS& L = S.L[l];
+            L.st1 = carve<float2>(c, M, dry); L.st2 = carve<float2>(c, M, dry);
+            L.q = carve_at(c, M * D, dry); L.k = carve_at(c, M * D, dry); L.v = carve_at(c, M * D, dry);
+            L.attn_o = carve_at(c, M * D, dry);
+            L.lse = carve<float>(c, B * NH * NT, dry);
+            L.u = carve<float>(c, M * D, dry);
+            L.u_at = c->prec == 0 ? (void*)L.u : carve_at(c, M * D, dry);
+            L.z = carve_at(c, M * DM, dry);
+            L.d_act = carve_at(c, M * RP, dry);
+            L.h = carve<float>(c, M * D, dry);
+            L.soft = carve<float>(c, M, dry); L.maskf = carve<float>(c, M, dry);
+            L.keep_local = carve<int>(c, M, dry); L.offsets = carve<int>(c, B, dry);
+            L.total = carve<int>(c, 4, dry); L.row_src = carve<int>(c, M, dry); L.dst_of = carve<int>(c, M, dry);
+        }
+    }
+    c->xn = carve_at(c, M * D, dry);
+    c->h1 = carve_at(c, M * DM, dry);
+    c->g_at = carve_at(c, M * D, dry);
+    c->dH = carve_at(c, M * D, dry);
+    c->dZ = carve_at(c, M * DM, dry);
+    c->ddz = carve_at(c, M * RP, dry);
+    c->du_at = carve_at(c, M * D, dry);
+    c->dO = carve_at(c, M * D, dry);
+    c->dqkv = carve_at(c, M * 3 * D, dry);
+    c->g = carve<float>(c, M * D, dry);
+    c->dA2 = carve<float>(c, M * D, dry);
+    c->dxn = carve<float>(c, M * D, dry);
+    c->delta = carve<float>(c, B * NH * NT, dry);
+    c->dmask = carve<float>(c, M, dry);
+    c->tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
+    c->wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)D * 80, dry);
+    c->dl_s = carve<float>(c, B * C, dry); c->dl_t = carve<float>(c, B * C, dry);
+    c->logits_s = carve<float>(c, B * C, dry); c->logits_t = carve<float>(c, B * C, dry);
+    c->dtok = carve<float>(c, 4, dry);
+    c->losses = carve<float>(c, 8, dry);
+}
+
+static void trainable_layout(dyt_ctx* c) {
+    const int64_t r = c->cfg.ffn_num, C = c->cfg.num_classes;
+    auto a4 = [](int64_t v) { return (v + 3) / 4 * 4; };
+    int64_t o = 0;
+    c->off_dw = o; o = a4(o + r * D);
+    c->off_db = o; o = a4(o + r);
+    c->off_uw = o; o = a4(o + (int64_t)D * r);
+    c->off_ub = o; o = a4(o + D);
+    c->off_gw = o; o += D;       // gate weight and bias stay adjacent (one 769-wide reduction)
+    c->off_gb = o; o = a4(o + 1);
+    c->layer_stride = o;
+    o = c->layer_stride * c->cfg.depth;
+    c->off_hw = o; o = a4(o + C * D);
+    c->off_hb = o; o = a4(o + C);
+    c->n_train = o;
+}
+
+extern "C" const char* dyt_last_error(void) { return g_err; }
+extern "C" int dyt_version(void) { return 1; }
+
+extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
+    if (!cfg || !out) { set_error("null argument"); return DYT_ERR_ARG; }
+    if (cfg->ffn_num < 1 || cfg->ffn_num > RP || cfg->depth < 1 || cfg->depth > 64 || cfg->max_batch < 1 ||
+        cfg->num_classes < 1 || cfg->num_classes > 1024 || cfg->slots < 1 || cfg->slots > 4 ||
+        (cfg->precision != DYT_PREC_FP32 && cfg->precision != DYT_PREC_BF16)) {
+        set_error("unsupported config: ffn_num=%d (1..64) depth=%d max_batch=%d num_classes=%d (1..1024) slots=%d precision=%d",
+                  cfg->ffn_num, cfg->depth, cfg->max_batch, cfg->num_classes, cfg->slots, cfg->precision);
+        return DYT_ERR_ARG;
+    }
+    int ndev = 0;
+    DYT_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) { set_error("no HIP device"); return DYT_ERR_HIP; }
+    dyt_ctx* c = new dyt_ctx();
+    c->cfg = *cfg;
+    c->prec = cfg->precision;
+    c->at = at_size(c->prec);
+    trainable_layout(c);
+    layout(c, true);
+    c->arena_size = c->arena_used;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->arena), c->arena_size);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", c->arena_size, hipGetErrorString(e));
+        delete c;
+        return DYT_ERR_HIP;
+    }
+    layout(c, false);
+    e = hipMemset(c->arena, 0, c->arena_size);
+    if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); hipFree(c->arena); delete c; return DYT_ERR_HIP; }
+    *out = c;
+    return DYT_OK;
+}
+
+extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
+    if (!c) return DYT_OK;
+    for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto e : c->pool) hipEventDestroy(e);
+    if (c->arena) hipFree(c->arena);
+    delete c;
+    return DYT_OK;
+}
+
+extern "C" int dyt_ctx_bytes(const dyt_ctx* c, int64_t* bytes) {
+    if (!c || !bytes) { set_error("null argument"); return DYT_ERR_ARG; }
+    *bytes = (int64_t)c->arena_size;
+    return DYT_OK;
+}
+
+extern "C" int dyt_trainable_numel(const dyt_ctx* c, int64_t* n) {
+    if (!c || !n) { set_error("null argument"); return DYT_ERR_ARG; }
+    *n = c->n_train;
+    return DYT_OK;
+}
+
+extern "C" int dyt_trainable_offset(const dyt_ctx* c, int param, int layer, int64_t* off, int64_t* numel) {
+    if (!c || !off || !numel) { set_error("null argument"); return DYT_ERR_ARG; }
+    const int64_t r = c->cfg.ffn_num, C = c->cfg.num_classes;
+    const int64_t base = (int64_t)layer * c->layer_stride;
+    if (param >= DYT_P_AD_DOWN_W && param <= DYT_P_GATE_B && (layer < 0 || layer >= c->cfg.depth)) {
+        set_error("layer %d out of range", layer);
+        return DYT_ERR_ARG;
+    }
+    switch (param) {
+        case DYT_P_AD_DOWN_W: *off = base + c->off_dw; *numel = r * D; break;
+        case DYT_P_AD_DOWN_B: *off = base + c->off_db; *numel = r; break;
+        case DYT_P_AD_UP_W: *off = base + c->off_uw; *numel = D * r; break;
+        case DYT_P_AD_UP_B: *off = base + c->off_ub; *numel = D; break;
+        case DYT_P_GATE_W: *off = base + c->off_gw; *numel = D; break;
+        case DYT_P_GATE_B: *off = base + c->off_gb; *numel = 1; break;
+        case DYT_P_HEAD_W: *off = c->off_hw; *numel = C * D; break;
+        case DYT_P_HEAD_B: *off = c->off_hb; *numel = C; break;
+        default: set_error("param %d is not trainable", param); return DYT_ERR_ARG;
+    }
+    return DYT_OK;
+}
+
+// weight [N,K] fp32 -> AT copy and transposed AT copy [K,N]
+static int set_matrix(dyt_ctx* c, const float* src, void* w, void* wT, int N, int K, hipStream_t s) {
+    int rc = launch_pad_convert(c->prec, src, w, N, K, N, K, s);
+    if (rc) return rc;
+    if (wT) rc = launch_transpose_convert(c->prec, src, wT, N, K, K, N, s);
+    return rc;
+}
+static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
+    DYT_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src, void* stream) {
+    if (!c || !src) { set_error("null argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool per_layer = param >= DYT_P_LN1_W && param <= DYT_P_FC2_B;
+    if (per_layer && (layer < 0 || layer >= c->cfg.depth)) { set_error("layer %d out of range", layer); return DYT_ERR_ARG; }
+    LayerW* w = per_layer ? &c->W[layer] : nullptr;
+    switch (param) {
+        case DYT_P_CLS: return copy_f32(c->cls, src, D, s);
+        case DYT_P_POS: return copy_f32(c->pos, src, (size_t)NT * D, s);
+        case DYT_P_PE_W: return set_matrix(c, src, c->pe_w, nullptr, D, D, s);  // [768, 3*16*16]
+        case DYT_P_PE_B: return copy_f32(c->pe_b, src, D, s);
+        case DYT_P_LN1_W: return copy_f32(w->ln1_w, src, D, s);
+        case DYT_P_LN1_B: return copy_f32(w->ln1_b, src, D, s);
+        case DYT_P_QKV_W: return set_matrix(c, src, w->qkv_w, w->qkv_wT, 3 * D, D, s);
+        case DYT_P_QKV_B: return copy_f32(w->qkv_b, src, 3 * D, s);
+        case DYT_P_PROJ_W: return set_matrix(c, src, w->proj_w, w->proj_wT, D, D, s);
+        case DYT_P_PROJ_B: return copy_f32(w->proj_b, src, D, s);
+        case DYT_P_LN2_W: return copy_f32(w->ln2_w, src, D, s);
+        case DYT_P_LN2_B: return copy_f32(w->ln2_b, src, D, s);
+        case DYT_P_FC1_W: return set_matrix(c, src, w->fc1_w, w->fc1_wT, DM, D, s);
+        case DYT_P_FC1_B: return copy_f32(w->fc1_b, src, DM, s);
+        case DYT_P_FC2_W: return set_matrix(c, src, w->fc2_w, w->fc2_wT, D, DM, s);
+        case DYT_P_FC2_B: return copy_f32(w->fc2_b, src, D, s);
+        case DYT_P_NORM_W: return copy_f32(c->norm_w, src, D, s);
+        case DYT_P_NORM_B: return copy_f32(c->norm_b, src, D, s);
+        default: set_error("param %d is not a frozen parameter", param); return DYT_ERR_ARG;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// profiling helpers
+// ------------------------------------------------------------------------------------------
+static hipEvent_t get_event(dyt_ctx* c) {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    dyt_ctx* c; hipStream_t s; ProfRec r; bool on;
+    ProfScope(dyt_ctx* c_, hipStream_t s_, int cat, double flops) : c(c_), s(s_), on(c_->prof) {
+        if (on) { r.cat = cat; r.flops = flops; r.a = get_event(c); r.b = get_event(c); hipEventRecord(r.a, s); }
+    }
+    ~ProfScope() { if (on) { hipEventRecord(r.b, s); c->recs.push_back(r); } }
+};
+#define RUN(cat, flops, call)                  \
+    do {                                       \
+        ProfScope _ps(c, s, (cat), (flops));   \
+        int _rc = (call);                      \
+        if (_rc) return _rc;                   \
+    } while (0)
+
+extern "C" int dyt_profile_enable(dyt_ctx* c, int on) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    c->prof = on != 0;
+    return DYT_OK;
+}
+extern "C" int dyt_profile_read(dyt_ctx* c, int category, double* ms, int64_t* launches, double* flops) {
+    if (!c || !ms || !launches || !flops) { set_error("null argument"); return DYT_ERR_ARG; }
+    DYT_HIP_CHECK(hipDeviceSynchronize());
+    double t = 0, f = 0;
+    int64_t n = 0;
+    std::vector<ProfRec> keep;
+    for (auto& r : c->recs) {
+        if (r.cat != category) { keep.push_back(r); continue; }
+        float e = 0.f;
+        hipEventElapsedTime(&e, r.a, r.b);
+        t += e; f += r.flops; ++n;
+        c->pool.push_back(r.a); c->pool.push_back(r.b);
+    }
+    c->recs.swap(keep);
+    *ms = t; *launches = n; *flops = f;
+    return DYT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
+    const dim3 grid((RP * D + 255) / 256, c->cfg.depth);
+    if (c->prec == 0)
+        hipLaunchKernelGGL(prep_adapters_kernel<float>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
+                           c->off_uw, c->cfg.ffn_num, (float*)c->ad_down_w, (float*)c->ad_down_wT, (float*)c->ad_up_w,
+                           (float*)c->ad_up_wT, c->ad_down_b);
+    else
+        hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
+                           c->off_uw, c->cfg.ffn_num, (bf16*)c->ad_down_w, (bf16*)c->ad_down_wT, (bf16*)c->ad_up_w,
+                           (bf16*)c->ad_up_wT, c->ad_down_b);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
+
+static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int flags, const float* trainable,
+                        const float* g1, const float* g2, const uint8_t* keep_mask, uint64_t seed, float* logits,
+                        float* token_select, float* token_logits, bool do_prep, hipStream_t s) {
+    if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
+    if (B < 1 || B > c->cfg.max_batch) { set_error("batch %d exceeds max_batch %d", B, c->cfg.max_batch); return DYT_ERR_ARG; }
+    if (!images || !trainable || !logits) { set_error("null argument"); return DYT_ERR_ARG; }
+    if ((g1 == nullptr) != (g2 == nullptr)) { set_error("g1 and g2 must be given together"); return DYT_ERR_ARG; }
+    const int P = c->prec, depth = c->cfg.depth, M = B * NT, r = c->cfg.ffn_num;
+    const bool training = flags & DYT_F_TRAINING, complete = flags & DYT_F_COMPLETE, save = flags & DYT_F_SAVE;
+    const bool masked_dense = (flags & DYT_F_MASKED_DENSE) && !complete;
+    const bool dense = complete || masked_dense;
+    const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
+    const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
+    Slot& S = c->slots[slot];
+    S.valid = false;
+    if (do_prep) { int rc = prep_adapters(c, trainable, s); if (rc) return rc; }
+
+    // patch embedding: im2col + GEMM (+bias +pos_embed), cls rows
+    RUN(2, 0, launch_im2col(P, images, c->xn, B, s));
+    {
+        GemmArgs a; a.A = c->xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
+        a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0];
+        RUN(0, a.flops(), launch_gemm(P, EPI_EMBED, a, s));
+    }
+    RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
+
+    for (int l = 0; l < depth; ++l) {
+        const LayerW& W = c->W[l];
+        LayerS& L = S.L[l];
+        const float* base = trainable + (int64_t)l * c->layer_stride;
+        float* x = S.xs[l];
+        float* xo = S.xs[l + 1];
+        RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, c->xn, L.st1, M, s));
+        {
+            GemmArgs a; a.A = c->xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
+            a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
+            RUN(0, a.flops(), launch_gemm(P, EPI_QKV, a, s));
+        }
+        RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
+        {
+            GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
+            a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
+            RUN(0, a.flops(), launch_gemm(P, EPI_BIAS_RESID, a, s));
+        }
+        int* counts = S.counts + (size_t)l * B;
+        if (use_gate) {
+            GateArgs ga;
+            ga.u = L.u; ga.w = base + c->off_gw; ga.b = base + c->off_gb;
+            ga.g1 = g1 ? g1 + (size_t)l * B * NP : nullptr;
+            ga.g2 = g2 ? g2 + (size_t)l * B * NP : nullptr;
+            ga.batch = B; ga.training = training; ga.tau = c->cfg.tau; ga.threshold = c->cfg.threshold;
+            ga.seed = seed; ga.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2);
+            ga.soft = L.soft; ga.maskf = L.maskf;
+            ga.out_select = token_select ? token_select + (size_t)l * NP : nullptr;
+            ga.out_logits = token_logits ? token_logits + (size_t)l * NP : nullptr;
+            ga.out_stride = depth * NP;
+            ga.keep_local = L.keep_local; ga.counts = counts;
+            RUN(2, 0, launch_gate(ga, s));
+        }
+        if (!dense) {
+            RUN(2, 0, launch_scan(counts, L.offsets, L.total, B, s));
+            RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.offsets, L.maskf, c->xn, L.st2,
+                                       L.row_src, L.dst_of, B, s));
+        } else {
+            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, c->xn, L.st2, M, s));
+        }
+        // adapter (all tokens): x_out = u + scale * up(dropout(relu(down(u))))
+        {
+            GemmArgs a; a.A = L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
+            a.bias = c->ad_down_b + l * RP; a.out_at = L.d_act; a.r = r; a.drop_p = drop_p;
+            a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+            a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
+            a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1);
+            RUN(0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
+        }
+        {
+            GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
+            a.bias = base + c->off_ub; a.resid = L.u; a.out_f32 = xo; a.scale = c->cfg.adapter_scale;
+            RUN(0, a.flops(), launch_gemm(P, EPI_AD_UP, a, s));
+        }
+        // MLP on the kept (or all) tokens, scatter-add into the residual stream
+        const int* kdev = dense ? nullptr : L.total;
+        {
+            GemmArgs a; a.A = c->xn; a.W = W.fc1_w; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
+            a.out_at = c->h1; a.out_at2 = save ? L.z : nullptr;
+            RUN(0, a.flops(), launch_gemm(P, EPI_FC1, a, s));
+        }
+        {
+            GemmArgs a; a.A = c->h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
+            a.out_f32 = xo; a.row_map = dense ? nullptr : L.row_src; a.row_mask = masked_dense ? L.maskf : nullptr;
+            a.h_out = (save && !complete) ? L.h : nullptr;
+            RUN(0, a.flops(), launch_gemm(P, EPI_FC2, a, s));
+        }
+    }
+    RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
+                              S.head_stats, logits, B, c->cfg.num_classes, s));
+    S.batch = B; S.flags = flags; S.valid = save; S.trainable = trainable;
+    return DYT_OK;
+}
+
+extern "C" int dyt_forward(dyt_ctx* c, int slot, const float* images, int batch, int flags, const float* trainable,
+                           const float* g1, const float* g2, const uint8_t* keep_mask, uint64_t seed, float* logits,
+                           float* token_select, float* token_logits, void* stream) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    return forward_impl(c, slot, images, batch, flags, trainable, g1, g2, keep_mask, seed, logits, token_select,
+                        token_logits, true, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const float* dlogits, const float* dtoken_select,
+                         const float* dtok, const float* dtoken_logits, float* grad, hipStream_t s) {
+    if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
+    Slot& S = c->slots[slot];
+    if (!S.valid) { set_error("slot %d holds no saved forward (call dyt_forward with DYT_F_SAVE)", slot); return DYT_ERR_STATE; }
+    if (!dlogits || !grad || !trainable) { set_error("null argument"); return DYT_ERR_ARG; }
+    const int P = c->prec, depth = c->cfg.depth, B = S.batch, M = B * NT, r = c->cfg.ffn_num;
+    const int flags = S.flags;
+    const bool training = flags & DYT_F_TRAINING, complete = flags & DYT_F_COMPLETE;
+    const bool masked_dense = (flags & DYT_F_MASKED_DENSE) && !complete;
+    const bool dense = complete || masked_dense;
+    const bool student = !complete;
+    const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const float scale = c->cfg.adapter_scale;
+    float* g = c->g;
+
+    RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw, g,
+                              grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes, s));
+
+    for (int l = depth - 1; l >= 0; --l) {
+        const LayerW& W = c->W[l];
+        LayerS& L = S.L[l];
+        const float* base = trainable + (int64_t)l * c->layer_stride;
+        float* gbase = grad + (int64_t)l * c->layer_stride;
+        const bool first = l == 0;
+        const int* kdev = dense ? nullptr : L.total;
+
+        // ---- 1. prep: AT copy of g, gathered/masked MLP gradient rows, <g,h> per token ----
+        const bool need_dH = !dense || masked_dense;
+        void* g_at = P == 0 ? nullptr : c->g_at;
+        if (g_at || need_dH || student) {
+            BwdPrepArgs a;
+            a.g = g; a.h = student ? L.h : nullptr; a.dst_of = dense ? nullptr : L.dst_of;
+            a.row_mask = masked_dense ? L.maskf : nullptr;
+            a.g_at = g_at; a.dH = (need_dH && !first) ? c->dH : nullptr; a.dmask = student ? c->dmask : nullptr; a.M = M;
+            RUN(2, 0, launch_bwd_prep(P, a, s));
+        }
+        const void* A_g = g_at ? g_at : (const void*)g;
+        // ---- 2. MLP dgrad (frozen weights): dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
+        if (!first) {
+            const void* A_dh = need_dH ? (const void*)c->dH : A_g;
+            {
+                GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
+                a.out_at = c->dZ;
+                RUN(0, a.flops(), launch_gemm(P, EPI_GELU_BWD, a, s));
+            }
+            {
+                GemmArgs a; a.A = c->dZ; a.W = W.fc1_wT; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.out_f32 = c->dA2;
+                RUN(0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+            }
+        }
+        // ---- 3. adapter: dgrad through up_proj, both wgrads, dgrad through down_proj ----
+        {
+            GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
+            a.aux_at = L.d_act; a.out_at = c->ddz; a.scale = scale; a.inv_keep = inv_keep;
+            RUN(0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s));
+        }
+        {
+            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = c->wg_partial;
+            a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
+            a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
+            RUN(2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
+        }
+        {
+            WgradArgs a; a.X = L.u_at; a.Y = c->ddz; a.M = M; a.r = r; a.partial = c->wg_partial;
+            a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
+            a.out_xsum = nullptr; a.alpha_x = 0.f;
+            RUN(2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
+        }
+        RUN(2, 0, launch_colsum64(P, c->ddz, M, r, gbase + c->off_db, 1.0f, s));  // down_proj.bias
+        if (!first) {
+            GemmArgs a; a.A = c->ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
+            a.out_f32 = g; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
+            RUN(0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+        }
+        // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
+        if (!first || student) {
+            TokBwdArgs a;
+            a.du = g; a.dA2 = first ? nullptr : c->dA2; a.dst_of = dense ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
+            a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
+            a.dmask = c->dmask;
+            a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
+            a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
+            a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
+            a.du_at = (P != 0 && !first) ? c->du_at : nullptr; a.partial = c->tok_partial; a.M = M; a.write_du = !first;
+            int nblk = 0;
+            RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
+            if (student) RUN(2, 0, launch_reduce_partials(c->tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s));
+        }
+        if (first) break;
+        // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
+        {
+            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)c->du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
+            a.out_at = c->dO;
+            RUN(0, a.flops(), launch_gemm(P, EPI_STORE_AT, a, s));
+        }
+        RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
+            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, c->dO, L.lse, c->delta, c->dqkv, B, s));
+        {
+            GemmArgs a; a.A = c->dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_f32 = c->dxn;
+            RUN(0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+        }
+        RUN(2, 0, launch_ln_bwd(c->dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, s));
+    }
+    return DYT_OK;
+}
+
+extern "C" int dyt_backward(dyt_ctx* c, int slot, const float* dlogits, const float* dtoken_select, const float* dtok,
+                            const float* dtoken_logits, float* grad_flat, void* stream) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
+    return backward_impl(c, slot, c->slots[slot].trainable, dlogits, dtoken_select, dtok, dtoken_logits, grad_flat,
+                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dyt_loss(dyt_ctx* c, int slot_student, const float* logits_s, const float* logits_t, const int64_t* targets,
+                        int batch, float token_target_ratio, float token_loss_ratio, float token_minimal,
+                        float token_minimal_weight, float* dlogits_s, float* dlogits_t, float* out_losses, float* dtok,
+                        void* stream) {
+    if (!c || !logits_s || !logits_t || !targets || !dlogits_s || !dlogits_t || !out_losses || !dtok) {
+        set_error("null argument");
+        return DYT_ERR_ARG;
+    }
+    if (slot_student < 0 || slot_student >= c->cfg.slots) { set_error("slot out of range"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossArgs a;
+    a.logits_s = logits_s; a.logits_t = logits_t; a.targets = targets; a.counts = c->slots[slot_student].counts;
+    a.batch = batch; a.C = c->cfg.num_classes; a.depth = c->cfg.depth;
+    a.target_ratio = token_target_ratio; a.loss_ratio = token_loss_ratio; a.token_minimal = token_minimal;
+    a.token_minimal_weight = token_minimal_weight;
+    a.dlogits_s = dlogits_s; a.dlogits_t = dlogits_t; a.out_losses = out_losses; a.dtok = dtok;
+    return launch_loss(a, s);
+}
+
+extern "C" int dyt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int step,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                         void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || numel < 1 || step < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    return launch_adamw(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* targets, int batch, int flags,
+                                const float* trainable, const float* g1, const float* g2, const uint8_t* keep_mask,
+                                uint64_t seed, float token_target_ratio, float token_loss_ratio, float token_minimal,
+                                float token_minimal_weight, float* grad_flat, float* out_losses, float* logits_s,
+                                float* logits_t, float* token_select, void* stream) {
+    if (!c || !targets || !grad_flat || !out_losses) { set_error("null argument"); return DYT_ERR_ARG; }
+    if (c->cfg.slots < 2) { set_error("dyt_step_fwd_bwd needs 2 slots"); return DYT_ERR_STATE; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int depth = c->cfg.depth;
+    const size_t nz = (size_t)depth * batch * NP;        // per-pass noise stride
+    const size_t kz = (size_t)depth * batch * NT * c->cfg.ffn_num;
+    float* ls = logits_s ? logits_s : c->logits_s;
+    float* lt = logits_t ? logits_t : c->logits_t;
+    const int fl = (flags & DYT_F_MASKED_DENSE) | DYT_F_TRAINING | DYT_F_SAVE;
+    int rc = forward_impl(c, 0, images, batch, fl, trainable, g1, g2, keep_mask, seed, ls, token_select, nullptr, true, s);
+    if (rc) return rc;
+    // the teacher pass draws its own noise in the reference (mask discarded): only the dropout stream matters
+    rc = forward_impl(c, 1, images, batch, fl | DYT_F_COMPLETE, trainable, g1 ? g1 + nz : nullptr, g2 ? g2 + nz : nullptr,
+                      keep_mask ? keep_mask + kz : nullptr, seed, lt, nullptr, nullptr, false, s);
+    if (rc) return rc;
+    rc = dyt_loss(c, 0, ls, lt, targets, batch, token_target_ratio, token_loss_ratio, token_minimal, token_minimal_weight,
+                  c->dl_s, c->dl_t, out_losses, c->dtok, stream);
+    if (rc) return rc;
+    DYT_HIP_CHECK(hipMemsetAsync(grad_flat, 0, (size_t)c->n_train * sizeof(float), s));
+    rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s);
+    if (rc) return rc;
+    return backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, grad_flat, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// single-kernel entry points (unit tests).  These allocate scratch and synchronise: test-only.
+// ------------------------------------------------------------------------------------------
+extern "C" int dyt_layernorm(const float* x, const float* w, const float* b, float* out, int rows, void* stream) {
+    if (!x || !w || !b || !out || rows < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    return launch_ln_fwd_f32out(x, w, b, out, rows, static_cast<hipStream_t>(stream));
+}
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) hipFree(p); }
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+};
+
+extern "C" int dyt_linear(const float* a, const float* w, const float* bias, float* cmat, int M, int N, int K, int precision,
+                          void* stream) {
+    if (!a || !w || !cmat || M < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GemmArgs g; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out_f32 = cmat;
+    Scratch sc;
+    if (precision == 0) { g.A = a; g.W = w; }
+    else {
+        void* a2 = sc.get((size_t)M * K * 2); void* w2 = sc.get((size_t)N * K * 2);
+        if (!a2 || !w2) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+        int rc = launch_convert(1, a, a2, (int64_t)M * K, s); if (rc) return rc;
+        rc = launch_convert(1, w, w2, (int64_t)N * K, s); if (rc) return rc;
+        g.A = a2; g.W = w2;
+    }
+    int rc = launch_gemm(precision, EPI_BIAS_F32, g, s);
+    if (rc) return rc;
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
+}
+
+template <class AT>
+static int attention_test(const float* qkv, float* out, const float* dout, float* dqkv, int B, int P, hipStream_t s) {
+    Scratch sc;
+    const size_t M = (size_t)B * NT;
+    AT* q = (AT*)sc.get(M * D * sizeof(AT)); AT* k = (AT*)sc.get(M * D * sizeof(AT)); AT* v = (AT*)sc.get(M * D * sizeof(AT));
+    AT* o = (AT*)sc.get(M * D * sizeof(AT));
+    float* lse = (float*)sc.get((size_t)B * NH * NT * 4);
+    if (!q || !k || !v || !o || !lse) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    const size_t n3 = M * 3 * D;
+    hipLaunchKernelGGL(qkv_split_kernel<AT>, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, s, qkv, q, k, v, B);
+    int rc = launch_attn_fwd(P, q, k, v, o, lse, B, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(to_f32_kernel<AT>, dim3((unsigned)((M * D + 255) / 256)), dim3(256), 0, s, (const AT*)o, out, M * D);
+    if (dout && dqkv) {
+        AT* d_o = (AT*)sc.get(M * D * sizeof(AT)); AT* dq = (AT*)sc.get(n3 * sizeof(AT));
+        float* delta = (float*)sc.get((size_t)B * NH * NT * 4);
+        if (!d_o || !dq || !delta) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+        rc = launch_convert(P, dout, d_o, (int64_t)(M * D), s); if (rc) return rc;
+        rc = launch_attn_bwd(P, q, k, v, o, d_o, lse, delta, dq, B, s); if (rc) return rc;
+        hipLaunchKernelGGL(to_f32_kernel<AT>, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, s, (const AT*)dq, dqkv, n3);
+    }
+    DYT_HIP_CHECK(hipGetLastError());
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
+}
+
+extern "C" int dyt_attention(const float* qkv, float* out, const float* dout, float* dqkv, int batch, int precision,
+                             void* stream) {
+    if (!qkv || !out || batch < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return precision == 0 ? attention_test<float>(qkv, out, dout, dqkv, batch, 0, s)
+                          : attention_test<bf16>(qkv, out, dout, dqkv, batch, 1, s);
+}
+
+extern "C" int dyt_gate_compact(const float* u, const float* w, const float* b, const float* g1, const float* g2, int batch,
+                                int training, float tau, float threshold, float* mask, float* logits, int32_t* keep_idx,
+                                int32_t* counts, int32_t* total, void* stream) {
+    if (!u || !w || !b || !mask || !logits || !keep_idx || !counts || !total || batch < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch sc;
+    const size_t M = (size_t)batch * NT;
+    float* soft = (float*)sc.get(M * 4); float* maskf = (float*)sc.get(M * 4);
+    int* keep_local = (int*)sc.get(M * 4); int* offsets = (int*)sc.get((size_t)batch * 4);
+    if (!soft || !maskf || !keep_local || !offsets) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    GateArgs ga;
+    ga.u = u; ga.w = w; ga.b = b; ga.g1 = g1; ga.g2 = g2; ga.batch = batch; ga.training = training; ga.tau = tau;
+    ga.threshold = threshold; ga.seed = 0; ga.subseq = 0; ga.soft = soft; ga.maskf = maskf; ga.out_select = mask;
+    ga.out_logits = logits; ga.out_stride = NP; ga.keep_local = keep_local; ga.counts = counts;
+    int rc = launch_gate(ga, s); if (rc) return rc;
+    rc = launch_scan(counts, offsets, total, batch, s); if (rc) return rc;
+    // flat ascending list of kept rows = what nonzero() returns in model_speed_test.py:300
+    std::vector<int> hc(batch), ho(batch), hk(M);
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    DYT_HIP_CHECK(hipMemcpy(hc.data(), counts, batch * 4, hipMemcpyDeviceToHost));
+    DYT_HIP_CHECK(hipMemcpy(ho.data(), offsets, batch * 4, hipMemcpyDeviceToHost));
+    DYT_HIP_CHECK(hipMemcpy(hk.data(), keep_local, M * 4, hipMemcpyDeviceToHost));
+    std::vector<int> flat(M, -1);
+    for (int bb = 0; bb < batch; ++bb)
+        for (int j = 0; j < hc[bb]; ++j) flat[ho[bb] + j] = bb * NT + hk[(size_t)bb * NT + j];
+    DYT_HIP_CHECK(hipMemcpy(keep_idx, flat.data(), M * 4, hipMemcpyHostToDevice));
+    return DYT_OK;
+}

@@ -1,0 +1,878 @@
+// Row-wise and small kernels of the DyT hot path (gfx950): LayerNorm fwd/bwd, the token
+// dispatcher (gate) with index compaction, gather, adapter/gate weight gradients, head, the
+// step loss and AdamW.  All are HBM-bound: one 64-lane wave owns one 768-channel token row
+// (3 x float4 per lane, fully coalesced), reductions are wave shuffles.
+//
+// Reference ops replaced (paths relative to the reference root):
+//   nn.LayerNorm(eps=1e-6)                      models/vision_transformer_IN21K.py:110,123,314
+//   TokenSelect.forward / _gumbel_sigmoid       models/dynamic_adapter.py:25-77
+//   nonzero + gather of model_speed_test        models/model_speed_test.py:297-304
+//   head / cls pooling                          models/vision_transformer_IN21K.py:375-380
+//   CE + KL + AdaLoss                           engine_finetune.py:52-63, models/losses.py:48-84
+//   torch.optim.AdamW                           main_image.py:285
+#include "kernels.h"
+
+namespace dyt {
+
+#define LAUNCH_CHECK() DYT_HIP_CHECK(hipGetLastError())
+
+// a wave's view of one 768-float row: lane holds cols {lane*4 + 256*i + e}
+struct Row12 {
+    float v[12];
+    __device__ __forceinline__ void load(const float* p, int lane) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(p + i * 256 + lane * 4);
+            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+        }
+    }
+    template <class T>
+    __device__ __forceinline__ void load_at(const T* p, int lane) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float t[4];
+            load4(p + i * 256 + lane * 4, t);
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+        }
+    }
+    template <class T>
+    __device__ __forceinline__ void store(T* p, int lane) const {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) store4(p + i * 256 + lane * 4, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    __device__ __forceinline__ float sum() const {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s += v[i];
+        return wave_sum(s);
+    }
+};
+
+__device__ __forceinline__ float dot12(const Row12& a, const Row12& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s = fmaf(a.v[i], b.v[i], s);
+    return wave_sum(s);
+}
+
+// normalise a row held in registers; returns (mean, rstd)
+__device__ __forceinline__ float2 ln_stats(const Row12& x) {
+    const float mean = x.sum() * (1.0f / D);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float d = x.v[i] - mean; s = fmaf(d, d, s); }
+    const float var = wave_sum(s) * (1.0f / D);
+    return make_float2(mean, 1.0f / sqrtf(var + LN_EPS));
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward / backward
+// ------------------------------------------------------------------------------------------
+template <class AT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, AT* __restrict__ out,
+                                                     float2* __restrict__ stats, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row12 xr, wr, br;
+    xr.load(x + (size_t)row * D, lane);
+    wr.load(w, lane);
+    br.load(b, lane);
+    const float2 st = ln_stats(xr);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - st.x) * st.y * wr.v[i] + br.v[i];
+    xr.store(out + (size_t)row * D, lane);
+    if (stats && lane == 0) stats[row] = st;
+}
+
+__device__ __forceinline__ void ln_bwd_row(Row12& dy, const Row12& x, const Row12& w, float2 st) {
+    // in: dy = dL/d(LN out); out: dy = dL/dx
+    float s1 = 0.f, s2 = 0.f;
+    Row12 xh;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        xh.v[i] = (x.v[i] - st.x) * st.y;
+        dy.v[i] *= w.v[i];
+        s1 += dy.v[i];
+        s2 = fmaf(dy.v[i], xh.v[i], s2);
+    }
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dy.v[i] = st.y * (dy.v[i] - s1 - xh.v[i] * s2);
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float2* __restrict__ stats, const float* __restrict__ w,
+                                                     const float* __restrict__ base, float* __restrict__ dx, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row12 g, xr, wr;
+    g.load(dy + (size_t)row * D, lane);
+    xr.load(x + (size_t)row * D, lane);
+    wr.load(w, lane);
+    ln_bwd_row(g, xr, wr, stats[row]);
+    if (base) {
+        Row12 br;
+        br.load(base + (size_t)row * D, lane);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
+    }
+    g.store(dx + (size_t)row * D, lane);
+}
+
+int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats, int rows,
+                  hipStream_t s) {
+    const int grid = (rows + 3) / 4;
+    if (precision == 0)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, b, (float*)out, stats, rows);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, x, w, b, (bf16*)out, stats, rows);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s) {
+    return launch_ln_fwd(0, x, w, b, out, nullptr, rows, s);
+}
+int launch_ln_bwd(const float* dy, const float* x, const float2* stats, const float* w, const float* base, float* dx,
+                  int rows, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, stats, w, base, dx, rows);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// token dispatcher: logits, (Gumbel-)sigmoid, hard threshold, per-image index compaction in LDS
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
+    __shared__ float logit_s[NT];
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Row12 wr;
+    wr.load(a.w, lane);
+    const float bias = a.b[0];
+    for (int n = 1 + wave; n < NT; n += 4) {
+        Row12 ur;
+        ur.load(a.u + ((size_t)b * NT + n) * D, lane);
+        const float l = dot12(ur, wr) + bias;
+        if (lane == 0) logit_s[n] = l;
+    }
+    __syncthreads();
+    bool keep = false;
+    const int n = tid;
+    if (n < NT) {
+        const size_t t = (size_t)b * NT + n;
+        if (n == 0) {
+            keep = true;
+            a.maskf[t] = 1.0f;
+            a.soft[t] = 1.0f;
+        } else {
+            const float l = logit_s[n];
+            float z = l;
+            if (a.training) {
+                if (a.g1) {
+                    z = (l + a.g1[(size_t)b * NP + n - 1] - a.g2[(size_t)b * NP + n - 1]) / a.tau;
+                } else {
+                    Philox ph(a.seed, a.subseq, t);
+                    const float u = ph.u01(0);
+                    z = (l + (logf(u) - log1pf(-u))) / a.tau;  // Gumbel - Gumbel ~ Logistic(0,1)
+                }
+            }
+            const float sft = sigmoidf(z);
+            keep = sft > a.threshold;
+            a.soft[t] = sft;
+            a.maskf[t] = keep ? 1.0f : 0.0f;
+            if (a.out_select) a.out_select[(size_t)b * a.out_stride + n - 1] = keep ? 1.0f : 0.0f;
+            if (a.out_logits) a.out_logits[(size_t)b * a.out_stride + n - 1] = l;
+        }
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (keep) a.keep_local[(size_t)b * NT + off + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+    if (tid == 0) a.counts[b] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+int launch_gate(const GateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gate_kernel, dim3(a.batch), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ total, int batch) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < batch; ++b) { offsets[b] = acc; acc += counts[b]; }
+        total[0] = acc;
+    }
+}
+int launch_scan(const int* counts, int* offsets, int* total, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, total, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <class AT>
+__global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                        const float* __restrict__ bb, const int* __restrict__ keep_local,
+                                                        const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                        const float* __restrict__ maskf, AT* __restrict__ out,
+                                                        float2* __restrict__ stats, int* __restrict__ row_src,
+                                                        int* __restrict__ dst_of, int batch) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= batch * NT) return;
+    const int b = slot / NT, j = slot - b * NT;
+    const int cnt = counts[b];
+    // role 1: this wave owns TOKEN `slot`: a dropped token has no compact row
+    if (lane == 0 && maskf[slot] == 0.f) dst_of[slot] = -1;
+    // role 2: this wave owns COMPACT slot j of image b
+    if (j >= cnt) return;
+    const int src = b * NT + keep_local[(size_t)b * NT + j];
+    const int dst = offsets[b] + j;
+    Row12 xr, wr, br;
+    xr.load(u + (size_t)src * D, lane);
+    wr.load(w, lane);
+    br.load(bb, lane);
+    const float2 st = ln_stats(xr);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - st.x) * st.y * wr.v[i] + br.v[i];
+    xr.store(out + (size_t)dst * D, lane);
+    if (lane == 0) {
+        stats[src] = st;
+        row_src[dst] = src;
+        dst_of[src] = dst;
+    }
+}
+
+int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
+                     const int* counts, const int* offsets, const float* maskf, void* out, float2* stats,
+                     int* row_src, int* dst_of, int batch, hipStream_t s) {
+    const int grid = (batch * NT + 3) / 4;
+    if (precision == 0)
+        hipLaunchKernelGGL(ln_gather_kernel<float>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, offsets,
+                           maskf, (float*)out, stats, row_src, dst_of, batch);
+    else
+        hipLaunchKernelGGL(ln_gather_kernel<bf16>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, offsets,
+                           maskf, (bf16*)out, stats, row_src, dst_of, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// patch embedding prologue
+// ------------------------------------------------------------------------------------------
+template <class AT>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, AT* __restrict__ out, int batch) {
+    // out[(b*196 + py*14 + px)*768 + c*256 + i*16 + j] = img[b][c][py*16+i][px*16+j]; 4 consecutive j per thread
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)batch * NP * (D / 4);
+    if (idx >= total) return;
+    const int k4 = (int)(idx % (D / 4));
+    const size_t row = idx / (D / 4);
+    const int p = (int)(row % NP);
+    const int b = (int)(row / NP);
+    const int k = k4 * 4, c = k >> 8, i = (k >> 4) & 15, j = k & 15;
+    const int py = p / 14, px = p - py * 14;
+    const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * 3 + c) * 224 + py * 16 + i) * 224 + px * 16 + j);
+    store4(out + row * D + k, v.x, v.y, v.z, v.w);
+}
+int launch_im2col(int precision, const float* images, void* out, int batch, hipStream_t s) {
+    const size_t total = (size_t)batch * NP * (D / 4);
+    const int grid = (int)((total + 255) / 256);
+    if (precision == 0) hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, s, images, (float*)out, batch);
+    else hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(grid), dim3(256), 0, s, images, (bf16*)out, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x0, int batch) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= batch * D) return;
+    const int b = idx / D, c = idx - b * D;
+    x0[(size_t)b * NT * D + c] = cls[c] + pos[c];
+}
+int launch_cls_rows(const float* cls, const float* pos, float* x0, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((batch * D + 255) / 256), dim3(256), 0, s, cls, pos, x0, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// dtype / layout conversion of weights
+// ------------------------------------------------------------------------------------------
+template <class AT>
+__global__ void pad_convert_kernel(const float* __restrict__ src, AT* __restrict__ dst, int rows, int cols, int drows,
+                                   int dcols, int transpose) {
+    // dst[dr][dc] = transpose ? src[dc][dr] : src[dr][dc], zero outside the source
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)drows * dcols) return;
+    const int dr = (int)(idx / dcols), dc = (int)(idx - (size_t)dr * dcols);
+    float v = 0.f;
+    if (transpose) { if (dc < rows && dr < cols) v = src[(size_t)dc * cols + dr]; }
+    else { if (dr < rows && dc < cols) v = src[(size_t)dr * cols + dc]; }
+    dst[idx] = from_f32<AT>(v);
+}
+static int pad_convert(int precision, const float* src, void* dst, int rows, int cols, int drows, int dcols, int tr,
+                       hipStream_t s) {
+    const size_t total = (size_t)drows * dcols;
+    const int grid = (int)((total + 255) / 256);
+    if (precision == 0)
+        hipLaunchKernelGGL(pad_convert_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, rows, cols, drows, dcols, tr);
+    else
+        hipLaunchKernelGGL(pad_convert_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, (bf16*)dst, rows, cols, drows, dcols, tr);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_convert(int precision, const float* src, void* dst, int64_t n, hipStream_t s) {
+    return pad_convert(precision, src, dst, 1, (int)n, 1, (int)n, 0, s);
+}
+int launch_transpose_convert(int precision, const float* src, void* dst, int rows, int cols, int dst_rows, int dst_cols,
+                             hipStream_t s) {
+    return pad_convert(precision, src, dst, rows, cols, dst_rows, dst_cols, 1, s);
+}
+int launch_pad_convert(int precision, const float* src, void* dst, int rows, int cols, int dst_rows, int dst_cols,
+                       hipStream_t s) {
+    return pad_convert(precision, src, dst, rows, cols, dst_rows, dst_cols, 0, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// head: final LayerNorm on the cls rows + Linear(768, C)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nw,
+                                                       const float* __restrict__ nb, const float* __restrict__ hw,
+                                                       const float* __restrict__ hb, float* __restrict__ cls_n,
+                                                       float2* __restrict__ stats, float* __restrict__ logits, int C) {
+    __shared__ float row[D];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xp = x + (size_t)b * NT * D;
+    float v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { v[i] = xp[tid + 256 * i]; s += v[i]; }
+    const float mean = block_sum256(s, red) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(block_sum256(q, red) * (1.0f / D) + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid + 256 * i;
+        const float y = (v[i] - mean) * rstd * nw[c] + nb[c];
+        row[c] = y;
+        cls_n[(size_t)b * D + c] = y;
+    }
+    if (tid == 0) stats[b] = make_float2(mean, rstd);
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        float acc = 0.f;
+        const float* wp = hw + (size_t)c * D;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc = fmaf(row[lane + 64 * i], wp[lane + 64 * i], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) logits[(size_t)b * C + c] = acc + hb[c];
+    }
+}
+int launch_head_fwd(const float* x, const float* nw, const float* nb, const float* hw, const float* hb, float* cls_n,
+                    float2* stats, float* logits, int batch, int C, hipStream_t s) {
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(batch), dim3(256), 0, s, x, nw, nb, hw, hb, cls_n, stats, logits, C);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
+                                                          const float2* __restrict__ stats, const float* __restrict__ nw,
+                                                          const float* __restrict__ hw, float* __restrict__ g, int C) {
+    __shared__ float red[4];
+    __shared__ float dl[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) dl[c] = dlogits[(size_t)b * C + c];
+    __syncthreads();
+    const float2 st = stats[b];
+    float dy[3], xh[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = tid + 256 * i;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(dl[c], hw[(size_t)c * D + ch], acc);
+        xh[i] = (x[(size_t)b * NT * D + ch] - st.x) * st.y;
+        dy[i] = acc * nw[ch];
+        s1 += dy[i];
+        s2 = fmaf(dy[i], xh[i], s2);
+    }
+    s1 = block_sum256(s1, red) * (1.0f / D);
+    s2 = block_sum256(s2, red) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[(size_t)b * NT * D + tid + 256 * i] = st.y * (dy[i] - s1 - xh[i] * s2);
+}
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ dlogits, const float* __restrict__ cls_n,
+                                                          float* __restrict__ dW, float* __restrict__ db, int batch, int C) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float acc[3] = {0.f, 0.f, 0.f};
+    float sb = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float d = dlogits[(size_t)b * C + c];
+        sb += d;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = fmaf(d, cls_n[(size_t)b * D + tid + 256 * i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dW[(size_t)c * D + tid + 256 * i] += acc[i];
+    if (tid == 0) db[c] += sb;
+}
+int launch_head_bwd(const float* dlogits, const float* x, const float* cls_n, const float2* stats, const float* nw,
+                    const float* hw, float* g, float* dWh, float* dbh, int batch, int C, hipStream_t s) {
+    if (C > 1024) { set_error("head_bwd: num_classes %d > 1024 unsupported", C); return -1; }
+    DYT_HIP_CHECK(hipMemsetAsync(g, 0, (size_t)batch * NT * D * sizeof(float), s));
+    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(batch), dim3(256), 0, s, dlogits, x, stats, nw, hw, g, C);
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(C), dim3(256), 0, s, dlogits, cls_n, dWh, dbh, batch, C);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// step loss (one workgroup; B x C is tiny)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+    __shared__ float red[4][4];
+    __shared__ float redk[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, B = a.batch;
+    float ce_s = 0.f, ce_t = 0.f, kl = 0.f;
+    const float invB = 1.0f / B;
+    for (int b = wave; b < B; b += 4) {
+        const float* ls = a.logits_s + (size_t)b * C;
+        const float* lt = a.logits_t + (size_t)b * C;
+        float ms = -INFINITY, mt = -INFINITY;
+        for (int c = lane; c < C; c += 64) { ms = fmaxf(ms, ls[c]); mt = fmaxf(mt, lt[c]); }
+        ms = wave_max(ms); mt = wave_max(mt);
+        float ss = 0.f, st = 0.f;
+        for (int c = lane; c < C; c += 64) { ss += expf(ls[c] - ms); st += expf(lt[c] - mt); }
+        const float lse_s = ms + logf(wave_sum(ss)), lse_t = mt + logf(wave_sum(st));
+        const int y = (int)a.targets[b];
+        float klb = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float lps = ls[c] - lse_s, lpt = lt[c] - lse_t;
+            const float ps = expf(lps), pt = expf(lpt);
+            klb += pt * (lpt - lps);
+            const float oh = c == y ? 1.0f : 0.0f;
+            a.dlogits_s[(size_t)b * C + c] = ((ps - oh) + (ps - pt)) * invB;
+            a.dlogits_t[(size_t)b * C + c] = (pt - oh) * invB;
+        }
+        klb = wave_sum(klb);
+        ce_s += -(ls[y] - lse_s);
+        ce_t += -(lt[y] - lse_t);
+        kl += klb;
+    }
+    float kept = 0.f;
+    if (a.counts)
+        for (int i = tid; i < a.depth * B; i += 256) kept += (float)(a.counts[i] - 1);
+    kept = wave_sum(kept);
+    if (lane == 0) { red[wave][0] = ce_s; red[wave][1] = ce_t; red[wave][2] = kl; redk[wave] = kept; }
+    __syncthreads();
+    if (tid == 0) {
+        const float base = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * invB;
+        const float teacher = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * invB;
+        const float klv = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * invB;
+        float tok = 0.f, mean = 0.f, keptv = 0.f;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if (a.counts) {
+            keptv = redk[0] + redk[1] + redk[2] + redk[3];
+            const float N = (float)a.depth * B * NP;
+            mean = keptv / N;
+            const float diff = mean - a.target_ratio;
+            tok = diff * diff;
+            d0 = a.loss_ratio * 2.0f * diff / N;
+            if (a.token_minimal_weight > 0.f) {
+                tok += a.token_minimal_weight * ((N - keptv) * fmaxf(a.token_minimal, 0.f) + keptv * fmaxf(a.token_minimal - 1.0f, 0.f));
+                d1 = a.token_minimal > 0.f ? -a.loss_ratio * a.token_minimal_weight : 0.f;
+                d2 = a.token_minimal > 1.f ? -a.loss_ratio * a.token_minimal_weight : 0.f;
+            }
+        }
+        const float token_loss = a.loss_ratio * tok;
+        a.out_losses[0] = base + token_loss + teacher + klv;
+        a.out_losses[1] = base;
+        a.out_losses[2] = token_loss;
+        a.out_losses[3] = teacher;
+        a.out_losses[4] = klv;
+        a.out_losses[5] = mean;
+        a.out_losses[6] = keptv;
+        a.out_losses[7] = 0.f;
+        a.dtok[0] = d0; a.dtok[1] = d1; a.dtok[2] = d2;
+    }
+}
+int launch_loss(const LossArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW over the flat trainable buffer
+// ------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float rsqrt_bc2, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                 float wd, float bc1, float bc2, float gscale, hipStream_t s) {
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
+                       wd, bc1, 1.0f / sqrtf(bc2), gscale);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward prep of a block: AT copy of g, gathered MLP gradient rows, <g, h> per token
+// ------------------------------------------------------------------------------------------
+template <class AT>
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                       const int* __restrict__ dst_of, const float* __restrict__ row_mask,
+                                                       AT* __restrict__ g_at, AT* __restrict__ dH,
+                                                       float* __restrict__ dmask, int M) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= M) return;
+    Row12 gr;
+    gr.load(g + (size_t)t * D, lane);
+    if (g_at) gr.store(g_at + (size_t)t * D, lane);
+    const int r = dst_of ? dst_of[t] : t;
+    float dm = 0.f;
+    if (r >= 0) {
+        if (h) {
+            Row12 hr;
+            hr.load(h + (size_t)r * D, lane);
+            dm = dot12(gr, hr);
+        }
+        if (dH) {
+            if (row_mask) {
+                const float mk = row_mask[t];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) gr.v[i] *= mk;
+            }
+            gr.store(dH + (size_t)r * D, lane);
+        }
+    }
+    if (dmask && lane == 0) dmask[t] = dm;
+}
+int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s) {
+    const int grid = (a.M + 3) / 4;
+    if (precision == 0)
+        hipLaunchKernelGGL(bwd_prep_kernel<float>, dim3(grid), dim3(256), 0, s, a.g, a.h, a.dst_of, a.row_mask,
+                           (float*)a.g_at, (float*)a.dH, a.dmask, a.M);
+    else
+        hipLaunchKernelGGL(bwd_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, a.g, a.h, a.dst_of, a.row_mask,
+                           (bf16*)a.g_at, (bf16*)a.dH, a.dmask, a.M);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-token tail of a block's backward
+// ------------------------------------------------------------------------------------------
+constexpr int TOK_PER_BLOCK = 32;
+
+template <class AT>
+__global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
+    __shared__ float red[4][D + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Row12 wg, ln2w, dwg;
+    float dbg = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dwg.v[i] = 0.f;
+    if (a.gate_w) wg.load(a.gate_w, lane);
+    if (a.dA2) ln2w.load(a.ln2_w, lane);
+    const int t0 = blockIdx.x * TOK_PER_BLOCK;
+    for (int k = wave; k < TOK_PER_BLOCK; k += 4) {
+        const int t = t0 + k;
+        if (t >= a.M) break;
+        const int b = t / NT, n = t - b * NT;
+        Row12 du, ur;
+        const bool need_u = a.dA2 || a.gate_w;
+        if (need_u) ur.load(a.u + (size_t)t * D, lane);
+        if (a.write_du) du.load(a.du + (size_t)t * D, lane);
+        else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) du.v[i] = 0.f;
+        }
+        if (a.dA2 && a.write_du) {
+            const int r = a.dst_of ? a.dst_of[t] : t;
+            if (r >= 0) {
+                Row12 dy;
+                dy.load(a.dA2 + (size_t)r * D, lane);
+                ln_bwd_row(dy, ur, ln2w, a.stats2[t]);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i];
+            }
+        }
+        if (a.gate_w && n >= 1) {
+            const size_t oi = (size_t)b * a.out_stride + n - 1;
+            float ext = 0.f;
+            if (a.dtoken_select) ext = a.dtoken_select[oi];
+            else if (a.dtok) ext = a.dtok[0] + (a.maskf[t] != 0.f ? a.dtok[2] : a.dtok[1]);
+            const float sf = a.soft[t];
+            float dlogit = (a.dmask[t] + ext) * sf * (1.0f - sf);
+            if (a.training) dlogit /= a.tau;
+            if (a.dtoken_logits) dlogit += a.dtoken_logits[oi];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                du.v[i] = fmaf(dlogit, wg.v[i], du.v[i]);
+                dwg.v[i] = fmaf(dlogit, ur.v[i], dwg.v[i]);
+            }
+            dbg += dlogit;
+        }
+        if (a.write_du) {
+            du.store(a.du + (size_t)t * D, lane);
+            if (a.du_at) du.store(reinterpret_cast<AT*>(a.du_at) + (size_t)t * D, lane);
+        }
+    }
+    if (a.gate_w) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][i * 256 + lane * 4 + e] = dwg.v[4 * i + e];
+        if (lane == 0) red[wave][D] = dbg;  // dbg is lane-uniform
+        __syncthreads();
+        for (int c = tid; c < D + 1; c += 256)
+            a.partial[(size_t)blockIdx.x * (D + 1) + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s) {
+    const int grid = (a.M + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK;
+    if (nblocks_out) *nblocks_out = grid;
+    if (precision == 0) hipLaunchKernelGGL(tok_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tok_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int stride, float* __restrict__ out,
+                                       int n, float alpha) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * stride + i];
+    out[i] += alpha * acc;
+}
+int launch_reduce_partials(const float* partial, int nparts, int stride, float* out, int n, float alpha, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, stride, out, n, alpha);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// adapter weight gradients:  C[c][j] = sum_m X[m][c] Y[m][j]   (+ column sums of X in j = 64)
+// ------------------------------------------------------------------------------------------
+constexpr int WG_J = 80;        // 64 adapter columns + the ones column (+ pad)
+constexpr int WG_CHUNK = 512;   // tokens per workgroup
+
+// bf16: MFMA 16x16x32 with the token dimension as K; tiles are transposed while staged to LDS
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Y, int M,
+                                                         float* __restrict__ partial) {
+    constexpr int LDT = 40;  // bf16 per LDS row: 32 tokens + 8 pad (80 B, 16-B aligned rows)
+    __shared__ __attribute__((aligned(16))) bf16 Xt[128 * LDT];
+    __shared__ __attribute__((aligned(16))) bf16 Yt[64 * LDT];
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * WG_CHUNK;
+    f32x4 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (lane & 15) == 0 ? (bf16)1.0f : (bf16)0.0f;
+
+    const int xp = tid >> 4, xc = tid & 15;  // token pair, 8-channel chunk
+    const int yp = (tid & 127) >> 3, yc = tid & 7;
+    for (int step = 0; step < WG_CHUNK / 32; ++step) {
+        const int tb = m0 + step * 32;
+        if (tb >= M) break;
+        bf16x8 xa, xb, ya, yb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xa[i] = (bf16)0.f; xb[i] = (bf16)0.f; ya[i] = (bf16)0.f; yb[i] = (bf16)0.f; }
+        const int tx = tb + 2 * xp;
+        if (tx < M) xa = *reinterpret_cast<const bf16x8*>(X + (size_t)tx * D + c0 + xc * 8);
+        if (tx + 1 < M) xb = *reinterpret_cast<const bf16x8*>(X + (size_t)(tx + 1) * D + c0 + xc * 8);
+        const int ty = tb + 2 * yp;
+        if (tid < 128) {
+            if (ty < M) ya = *reinterpret_cast<const bf16x8*>(Y + (size_t)ty * RP + yc * 8);
+            if (ty + 1 < M) yb = *reinterpret_cast<const bf16x8*>(Y + (size_t)(ty + 1) * RP + yc * 8);
+        }
+        __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf16x2 pv = {xa[i], xb[i]};
+            *reinterpret_cast<bf16x2*>(&Xt[(xc * 8 + i) * LDT + 2 * xp]) = pv;
+        }
+        if (tid < 128) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf16x2 pv = {ya[i], yb[i]};
+                *reinterpret_cast<bf16x2*>(&Yt[(yc * 8 + i) * LDT + 2 * yp]) = pv;
+            }
+        }
+        __syncthreads();
+        const int kg = lane >> 4, fr = lane & 15;
+        bf16x8 xf[2], yf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(&Xt[(wave * 32 + i * 16 + fr) * LDT + kg * 8]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 16 + fr) * LDT + kg * 8]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+            acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], ones, acc[i][4], 0, 0, 0);
+        }
+    }
+    // D[c][j]: col j = lane & 15, row c = (lane >> 4) * 4 + reg
+    float* pp = partial + (size_t)blockIdx.y * D * WG_J;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + wave * 32 + i * 16 + (lane >> 4) * 4 + e;
+                pp[(size_t)c * WG_J + j * 16 + (lane & 15)] = acc[i][j][e];
+            }
+}
+
+// fp32 exact variant: 64 channels x 64 columns per workgroup, 4x4 outputs per thread
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M,
+                                                        float* __restrict__ partial) {
+    __shared__ float Xs[16][64 + 4];
+    __shared__ float Ys[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * WG_CHUNK;
+    const int ty = tid >> 4, tx = tid & 15;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    float acc[4][4] = {};
+    float xs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tb = m0; tb < min(m0 + WG_CHUNK, M); tb += 16) {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yv = xv;
+        if (tb + lr < M) {
+            xv = *reinterpret_cast<const float4*>(X + (size_t)(tb + lr) * D + c0 + lc);
+            yv = *reinterpret_cast<const float4*>(Y + (size_t)(tb + lr) * RP + lc);
+        }
+        __syncthreads();
+        *reinterpret_cast<float4*>(&Xs[lr][lc]) = xv;
+        *reinterpret_cast<float4*>(&Ys[lr][lc]) = yv;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&Xs[k][ty * 4]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ys[k][tx * 4]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+                xs[i] += av[i];
+            }
+        }
+    }
+    float* pp = partial + (size_t)blockIdx.y * D * WG_J;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty * 4 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pp[(size_t)c * WG_J + tx * 4 + j] = acc[i][j];
+        if (tx == 0) pp[(size_t)c * WG_J + 64] = xs[i];
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int r, float* __restrict__ out_w,
+                                    int sc, int sj, float alpha, float* __restrict__ out_xsum, float alpha_x) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= D * (r + 1)) return;
+    const int c = idx / (r + 1), j = idx - c * (r + 1);
+    const int col = j < r ? j : 64;
+    float acc = 0.f;
+    for (int p = 0; p < nchunks; ++p) acc += partial[((size_t)p * D + c) * WG_J + col];
+    if (j < r) out_w[(size_t)c * sc + (size_t)j * sj] += alpha * acc;
+    else if (out_xsum) out_xsum[c] += alpha_x * acc;
+}
+
+int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
+    const int nchunks = (a.M + WG_CHUNK - 1) / WG_CHUNK;
+    if (precision == 0)
+        hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 64, nchunks), dim3(256), 0, s, (const float*)a.X, (const float*)a.Y,
+                           a.M, a.partial);
+    else
+        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks), dim3(256), 0, s, (const bf16*)a.X, (const bf16*)a.Y,
+                           a.M, a.partial);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((D * (a.r + 1) + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.r,
+                       a.out_w, a.sc, a.sj, a.alpha, a.out_xsum, a.alpha_x);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <class AT>
+__global__ __launch_bounds__(256) void colsum64_kernel(const AT* __restrict__ Y, int M, int r, float* __restrict__ out,
+                                                       float alpha) {
+    __shared__ float red[4][64];
+    const int j = threadIdx.x & 63, rr = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int m = blockIdx.x * 4 + rr; m < M; m += gridDim.x * 4) acc += to_f32(Y[(size_t)m * RP + j]);
+    red[rr][j] = acc;
+    __syncthreads();
+    if (rr == 0 && j < r) atomicAdd(out + j, alpha * (red[0][j] + red[1][j] + red[2][j] + red[3][j]));
+}
+int launch_colsum64(int precision, const void* Y, int M, int r, float* out, float alpha, hipStream_t s) {
+    const int grid = min(64, (M + 3) / 4);
+    if (precision == 0) hipLaunchKernelGGL(colsum64_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)Y, M, r, out, alpha);
+    else hipLaunchKernelGGL(colsum64_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)Y, M, r, out, alpha);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void fill_f32_kernel(float* p, float v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+int launch_fill_f32(float* p, float v, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+__global__ void iota_kernel(int* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+int launch_iota(int* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace dyt

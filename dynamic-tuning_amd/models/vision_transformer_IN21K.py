@@ -1,0 +1,273 @@
+"""``models.vision_transformer_IN21K`` of the reference on MI355X.
+
+Same factory, constructor arguments, parameter names/shapes (checkpoint compatible) and
+``forward(x, complete_model) -> (logits, {"token_select", "token_logits"})`` contract as
+reference models/vision_transformer_IN21K.py:192-421 -- so main_image.py / main_vtab.py /
+engine_finetune.py drop onto it -- but the arithmetic is one call into libdyt_hip.so
+(hand-written HIP kernels, include/dyt_hip.h).  Sub-modules are parameter containers with the
+reference's names; there is no PyTorch compute path and no CPU fallback.
+"""
+import os
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from _lib import DyTError, key_to_param, is_trainable_param
+from runtime import DyTEngine, parse_precision
+from .dynamic_adapter import Adapter, TokenSelect, _LinearParams
+
+
+def _cfg_get(cfg, key, default=None):
+    """attribute-dict lookup that tolerates EasyDict (AttributeError) and plain dict subclasses (KeyError)"""
+    try:
+        return getattr(cfg, key)
+    except (AttributeError, KeyError):
+        return default
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _ConvParams(nn.Module):
+    def __init__(self, in_chans, embed_dim, patch):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(embed_dim, in_chans, patch, patch))
+        self.bias = nn.Parameter(torch.empty(embed_dim))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        nn.init.uniform_(self.bias, -1 / (in_chans * patch * patch) ** 0.5, 1 / (in_chans * patch * patch) ** 0.5)
+
+
+class PatchEmbed(nn.Module):
+    """timm PatchEmbed's parameter surface (``proj.weight`` [768,3,16,16], ``proj.bias``)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True):
+        super().__init__()
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = _ConvParams(in_chans, embed_dim, patch_size)
+
+
+class Mlp(nn.Module):
+    """timm Mlp's parameter surface (``fc1``, ``fc2``)."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = _LinearParams(in_features, hidden_features)
+        self.fc2 = _LinearParams(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    """Reference :27-75 (parameters ``qkv``, ``proj``)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, **_):
+        super().__init__()
+        assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = _LinearParams(dim, dim * 3, bias=qkv_bias)
+        self.proj = _LinearParams(dim, dim)
+
+
+class Block(nn.Module):
+    """Reference :88-185: norm1, attn, norm2, mlp, adaptmlp, mlp_token_select (+ count_flops attrs)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, tuning_config=None, layer_id=None, select=False, **_):
+        super().__init__()
+        self.tuning_config = tuning_config
+        self.norm1 = _LayerNormParams(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = _LayerNormParams(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.adaptmlp = Adapter(self.tuning_config, dropout=0.1, bottleneck=tuning_config.ffn_num,
+                                init_option=tuning_config.ffn_adapter_init_option,
+                                adapter_scalar=tuning_config.ffn_adapter_scalar,
+                                adapter_layernorm_option=tuning_config.ffn_adapter_layernorm_option)
+        self.mlp_token_select = TokenSelect(dim, num_sub_layer=1)
+        self.count_flops = None
+        self.token_select_num = None
+
+    def forward(self, x, complete_model=False):
+        raise DyTError("Block is evaluated inside VisionTransformer's fused HIP path; call the model")
+
+
+class _DyTFunction(torch.autograd.Function):
+    """Autograd bridge: forward = dyt_forward (activations saved inside the library, slot 0 =
+    student / 1 = complete_model pass), backward = dyt_backward -> gradients of the 74 trainables."""
+
+    @staticmethod
+    def forward(ctx, model, x, complete_model, g1, g2, keep_mask, seed, *params):
+        eng = model._engine
+        slot = 1 if complete_model else 0
+        logits, ts, tl = eng.forward(x, slot=slot, training=model.training, complete_model=complete_model, save=True,
+                                     masked_dense=(model.train_mode == "masked"), gate_always=True, g1=g1, g2=g2,
+                                     keep_mask=keep_mask, seed=seed)
+        ctx.model, ctx.slot, ctx.batch = model, slot, x.shape[0]
+        ctx.set_materialize_grads(False)
+        return logits, ts, tl
+
+    @staticmethod
+    def backward(ctx, dlogits, dts, dtl):
+        model = ctx.model
+        eng = model._engine
+        gbuf = torch.zeros_like(eng.flat)
+        if dlogits is None:
+            dlogits = torch.zeros(ctx.batch, eng.num_classes, device=eng.device)
+        eng.backward(ctx.slot, dlogits.float().contiguous(), gbuf,
+                     dtoken_select=None if dts is None else dts.float().contiguous(),
+                     dtoken_logits=None if dtl is None else dtl.float().contiguous())
+        grads = tuple(eng.trainable_view(n, p.shape, gbuf) if p.requires_grad else None
+                      for n, p in model._trainables)
+        return (None,) * 7 + grads
+
+
+class VisionTransformer(nn.Module):
+    """DyT ViT-B/16 (reference :192-385)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, global_pool='token', embed_dim=768,
+                 depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True, qk_norm=False, init_values=None, class_token=True,
+                 no_embed_class=False, pre_norm=False, fc_norm=None, drop_rate=0., pos_drop_rate=0., patch_drop_rate=0.,
+                 proj_drop_rate=0., attn_drop_rate=0., drop_path_rate=0., weight_init='', embed_layer=None,
+                 norm_layer=None, act_layer=None, block_fn=Block, mlp_layer=None, tuning_config=None, select_config=None,
+                 precision=None, max_batch=None, train_mode=None):
+        super().__init__()
+        fixed = dict(img_size=(img_size, 224), patch_size=(patch_size, 16), in_chans=(in_chans, 3), embed_dim=(embed_dim, 768),
+                     num_heads=(num_heads, 12), mlp_ratio=(mlp_ratio, 4.0), qkv_bias=(qkv_bias, True), global_pool=(global_pool, 'token'),
+                     class_token=(class_token, True), qk_norm=(qk_norm, False), init_values=(init_values, None),
+                     no_embed_class=(no_embed_class, False), pre_norm=(pre_norm, False))
+        for k, (got, want) in fixed.items():
+            if got != want:
+                raise NotImplementedError("%s=%r: the HIP path implements vit_base_patch16_224_in21k (%s=%r)" % (k, got, k, want))
+        if max(drop_rate, pos_drop_rate, patch_drop_rate, proj_drop_rate, attn_drop_rate) > 0:
+            raise NotImplementedError("dropout rates other than the adapter's are 0 in every reference entry point")
+        if drop_path_rate:
+            raise NotImplementedError("drop_path_rate=%r: train_IN21K.sh / train_vtab.sh run with drop_path 0.0" % drop_path_rate)
+        assert tuning_config is not None and select_config is not None
+        if not (select_config.open and select_config.keep_layers == 0):
+            raise NotImplementedError("select_config must be open with keep_layers=0 (main_image.py:196-198)")
+        if _cfg_get(tuning_config, "ffn_option", "parallel") != "parallel":
+            raise NotImplementedError("ffn_option must be 'parallel'")
+        self.tuning_config = tuning_config
+        self.num_classes = num_classes
+        self.global_pool = global_pool
+        self.num_features = self.embed_dim = embed_dim
+        self.num_prefix_tokens = 1
+        self.depth = depth
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + 1, embed_dim) * .02)
+        self.blocks = nn.Sequential(*[
+            block_fn(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, tuning_config=tuning_config,
+                     layer_id=i, select=select_config.open and i >= select_config.keep_layers) for i in range(depth)])
+        self.norm = _LayerNormParams(embed_dim)
+        self.head = _LinearParams(embed_dim, num_classes)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        self.apply(self.init_weights)
+        # MI355X knobs (not in the reference): arithmetic mode and training mode
+        self.precision = parse_precision(precision if precision is not None else
+                                         _cfg_get(tuning_config, "precision") or os.environ.get("DYT_PRECISION", "bf16"))
+        self.train_mode = train_mode or _cfg_get(tuning_config, "dyt_train_mode") or os.environ.get("DYT_TRAIN_MODE", "compact")
+        assert self.train_mode in ("compact", "masked")
+        self.max_batch = max_batch
+        self._engine = None
+        self._sync_state = None
+        self._seed_counter = 0
+
+    def init_weights(self, m):  # reference :323-332
+        if isinstance(m, _LinearParams):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif hasattr(m, '_init_weights'):
+            m._init_weights()
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+    # ---- engine plumbing ----------------------------------------------------------------------
+    def _named_params(self):
+        out = []
+        for n, p in self.named_parameters():
+            pid, _ = key_to_param(n)
+            out.append((n, p, is_trainable_param(pid)))
+        return out
+
+    def engine(self, batch, device):
+        """Create (or grow) the libdyt_hip context and (re)upload parameters that changed."""
+        eng = self._engine
+        if eng is None or eng.device != device or batch > eng.cfg.max_batch:
+            mb = max(batch, self.max_batch or 0)
+            old = self._engine
+            self._engine = None
+            del old
+            eng = DyTEngine(self.num_classes, self.tuning_config.ffn_num, self.blocks[0].adaptmlp.scale, device,
+                            precision=self.precision, max_batch=mb, depth=self.depth,
+                            adapter_dropout=self.blocks[0].adaptmlp.dropout, tau=self.blocks[0].mlp_token_select.tau,
+                            threshold=self.blocks[0].mlp_token_select.threshold)
+            self._engine = eng
+            self._sync_state = None
+        self._sync(eng)
+        return eng
+
+    def _sync(self, eng):
+        params = self._named_params()
+        # frozen tensors: re-upload when any was modified in place or re-allocated
+        state = tuple((p.data_ptr(), p._version) for n, p, tr in params if not tr)
+        if state != self._sync_state:
+            for n, p, tr in params:
+                if not tr:
+                    eng.set_param(n, p.data)
+            self._sync_state = state
+        # trainable tensors live in the engine's flat buffer; re-home any that moved
+        self._trainables = []
+        for n, p, tr in params:
+            if not tr:
+                continue
+            view = eng.trainable_view(n, p.shape)
+            if p.data.data_ptr() != view.data_ptr():
+                view.copy_(p.data.to(eng.device, torch.float32))
+                p.data = view
+            self._trainables.append((n, p))
+
+    # ---- reference API ------------------------------------------------------------------------
+    def forward(self, x, complete_model=False, gumbel=None, keep_mask=None):
+        """x [B,3,224,224] -> (logits [B,C], {"token_select": [B,12,196,1], "token_logits": [B,12,196,1]}).
+
+        ``gumbel=(g1, g2)`` ([depth,B,196] each) and ``keep_mask`` ([depth,B*197,r] uint8) inject the
+        training-mode random draws (parity tests); by default they come from the on-device Philox
+        stream seeded from torch's seed and a per-model call counter."""
+        if not x.is_cuda:
+            raise DyTError("DyT VisionTransformer runs on a HIP device only (input is on %s); there is no CPU path" % x.device)
+        x = x.float().contiguous()
+        eng = self.engine(x.shape[0], x.device)
+        g1 = g2 = None
+        if gumbel is not None:
+            g1, g2 = (t.to(x.device, torch.float32).contiguous() for t in gumbel)
+        if keep_mask is not None:
+            keep_mask = keep_mask.to(x.device, torch.uint8).contiguous()
+        self._seed_counter += 1
+        seed = (torch.initial_seed() * 1000003 + self._seed_counter) & (2 ** 63 - 1)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._trainables)
+        if need_grad:
+            logits, ts, tl = _DyTFunction.apply(self, x, bool(complete_model), g1, g2, keep_mask, seed,
+                                                *[p for _, p in self._trainables])
+        else:
+            logits, ts, tl = eng.forward(x, slot=1 if complete_model else 0, training=self.training,
+                                         complete_model=bool(complete_model), save=False, gate_always=True, g1=g1, g2=g2,
+                                         keep_mask=keep_mask, seed=seed)
+        return logits, dict(token_select=ts.unsqueeze(-1), token_logits=tl.unsqueeze(-1))
+
+    def forward_features(self, x, complete_model=False):
+        raise DyTError("forward_features/forward_head are fused into one HIP call; use forward()")
+
+
+def vit_base_patch16_224_in21k(**kwargs):
+    """Reference :414-421."""
+    model_kwargs = dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, **kwargs)
+    return VisionTransformer(**model_kwargs)

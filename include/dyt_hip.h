@@ -1,0 +1,193 @@
+/*
+ * dyt_hip.h -- C ABI of libdyt_hip.so: the MI355X (gfx950) implementation of the
+ * Dynamic-Tuning ViT-B/16 fine-tune hot path.
+ *
+ * The reference (NUS-HPC-AI-Lab/Dynamic-Tuning) has no FFI: its hot path sits behind a
+ * Python nn.Module API.  This header is therefore the boundary a
+ * maintainer binds with ctypes from the reference's module files; every entry point cites
+ * the reference interface it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 (DYT_OK) or a negative error code; no exceptions cross the
+ *     ABI; dyt_last_error() returns a thread-local message for the last failure;
+ *   - all tensor arguments are DEVICE pointers owned by the caller (torch allocates them);
+ *     the library never frees them and never synchronises the host with the device;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - the library owns (hipMalloc) only its private copies of the frozen weights and its
+ *     activation workspace, both sized at dyt_ctx_create();
+ *   - one context per process / device; thread-compatible, not thread-safe.
+ */
+#ifndef DYT_HIP_H
+#define DYT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYT_OK 0
+#define DYT_ERR_ARG (-1)     /* bad argument / unsupported shape */
+#define DYT_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define DYT_ERR_STATE (-3)   /* call order violated (e.g. backward without a saved forward) */
+
+/* arithmetic mode of the dense contractions */
+#define DYT_PREC_FP32 0 /* exact: fp32 operands, fp32 accumulate -- the parity mode */
+#define DYT_PREC_BF16 1 /* fast: bf16 MFMA operands, fp32 accumulate, fp32 residual stream */
+
+/* dyt_forward flags */
+#define DYT_F_TRAINING 1       /* model.train(): Gumbel noise + adapter dropout (dynamic_adapter.py:29-42,127) */
+#define DYT_F_COMPLETE 2       /* forward(x, complete_model=True): mask not applied (vision_transformer_IN21K.py:161) */
+#define DYT_F_SAVE 4           /* keep activations of this pass in `slot` for dyt_backward */
+#define DYT_F_MASKED_DENSE 8   /* student pass computes the MLP for every token and multiplies by the
+                                  mask, exactly as the reference trains (vision_transformer_IN21K.py:159-162);
+                                  default is the compacted MLP of models/model_speed_test.py:274-310 */
+#define DYT_F_GATE_ALWAYS 16   /* also evaluate the token dispatcher in a COMPLETE pass (the reference does,
+                                  and discards it, :150-152) so token_select/token_logits are returned */
+
+/* parameter ids (frozen unless marked T = trainable); `layer` is the block index, or 0 */
+enum dyt_param {
+    DYT_P_CLS = 0,      /* cls_token [1,1,768] */
+    DYT_P_POS,          /* pos_embed [1,197,768] */
+    DYT_P_PE_W,         /* patch_embed.proj.weight [768,3,16,16] */
+    DYT_P_PE_B,         /* patch_embed.proj.bias [768] */
+    DYT_P_LN1_W, DYT_P_LN1_B,     /* blocks.i.norm1 */
+    DYT_P_QKV_W, DYT_P_QKV_B,     /* blocks.i.attn.qkv [2304,768] */
+    DYT_P_PROJ_W, DYT_P_PROJ_B,   /* blocks.i.attn.proj [768,768] */
+    DYT_P_LN2_W, DYT_P_LN2_B,     /* blocks.i.norm2 */
+    DYT_P_FC1_W, DYT_P_FC1_B,     /* blocks.i.mlp.fc1 [3072,768] */
+    DYT_P_FC2_W, DYT_P_FC2_B,     /* blocks.i.mlp.fc2 [768,3072] */
+    DYT_P_NORM_W, DYT_P_NORM_B,   /* norm */
+    DYT_P_AD_DOWN_W, DYT_P_AD_DOWN_B, /* T blocks.i.adaptmlp.down_proj [r,768] */
+    DYT_P_AD_UP_W, DYT_P_AD_UP_B,     /* T blocks.i.adaptmlp.up_proj [768,r] */
+    DYT_P_GATE_W, DYT_P_GATE_B,       /* T blocks.i.mlp_token_select.mlp_head [1,768] */
+    DYT_P_HEAD_W, DYT_P_HEAD_B,       /* T head [C,768] */
+    DYT_P_COUNT
+};
+
+/* Replaces the constructor arguments of vit_base_patch16_224_in21k(num_classes, tuning_config,
+ * select_config) -- models/vision_transformer_IN21K.py:199-323,414-421.  Fixed by the factory:
+ * patch 16, dim 768, depth 12, heads 12, mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6. */
+typedef struct dyt_config {
+    int32_t num_classes;     /* head width C */
+    int32_t ffn_num;         /* adapter bottleneck r (tuning_config.ffn_num), 1..64 */
+    int32_t depth;           /* 12 */
+    int32_t precision;       /* DYT_PREC_* */
+    int32_t max_batch;       /* images per call the workspace is sized for */
+    int32_t slots;           /* saved-activation slots (2: student + teacher pass) */
+    float adapter_scale;     /* tuning_config.ffn_adapter_scalar (0.1 main_image.py:192, 1.0 main_vtab.py:185) */
+    float adapter_dropout;   /* 0.1, vision_transformer_IN21K.py:133 */
+    float tau;               /* 5, dynamic_adapter.py:59 */
+    float threshold;         /* 0.5, dynamic_adapter.py:59 */
+} dyt_config;
+
+typedef struct dyt_ctx dyt_ctx;
+
+const char* dyt_last_error(void);
+int dyt_version(void);
+
+int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out);
+int dyt_ctx_destroy(dyt_ctx* ctx);
+/* bytes of device memory the context holds (weights + workspace) */
+int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
+
+/* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library
+ * keeps its own copies in the layouts/dtypes its kernels want (incl. transposes for dgrad).
+ * Replaces load_state_dict(...) for the frozen keys -- main_image.py:245. */
+int dyt_set_frozen(dyt_ctx* ctx, int param, int layer, const float* src, void* stream);
+
+/* The 74 trainable tensors live in ONE flat fp32 buffer owned by the caller (so one AdamW
+ * launch and one all-reduce cover them).  Offsets in elements. -- main_image.py:250-256,285 */
+int dyt_trainable_numel(const dyt_ctx* ctx, int64_t* numel);
+int dyt_trainable_offset(const dyt_ctx* ctx, int param, int layer, int64_t* offset, int64_t* numel);
+
+/* VisionTransformer.forward(x, complete_model) -- models/vision_transformer_IN21K.py:343-385,
+ * Block.forward :144-165, TokenSelect.forward / _gumbel_sigmoid dynamic_adapter.py:25-77,
+ * Adapter.forward :120-140.
+ *   images        [B,3,224,224] fp32
+ *   trainable     flat trainable buffer (dyt_trainable_offset layout)
+ *   g1, g2        [depth,B,196] fp32 Gumbel draws to inject (parity tests), or NULL: logistic noise
+ *                 from the on-device Philox stream (seed, slot) -- same distribution as g1-g2
+ *   keep_mask     [depth,B*197,r] uint8 adapter-dropout keep mask to inject, or NULL: Philox
+ *   logits        [B,C] out
+ *   token_select  [B,depth,196] out fp32 {0,1} (may be NULL)
+ *   token_logits  [B,depth,196] out fp32       (may be NULL)
+ */
+int dyt_forward(dyt_ctx* ctx, int slot, const float* images, int batch, int flags,
+                const float* trainable, const float* g1, const float* g2,
+                const uint8_t* keep_mask, uint64_t seed,
+                float* logits, float* token_select, float* token_logits, void* stream);
+
+/* Backward of one saved pass: what loss.backward() does through the module
+ * (engine_finetune.py:74-76 via misc.py:258-259).  Gradients of the trainable tensors are
+ * ACCUMULATED into grad_flat (same layout as `trainable`).
+ *   dlogits        [B,C]
+ *   dtoken_select  [B,depth,196] or NULL  (gradient w.r.t. the straight-through mask)
+ *   dtok_uniform   device float[3] or NULL: {uniform, extra for dropped, extra for kept} gradient per
+ *                  mask element, as produced by dyt_loss (used when dtoken_select is NULL)
+ *   dtoken_logits  [B,depth,196] or NULL
+ */
+int dyt_backward(dyt_ctx* ctx, int slot, const float* dlogits, const float* dtoken_select,
+                 const float* dtok_uniform, const float* dtoken_logits, float* grad_flat, void* stream);
+
+/* Loss of the fine-tune step and its gradient w.r.t. both logits -- engine_finetune.py:52-63 and
+ * AdaLoss.forward models/losses.py:48-84:
+ *   loss = CE(s,y) + ratio*((mean(mask)-target)^2 + w_min*sum(clamp(t_min-mask,0))) + CE(t,y)
+ *          + KL(log_softmax s || log_softmax t.detach(), batchmean)
+ * The mask statistics are taken from the token counts saved by the student pass in `slot_student`.
+ *   out_losses  device float[8]: loss, base_loss, token_loss(scaled), teacher_loss, distillation_loss,
+ *               mean keep ratio, kept tokens, 0
+ *   dtok        device float[3] (see dyt_backward)
+ */
+int dyt_loss(dyt_ctx* ctx, int slot_student, const float* logits_s, const float* logits_t,
+             const int64_t* targets, int batch, float token_target_ratio, float token_loss_ratio,
+             float token_minimal, float token_minimal_weight,
+             float* dlogits_s, float* dlogits_t, float* out_losses, float* dtok, void* stream);
+
+/* torch.optim.AdamW over the flat trainable buffer -- main_image.py:285; the gradient is first
+ * multiplied by grad_scale (1/world_size after a SUM all-reduce).  `step` is 1-based. */
+int dyt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+              int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+              float grad_scale, void* stream);
+
+/* One whole fine-tune step body (engine_finetune.py:47-79 without the host syncs): student +
+ * teacher forward, loss, one backward over both passes into grad_flat (zeroed first).  The caller
+ * all-reduces grad_flat (DDP, main_image.py:280-282) and then calls dyt_adamw. */
+int dyt_step_fwd_bwd(dyt_ctx* ctx, const float* images, const int64_t* targets, int batch,
+                     int flags, const float* trainable,
+                     const float* g1, const float* g2, const uint8_t* keep_mask, uint64_t seed,
+                     float token_target_ratio, float token_loss_ratio,
+                     float token_minimal, float token_minimal_weight,
+                     float* grad_flat, float* out_losses, float* logits_s, float* logits_t,
+                     float* token_select, void* stream);
+
+/* ---- single-kernel entry points (unit tests; also the building blocks of the sub-module API) ---- */
+/* nn.LayerNorm(768, eps=1e-6) forward; out fp32 */
+int dyt_layernorm(const float* x, const float* w, const float* b, float* out, int rows, void* stream);
+/* C[M,N] = A[M,K] @ W[N,K]^T + bias  (nn.Linear); precision selects the kernel family */
+int dyt_linear(const float* a, const float* w, const float* bias, float* c, int M, int N, int K,
+               int precision, void* stream);
+/* scaled_dot_product_attention over [B,12,197,64] from a fused qkv [B*197,2304] (Attention.forward
+ * vision_transformer_IN21K.py:54-72): out [B*197,768]; if dout != NULL also returns dqkv */
+int dyt_attention(const float* qkv, float* out, const float* dout, float* dqkv, int batch,
+                  int precision, void* stream);
+/* TokenSelect.forward + index compaction for one block: u [B*197,768], w[768], b[1];
+ * outputs mask [B,196], logits [B,196], keep_idx int32 [B*197] (flat kept rows, ascending),
+ * counts int32 [B] (kept per image incl. cls), total int32[1] */
+int dyt_gate_compact(const float* u, const float* w, const float* b, const float* g1, const float* g2,
+                     int batch, int training, float tau, float threshold,
+                     float* mask, float* logits, int32_t* keep_idx, int32_t* counts, int32_t* total,
+                     void* stream);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* bracket every kernel launch with hipEvents on `stream` and accumulate per category */
+int dyt_profile_enable(dyt_ctx* ctx, int on);
+/* categories: 0 gemm (big MFMA GEMMs), 1 attention, 2 everything else.  Returns accumulated
+ * milliseconds, launches and algorithmic FLOPs since the last call, then resets.  Synchronises. */
+int dyt_profile_read(dyt_ctx* ctx, int category, double* ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYT_HIP_H */

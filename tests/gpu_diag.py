@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""First-contact diagnostics on a real MI355X: runs every kernel-level and model-level parity
+check, prints one line per check and never stops at the first failure (pytest -m gpu is the gate;
+this is the debugging aid).  Usage: python tests/gpu_diag.py [--quick]"""
+import ctypes
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
+import synth  # noqa: E402
+from _lib import check, lib, ptr, stream_ptr  # noqa: E402
+from oracle import dyt_oracle as O  # noqa: E402
+
+RESULTS = []
+
+
+def report(name, err, tol, extra=""):
+    ok = bool(err <= tol)
+    RESULTS.append((name, ok))
+    print("%-58s %s err=%.3e tol=%.1e %s" % (name, "PASS" if ok else "FAIL", err, tol, extra), flush=True)
+
+
+def run(fn):
+    try:
+        fn()
+    except Exception:
+        RESULTS.append((fn.__name__, False))
+        print("%-58s EXCEPTION" % fn.__name__, flush=True)
+        traceback.print_exc()
+        sys.stdout.flush()
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def t_layernorm():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000, 768, generator=g) * 3 + 1
+    w, b = torch.randn(768, generator=g), torch.randn(768, generator=g)
+    out = torch.empty(1000, 768, device="cuda")
+    check(lib().dyt_layernorm(ptr(x.cuda()), ptr(w.cuda()), ptr(b.cuda()), ptr(out), 1000, stream_ptr()))
+    ref = torch.nn.functional.layer_norm(x, (768,), w, b, 1e-6)
+    report("layernorm fp32", float((out.cpu() - ref).abs().max()), 1e-5)
+
+
+def t_linear():
+    g = torch.Generator().manual_seed(1)
+    for prec, tol in ((0, 1e-5), (1, 2e-2)):
+        for (M, N, K) in ((197 * 2, 768, 768), (1000, 2304, 768), (333, 768, 3072), (130, 3072, 768), (394, 64, 768), (394, 768, 64)):
+            a = torch.randn(M, K, generator=g)
+            w = torch.randn(N, K, generator=g) * 0.05
+            bias = torch.randn(N, generator=g)
+            c = torch.full((M, N), float("nan"), device="cuda")
+            check(lib().dyt_linear(ptr(a.cuda()), ptr(w.cuda()), ptr(bias.cuda()), ptr(c), M, N, K, prec, stream_ptr()))
+            ref = (a.double() @ w.double().t() + bias.double()).float()
+            report("linear prec=%d M=%d N=%d K=%d" % (prec, M, N, K), relerr(c.cpu(), ref), tol)
+
+
+def attn_ref(qkv, B, dout=None):
+    q3 = qkv.double().reshape(B, 197, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    q3 = q3.detach().requires_grad_(True)
+    q, k, v = q3[0], q3[1], q3[2]
+    a = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1)
+    o = (a @ v).transpose(1, 2).reshape(B * 197, 768)
+    if dout is None:
+        return o.float(), None
+    (o * dout.double()).sum().backward()
+    dq = q3.grad.permute(1, 3, 0, 2, 4).reshape(B * 197, 2304)
+    return o.float(), dq.float()
+
+
+def t_attention():
+    g = torch.Generator().manual_seed(2)
+    B = 3
+    qkv = torch.randn(B * 197, 2304, generator=g) * 1.5
+    dout = torch.randn(B * 197, 768, generator=g)
+    ref_o, ref_dq = attn_ref(qkv, B, dout)
+    for prec, tol in ((0, 2e-5), (1, 3e-2)):
+        out = torch.full((B * 197, 768), float("nan"), device="cuda")
+        dqkv = torch.full((B * 197, 2304), float("nan"), device="cuda")
+        check(lib().dyt_attention(ptr(qkv.cuda()), ptr(out), ptr(dout.cuda()), ptr(dqkv), B, prec, stream_ptr()))
+        report("attention fwd prec=%d" % prec, relerr(out.cpu(), ref_o), tol)
+        d = dqkv.cpu()
+        for i, nm in enumerate(("dq", "dk", "dv")):
+            report("attention bwd %s prec=%d" % (nm, prec), relerr(d[:, i * 768:(i + 1) * 768], ref_dq[:, i * 768:(i + 1) * 768]), tol)
+
+
+def t_gate():
+    g = torch.Generator().manual_seed(3)
+    B = 5
+    u = torch.randn(B, 197, 768, generator=g)
+    w = torch.randn(768, generator=g) * 0.05
+    b = torch.randn(1, generator=g)
+    g1 = -torch.empty(B, 196).exponential_(generator=g).log()
+    g2 = -torch.empty(B, 196).exponential_(generator=g).log()
+    for training in (1, 0):
+        mask = torch.empty(B, 196, device="cuda")
+        logits = torch.empty(B, 196, device="cuda")
+        keep = torch.empty(B * 197, device="cuda", dtype=torch.int32)
+        counts = torch.empty(B, device="cuda", dtype=torch.int32)
+        total = torch.empty(1, device="cuda", dtype=torch.int32)
+        check(lib().dyt_gate_compact(ptr(u.cuda()), ptr(w.cuda()), ptr(b.cuda()), ptr(g1.cuda()), ptr(g2.cuda()), B, training,
+                                     5.0, 0.5, ptr(mask), ptr(logits), ptr(keep), ptr(counts), ptr(total), stream_ptr()))
+        rl = (u[:, 1:] @ w + b)
+        sel, _ = O.gumbel_sigmoid(rl, g1, g2, 5.0, 0.5, bool(training))
+        sel = sel.detach()
+        z = ((rl + g1 - g2) / 5.0) if training else rl
+        safe = z.abs() > 1e-5
+        report("gate logits training=%d" % training, float((logits.cpu() - rl).abs().max()), 1e-5)
+        report("gate mask training=%d" % training, float(((mask.cpu() != sel) & safe).sum()), 0, "ties=%d" % int((~safe).sum()))
+        full = torch.cat([torch.ones(B, 1), mask.cpu()], 1).reshape(-1)
+        ref_idx = full.nonzero()[:, 0].int()
+        n = int(total.item())
+        report("gate compaction index training=%d" % training, float(n != ref_idx.numel() or (keep.cpu()[:n] != ref_idx).any()), 0,
+               "kept=%d" % n)
+
+
+def build_model(g, precision, train_mode="compact", prefix=None):
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    C, r = int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = synth.make_state_dict(C, r, seed=int(g["meta_seed"]), kind="test", gate_bias=float(g["meta_gate_bias"]))
+    tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                 ffn_adapter_scalar=str(float(g["meta_scale"])), ffn_num=r, d_model=768)
+    model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0),
+                                       precision=precision, train_mode=train_mode)
+    msg = model.load_state_dict(sd, strict=True)
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    return model.cuda(), sd
+
+
+def t_eval_golden():
+    g = dict(np.load(os.path.join(ROOT, "tests/golden/eval_r64.npz")))
+    B, C = int(g["meta_batch"]), int(g["meta_num_classes"])
+    x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    for prec, tol in (("fp32", 1e-3), ("bf16", 0.25)):
+        model, sd = build_model(g, prec)
+        model.eval()
+        with torch.no_grad():
+            logits, aux = model(x.cuda())
+        report("eval logits vs golden prec=%s" % prec, float(np.abs(logits.cpu().numpy() - g["logits"]).max()), tol)
+        ts = aux["token_select"].cpu().numpy().astype(np.uint8)
+        flips = int((ts != g["token_select"]).sum())
+        report("eval masks vs golden prec=%s" % prec, flips, 0 if prec == "fp32" else 400, "of %d" % ts.size)
+        report("eval token_logits vs golden prec=%s" % prec, float(np.abs(aux["token_logits"].cpu().numpy() - g["token_logits"]).max()),
+               1e-3 if prec == "fp32" else 1.0)
+
+
+def t_step_golden():
+    g = dict(np.load(os.path.join(ROOT, "tests/golden/step_r64.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["s0_g1"]), torch.from_numpy(g["s0_g2"])
+    for prec in ("fp32", "bf16"):
+        for mode in ("masked", "compact"):
+            model, sd = build_model(g, prec, mode)
+            model.train()
+            eng = model.engine(B, torch.device("cuda", 0))
+            ls = torch.empty(B, C, device="cuda")
+            lt = torch.empty(B, C, device="cuda")
+            ts = torch.zeros(B, 12, 196, device="cuda")
+            losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), float(g["meta_target_ratio"]), 2.0, 0.0, 0.0, masked_dense=(mode == "masked"),
+                                      g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
+                                      token_select=ts).cpu()
+            tag = "%s/%s" % (prec, mode)
+            ltol = 1e-3 if prec == "fp32" else 0.25
+            report("step logits student %s" % tag, float(np.abs(ls.cpu().numpy() - g["s0_logits_student"]).max()), ltol)
+            report("step logits teacher %s" % tag, float(np.abs(lt.cpu().numpy() - g["s0_logits_teacher"]).max()), ltol)
+            flips = int((ts.cpu().numpy().astype(np.uint8) != g["s0_token_select"][..., 0]).sum())
+            report("step masks %s" % tag, flips, 0 if prec == "fp32" else 400, "of %d" % ts.numel())
+            for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
+                ref = float(g["s0_stat_" + k])
+                report("step %s %s" % (k, tag), abs(float(losses[i]) - ref), (1e-4 if prec == "fp32" else 0.05) * max(1.0, abs(ref)))
+            if mode == "masked":
+                gref = {n[len("s0_grad/"):]: torch.from_numpy(v) for n, v in g.items() if n.startswith("s0_grad/")}
+            else:
+                _, gg, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="compact",
+                                        token_target_ratio=float(g["meta_target_ratio"]))
+                gref = gg
+            worst, wname = 0.0, ""
+            for n, gr in gref.items():
+                got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
+                e = float((got - gr).norm() / (gr.norm() + 1e-20))
+                if e > worst:
+                    worst, wname = e, n
+            report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.2, wname)
+            # AdamW on the flat buffer
+            if prec == "fp32" and mode == "masked":
+                eng.adamw(float(g["meta_lr"]), float(g["meta_wd"]))
+                worst = 0.0
+                for n in gref:
+                    key = "s0_param_after/" + n
+                    if key in g:
+                        got = eng.trainable_view(n, g[key].shape).cpu().numpy()
+                        big = np.abs(g["s0_grad/" + n]) > 1e-6
+                        worst = max(worst, float(np.abs(got - g[key])[big].max(initial=0.0)))
+                report("adamw params after step", worst, 2e-5)
+            del model, eng
+            torch.cuda.empty_cache()
+
+
+def t_autograd_api():
+    """module API + autograd bridge vs the fused step (same numbers expected)."""
+    from models.losses import AdaLoss
+    import torch.nn.functional as F
+    g = dict(np.load(os.path.join(ROOT, "tests/golden/step_r64.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["s0_g1"]), torch.from_numpy(g["s0_g2"])
+    model, sd = build_model(g, "fp32", "masked")
+    model.train()
+    crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=float(g["meta_target_ratio"]), token_loss_ratio=2.0,
+                   token_minimal=0.0, token_minimal_weight=0.0)
+    xs, ys = x.cuda(), y.cuda()
+    out, tok = model(xs, gumbel=(g1[0], g2[0]), keep_mask=keep[0])
+    tout, _ = model(xs, complete_model=True, gumbel=(g1[1], g2[1]), keep_mask=keep[1])
+    kl = F.kl_div(F.log_softmax(out, -1), F.log_softmax(tout.detach(), -1), reduction="batchmean", log_target=True)
+    loss, d = crit(dict(prediction=out, **tok), ys)
+    loss = loss + crit.base_criterion(tout, ys) + kl
+    loss.backward()
+    report("autograd-API loss vs golden", abs(float(loss) - float(g["s0_stat_loss"])), 1e-4 * float(g["s0_stat_loss"]))
+    worst, wname = 0.0, ""
+    for n, p in model.named_parameters():
+        key = "s0_grad/" + n
+        if key in g and p.grad is not None:
+            e = float((p.grad.cpu() - torch.from_numpy(g[key])).norm() / (np.linalg.norm(g[key]) + 1e-20))
+            if e > worst:
+                worst, wname = e, n
+    report("autograd-API grads vs golden (worst rel L2)", worst, 2e-3, wname)
+
+
+def t_perf_smoke():
+    """Tiny timing probe at B=32 (not the bench): ms/step for both precisions."""
+    from engine_finetune import FusedAdamW, train_step
+    g = dict(np.load(os.path.join(ROOT, "tests/golden/step_r64.npz")))
+    B = 32
+    x, y = synth.make_batch(B, 100, seed=0)
+    for prec in ("bf16", "fp32"):
+        model, sd = build_model(g, prec, "compact")
+        model.train()
+        opt = FusedAdamW(model, lr=1e-3)
+        xs, ys = x.cuda(), y.cuda()
+        for _ in range(2):
+            out = train_step(model, xs, ys, opt, target_ratio=0.5, token_minimal=0.0, token_minimal_weight=0.0, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 5 if prec == "bf16" else 2
+        for i in range(n):
+            out = train_step(model, xs, ys, opt, target_ratio=0.5, token_minimal=0.0, token_minimal_weight=0.0, seed=2 + i)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / n
+        print("perf probe prec=%s B=%d: %.2f ms/step = %.1f img/s ; losses %s" % (prec, B, dt * 1e3, B / dt, [round(v, 4) for v in out.tolist()[:6]]), flush=True)
+        del model
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    print("device:", torch.cuda.get_device_name(0), "| lib version", lib().dyt_version(), flush=True)
+    tests = [t_layernorm, t_linear, t_attention, t_gate, t_eval_golden, t_step_golden, t_autograd_api, t_perf_smoke]
+    if len(sys.argv) > 1 and sys.argv[1] != "--quick":
+        tests = [t for t in tests if t.__name__ in sys.argv[1:]]
+    for t in tests:
+        run(t)
+    bad = [n for n, ok in RESULTS if not ok]
+    print("SUMMARY: %d checks, %d failed" % (len(RESULTS), len(bad)))
+    for n in bad:
+        print("  FAILED:", n)
+    sys.exit(1 if bad else 0)
