@@ -50,7 +50,8 @@ def t_layernorm():
     x = torch.randn(1000, 768, generator=g) * 3 + 1
     w, b = torch.randn(768, generator=g), torch.randn(768, generator=g)
     out = torch.empty(1000, 768, device="cuda")
-    check(lib().dyt_layernorm(ptr(x.cuda()), ptr(w.cuda()), ptr(b.cuda()), ptr(out), 1000, stream_ptr()))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()  # keep the device copies alive across the async launch
+    check(lib().dyt_layernorm(ptr(xd), ptr(wd), ptr(bd), ptr(out), 1000, stream_ptr()))
     ref = torch.nn.functional.layer_norm(x, (768,), w, b, 1e-6)
     report("layernorm fp32", float((out.cpu() - ref).abs().max()), 1e-5)
 
@@ -63,22 +64,23 @@ def t_linear():
             w = torch.randn(N, K, generator=g) * 0.05
             bias = torch.randn(N, generator=g)
             c = torch.full((M, N), float("nan"), device="cuda")
-            check(lib().dyt_linear(ptr(a.cuda()), ptr(w.cuda()), ptr(bias.cuda()), ptr(c), M, N, K, prec, stream_ptr()))
+            ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+            check(lib().dyt_linear(ptr(ad), ptr(wd), ptr(bd), ptr(c), M, N, K, prec, stream_ptr()))
             ref = (a.double() @ w.double().t() + bias.double()).float()
             report("linear prec=%d M=%d N=%d K=%d" % (prec, M, N, K), relerr(c.cpu(), ref), tol)
 
 
 def attn_ref(qkv, B, dout=None):
     q3 = qkv.double().reshape(B, 197, 3, 12, 64).permute(2, 0, 3, 1, 4)
-    q3 = q3.detach().requires_grad_(True)
+    q3 = q3.detach().clone().requires_grad_(dout is not None)
     q, k, v = q3[0], q3[1], q3[2]
     a = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1)
     o = (a @ v).transpose(1, 2).reshape(B * 197, 768)
     if dout is None:
-        return o.float(), None
+        return o.detach().float(), None
     (o * dout.double()).sum().backward()
     dq = q3.grad.permute(1, 3, 0, 2, 4).reshape(B * 197, 2304)
-    return o.float(), dq.float()
+    return o.detach().float(), dq.float()
 
 
 def t_attention():
@@ -90,7 +92,8 @@ def t_attention():
     for prec, tol in ((0, 2e-5), (1, 3e-2)):
         out = torch.full((B * 197, 768), float("nan"), device="cuda")
         dqkv = torch.full((B * 197, 2304), float("nan"), device="cuda")
-        check(lib().dyt_attention(ptr(qkv.cuda()), ptr(out), ptr(dout.cuda()), ptr(dqkv), B, prec, stream_ptr()))
+        qd, dd = qkv.cuda(), dout.cuda()
+        check(lib().dyt_attention(ptr(qd), ptr(out), ptr(dd), ptr(dqkv), B, prec, stream_ptr()))
         report("attention fwd prec=%d" % prec, relerr(out.cpu(), ref_o), tol)
         d = dqkv.cpu()
         for i, nm in enumerate(("dq", "dk", "dv")):
@@ -111,7 +114,8 @@ def t_gate():
         keep = torch.empty(B * 197, device="cuda", dtype=torch.int32)
         counts = torch.empty(B, device="cuda", dtype=torch.int32)
         total = torch.empty(1, device="cuda", dtype=torch.int32)
-        check(lib().dyt_gate_compact(ptr(u.cuda()), ptr(w.cuda()), ptr(b.cuda()), ptr(g1.cuda()), ptr(g2.cuda()), B, training,
+        ud, wd, bd, g1d, g2d = u.cuda(), w.cuda(), b.cuda(), g1.cuda(), g2.cuda()
+        check(lib().dyt_gate_compact(ptr(ud), ptr(wd), ptr(bd), ptr(g1d), ptr(g2d), B, training,
                                      5.0, 0.5, ptr(mask), ptr(logits), ptr(keep), ptr(counts), ptr(total), stream_ptr()))
         rl = (u[:, 1:] @ w + b)
         sel, _ = O.gumbel_sigmoid(rl, g1, g2, 5.0, 0.5, bool(training))
