@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the DyT ViT-B/16 fine-tune step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = engine_finetune.py:47-79 of the reference: student forward (compacted MLP, Gumbel
+gate, adapter dropout), teacher forward (complete model), CE + 2*token-ratio + teacher CE + KL,
+one backward over both passes, (all-reduce of the 5 MB trainable gradients), AdamW -- on a batch
+of synthetic N(0,1) images resident in HBM, B=128 per GPU (configs[1] of BASELINE.json, the
+train_IN21K.sh shape), r=64, C=100, gate biases calibrated so the measured keep ratio is ~0.70.
+
+Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
+  roofline     -- the dominant kernel (the bf16 MFMA GEMM family, csrc/gemm.hip): algorithmic FLOPs of
+                  its launches in one step / their summed duration, measured with HIP events on the
+                  launch stream inside this process, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, pinned to golden vectors)
+                  running the same step at B=16 on the host cores (N=1, rank 0 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dynamic-tuning_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import synth  # noqa: E402
+
+STEP_GFLOP_AT_07 = 126.851   # SURVEY.md section 8d / BASELINE.md section 3, compact mode, r=64, C=100
+STEP_GFLOP_SLOPE = 42.542    # d(GFLOP)/d(keep ratio)
+PEAK = {"bf16": 2500.0, "fp32": 157.3}   # TFLOP/s dense MFMA, MI355X_MICROARCH.md
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def build_model(args, device):
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    sd = synth.make_state_dict(args.classes, args.ffn_num, seed=0, kind="bench", gate_bias=math.log(0.7 / 0.3))
+    tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none",
+                 ffn_adapter_init_option="lora", ffn_adapter_scalar="0.1", ffn_num=args.ffn_num, d_model=768)
+    model = vit_base_patch16_224_in21k(num_classes=args.classes, drop_path_rate=0.0, tuning_config=tuning,
+                                       select_config=Cfg(open=True, keep_layers=0), precision=args.precision,
+                                       max_batch=args.batch, train_mode=args.mode)
+    model.load_state_dict(sd)
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    return model.to(device)
+
+
+def calibrate_gates(model, x, target, iters=8):
+    """Shift each block's gate bias until the measured training-mode keep ratio is `target`
+    (keep ratio is learned in the reference; benchmarks pin it)."""
+    model.train()
+    keep = None
+    with torch.no_grad():
+        for _ in range(iters):
+            _, aux = model(x)
+            keep = aux["token_select"].float().mean(dim=(0, 2, 3)).clamp(1e-3, 1 - 1e-3)  # [depth]
+            delta = (math.log(target / (1 - target)) - torch.log(keep / (1 - keep)))
+            for i, blk in enumerate(model.blocks):
+                blk.mlp_token_select.mlp_head.bias.add_(delta[i])
+    return float(keep.mean())
+
+
+def cpu_baseline(args):
+    """The oracle's full step (losses, autograd, AdamW) at B=16 on the host cores: 1 warm-up + 3 timed
+    (bounded: stops early if the sample exceeds ~60 s)."""
+    from oracle import dyt_oracle as O
+    B = 16
+    ncores = synth.available_cores()
+    torch.set_num_threads(ncores)
+    sd = synth.make_state_dict(args.classes, args.ffn_num, seed=0, kind="bench", gate_bias=math.log(0.7 / 0.3))
+    x, y = synth.make_batch(B, args.classes, seed=0)
+    g1, g2 = synth.make_noise(B, seed=2)
+    keep = synth.make_dropout_masks(B, args.ffn_num, seed=3)
+    opt = {}
+    times = []
+    t_all = time.time()
+    for i in range(4):
+        t0 = time.time()
+        O.train_step(sd, opt, x, y, g1, g2, keep, lr=1e-3, wd=0.01, scale=0.1, mode="masked", token_target_ratio=0.5)
+        times.append(time.time() - t0)
+        log("cpu baseline step %d: %.2f s" % (i, times[-1]))
+        if time.time() - t_all > 60 and len(times) >= 2:
+            break
+    dt = sum(times[1:]) / len(times[1:])
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(B / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/dyt_oracle.py train_step (reference-as-written masked step, fp32), B=16, %d timed steps "
+                      "after 1 warm-up, %.2f s/step, %s" % (len(times) - 1, dt, model)}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="compact", choices=["compact", "masked"])
+    ap.add_argument("--classes", type=int, default=100)
+    ap.add_argument("--ffn_num", type=int, default=64)
+    ap.add_argument("--keep", type=float, default=0.7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the DyT path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from engine_finetune import FusedAdamW, train_step
+    torch.manual_seed(1234 + rank)
+    model = build_model(args, device)
+    x, y = synth.make_batch(args.batch, args.classes, seed=100 + rank)  # each rank its own shard of the global batch
+    x, y = x.to(device), y.to(device)
+    log("model built, ctx %.1f GB" % (0 if model._engine is None else model._engine.bytes / 1e9))
+    keep_cal = calibrate_gates(model, x, args.keep)
+    log("calibrated keep ratio %.4f, ctx %.1f GB" % (keep_cal, model._engine.bytes / 1e9))
+    if world > 1:  # DDP broadcasts rank 0's weights at construction (main_image.py:281)
+        dist.broadcast(model._engine.flat, src=0)
+    model.train()
+    opt = FusedAdamW(model, lr=1e-3 * args.batch * world / 256, weight_decay=0.01)
+    eng = model._engine
+    losses = torch.zeros(8, device=device)
+    acc = torch.zeros(8, device=device)
+
+    def one_step(i):
+        train_step(model, x, y, opt, losses_out=losses, seed=1000 + i, target_ratio=args.keep, token_minimal=0.0,
+                   token_minimal_weight=0.0)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    log("warm-up done")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+        acc += losses
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    host = (acc / args.steps).tolist()
+    log("timed %d steps: %.2f ms/step" % (args.steps, dt / args.steps * 1e3))
+    keep_meas = host[5]
+
+    # dominant-kernel roofline: HIP events around every GEMM launch of ONE step (same stream)
+    roof = None
+    if rank == 0:
+        eng.profile(True)
+        one_step(10 ** 6)
+        ms, n, fl = eng.profile_read(0)
+        ms_a, n_a, fl_a = eng.profile_read(1)
+        ms_o, n_o, _ = eng.profile_read(2)
+        eng.profile(False)
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_%s_nt_kernel (all epilogues)" % ("bf16" if args.precision == "bf16" else "f32"),
+                "achieved": round(ach, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK[args.precision], 4),
+                "traffic": None, "launches_per_step": n, "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                "avg_launch_ms": round(ms / max(n, 1), 4), "gemm_ms_per_step": round(ms, 3),
+                "attention_ms_per_step": round(ms_a, 3), "attention_tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2) if ms_a else None,
+                "other_kernels_ms_per_step": round(ms_o, 3), "other_launches": n_o}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ips = args.batch * world * args.steps / dt
+        gflop = STEP_GFLOP_AT_07 + STEP_GFLOP_SLOPE * (keep_meas - 0.7) if args.mode == "compact" else 139.614
+        out = {
+            "metric": "images/sec DyT ViT-B/16 fine-tune step (student+teacher fwd, bwd, AdamW) @ keep~0.7",
+            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "ViT-B/16 DyT on CIFAR-100 shape, batch=128/GPU, 1xMI355X per rank, keep-ratio target 0.7 "
+                                   "(BASELINE.json configs[1]; N>1 = configs[3] shape: global batch 128*N, DP over RCCL)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "ffn_num": args.ffn_num,
+                       "num_classes": args.classes, "train_mode": args.mode, "parallelism": "dp%d" % world,
+                       "keep_ratio_measured": round(keep_meas, 4), "keep_ratio_calibrated": round(keep_cal, 4)},
+            "images_per_s_per_gpu": round(ips / world, 2),
+            "step_gflop_per_image": round(gflop, 3),
+            "step_mfma_frac": round(ips / world * gflop * 1e9 / (PEAK[args.precision] * 1e12), 4),
+            "loss": round(host[0], 4),
+            "roofline": roof,
+        }
+        log("roofline", roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,7 +109,7 @@ struct Slot {
     bool valid = false;
     const float* trainable = nullptr;  // flat trainable buffer the saved pass was computed with
 };
-struct ProfRec { int cat; double flops; hipEvent_t a, b; };
+struct ProfRec { int cat; double flops; hipEvent_t a, b; const int* m_dev; int M; };
 
 struct dyt_ctx {
     dyt_config cfg;
@@ -374,8 +374,13 @@ static hipEvent_t get_event(dyt_ctx* c) {
 }
 struct ProfScope {
     dyt_ctx* c; hipStream_t s; ProfRec r; bool on;
-    ProfScope(dyt_ctx* c_, hipStream_t s_, int cat, double flops) : c(c_), s(s_), on(c_->prof) {
-        if (on) { r.cat = cat; r.flops = flops; r.a = get_event(c); r.b = get_event(c); hipEventRecord(r.a, s); }
+    ProfScope(dyt_ctx* c_, hipStream_t s_, int cat, double flops, const int* m_dev = nullptr, int M = 0)
+        : c(c_), s(s_), on(c_->prof) {
+        if (on) {
+            r.cat = cat; r.flops = flops; r.m_dev = m_dev; r.M = M;
+            r.a = get_event(c); r.b = get_event(c);
+            hipEventRecord(r.a, s);
+        }
     }
     ~ProfScope() { if (on) { hipEventRecord(r.b, s); c->recs.push_back(r); } }
 };
@@ -384,6 +389,14 @@ struct ProfScope {
         ProfScope _ps(c, s, (cat), (flops));   \
         int _rc = (call);                      \
         if (_rc) return _rc;                   \
+    } while (0)
+// GEMM whose valid row count lives on the device (compacted MLP): FLOPs are scaled by the
+// count actually processed when the profile is read back
+#define RUN_GEMM(kind, a)                                                \
+    do {                                                                 \
+        ProfScope _ps(c, s, 0, (a).flops(), (a).m_dev, (a).M);           \
+        int _rc = launch_gemm(P, (kind), (a), s);                        \
+        if (_rc) return _rc;                                             \
     } while (0)
 
 extern "C" int dyt_profile_enable(dyt_ctx* c, int on) {
@@ -401,7 +414,12 @@ extern "C" int dyt_profile_read(dyt_ctx* c, int category, double* ms, int64_t* l
         if (r.cat != category) { keep.push_back(r); continue; }
         float e = 0.f;
         hipEventElapsedTime(&e, r.a, r.b);
-        t += e; f += r.flops; ++n;
+        double fl = r.flops;
+        if (r.m_dev && r.M > 0) {  // rows really processed (still holds the last step's count)
+            int m = r.M;
+            if (hipMemcpy(&m, r.m_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && m < r.M) fl *= (double)m / r.M;
+        }
+        t += e; f += fl; ++n;
         c->pool.push_back(r.a); c->pool.push_back(r.b);
     }
     c->recs.swap(keep);
@@ -450,7 +468,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     {
         GemmArgs a; a.A = c->xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
         a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0];
-        RUN(0, a.flops(), launch_gemm(P, EPI_EMBED, a, s));
+        RUN_GEMM(EPI_EMBED, a);
     }
     RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
 
@@ -464,13 +482,13 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         {
             GemmArgs a; a.A = c->xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
             a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
-            RUN(0, a.flops(), launch_gemm(P, EPI_QKV, a, s));
+            RUN_GEMM(EPI_QKV, a);
         }
         RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
         {
             GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
             a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
-            RUN(0, a.flops(), launch_gemm(P, EPI_BIAS_RESID, a, s));
+            RUN_GEMM(EPI_BIAS_RESID, a);
         }
         int* counts = S.counts + (size_t)l * B;
         if (use_gate) {
@@ -501,25 +519,25 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
             a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1);
-            RUN(0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
+            RUN_GEMM(EPI_AD_DOWN, a);
         }
         {
             GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
             a.bias = base + c->off_ub; a.resid = L.u; a.out_f32 = xo; a.scale = c->cfg.adapter_scale;
-            RUN(0, a.flops(), launch_gemm(P, EPI_AD_UP, a, s));
+            RUN_GEMM(EPI_AD_UP, a);
         }
         // MLP on the kept (or all) tokens, scatter-add into the residual stream
         const int* kdev = dense ? nullptr : L.total;
         {
             GemmArgs a; a.A = c->xn; a.W = W.fc1_w; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
             a.out_at = c->h1; a.out_at2 = save ? L.z : nullptr;
-            RUN(0, a.flops(), launch_gemm(P, EPI_FC1, a, s));
+            RUN_GEMM(EPI_FC1, a);
         }
         {
             GemmArgs a; a.A = c->h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
             a.out_f32 = xo; a.row_map = dense ? nullptr : L.row_src; a.row_mask = masked_dense ? L.maskf : nullptr;
             a.h_out = (save && !complete) ? L.h : nullptr;
-            RUN(0, a.flops(), launch_gemm(P, EPI_FC2, a, s));
+            RUN_GEMM(EPI_FC2, a);
         }
     }
     RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
@@ -584,18 +602,18 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             {
                 GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.out_at = c->dZ;
-                RUN(0, a.flops(), launch_gemm(P, EPI_GELU_BWD, a, s));
+                RUN_GEMM(EPI_GELU_BWD, a);
             }
             {
                 GemmArgs a; a.A = c->dZ; a.W = W.fc1_wT; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.out_f32 = c->dA2;
-                RUN(0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+                RUN_GEMM(EPI_STORE_F32, a);
             }
         }
         // ---- 3. adapter: dgrad through up_proj, both wgrads, dgrad through down_proj ----
         {
             GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
             a.aux_at = L.d_act; a.out_at = c->ddz; a.scale = scale; a.inv_keep = inv_keep;
-            RUN(0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s));
+            RUN_GEMM(EPI_AD_DGRAD_UP, a);
         }
         {
             WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = c->wg_partial;
@@ -613,7 +631,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         if (!first) {
             GemmArgs a; a.A = c->ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
             a.out_f32 = g; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
-            RUN(0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+            RUN_GEMM(EPI_STORE_F32, a);
         }
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
         if (!first || student) {
@@ -634,13 +652,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {
             GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)c->du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
             a.out_at = c->dO;
-            RUN(0, a.flops(), launch_gemm(P, EPI_STORE_AT, a, s));
+            RUN_GEMM(EPI_STORE_AT, a);
         }
         RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, c->dO, L.lse, c->delta, c->dqkv, B, s));
         {
             GemmArgs a; a.A = c->dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_f32 = c->dxn;
-            RUN(0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+            RUN_GEMM(EPI_STORE_F32, a);
         }
         RUN(2, 0, launch_ln_bwd(c->dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, s));
     }

@@ -10,6 +10,7 @@ container and on the GPU box; torch's own CPU ``randn`` is avoided on purpose.
 State-dict keys and shapes are exactly the reference's (SURVEY.md section 8b;
 ``models/vision_transformer_IN21K.py:272-320`` and ``models/dynamic_adapter.py:61,105-107``).
 """
+import os
 import zlib
 
 import numpy as np
@@ -134,3 +135,23 @@ def make_dropout_masks(batch, ffn_num=64, depth=DEPTH, seed=3, p=0.1, passes=2):
     r = _rng("dropout", seed)
     u = r.random(size=(passes, depth, batch * NUM_TOKENS, ffn_num))
     return torch.from_numpy((u >= p).astype(np.uint8))
+
+
+def available_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota.  (The GPU
+    box shows 256 logical CPUs under a 16-CPU quota; torch's default 128 threads are throttled to a
+    crawl there, so every CPU-side timing / oracle run sets torch.set_num_threads(available_cores()).)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n

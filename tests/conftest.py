@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    import synth
+    torch.set_num_threads(synth.available_cores())  # see synth.available_cores: cgroup quota << visible CPUs
 
 
 @pytest.fixture(scope="session")

@@ -274,6 +274,7 @@ def t_perf_smoke():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    torch.set_num_threads(synth.available_cores())
     print("device:", torch.cuda.get_device_name(0), "| lib version", lib().dyt_version(), flush=True)
     tests = [t_layernorm, t_linear, t_attention, t_gate, t_eval_golden, t_step_golden, t_autograd_api, t_perf_smoke]
     if len(sys.argv) > 1 and sys.argv[1] != "--quick":

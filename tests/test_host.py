@@ -1,0 +1,133 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/dyt_hip.h
+declares (no compute calls without a GPU), the module mirror keeps the reference's parameter
+surface, and the small host-side mirrors (AdaLoss, lr schedule, metrics) equal the oracle."""
+import os
+import re
+import types
+
+import pytest
+import torch
+
+import synth
+from oracle import dyt_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _model(**kw):
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                 ffn_adapter_scalar="0.1", ffn_num=kw.pop("ffn_num", 64), d_model=768)
+    return vit_base_patch16_224_in21k(num_classes=kw.pop("num_classes", 100), drop_path_rate=0.0, tuning_config=tuning,
+                                      select_config=Cfg(open=True, keep_layers=0), **kw)
+
+
+def test_library_exports_every_declared_symbol():
+    import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "dyt_hip.h")).read()
+    declared = set(re.findall(r"\b(dyt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.dyt_version() >= 1
+
+
+def test_ctx_create_fails_loudly_without_gpu():
+    import ctypes
+    import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = _lib.Config(100, 64, 12, 1, 2, 2, 0.1, 0.1, 5.0, 0.5)
+    h = ctypes.c_void_p()
+    assert _lib.lib().dyt_ctx_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert _lib.lib().dyt_last_error()
+
+
+def test_module_keeps_reference_parameter_surface():
+    m = _model()
+    sd = m.state_dict()
+    ref = synth.param_shapes(100, 64)
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    assert sum(p.numel() for p in m.parameters()) == 87074416
+    assert sum(p.numel() for n, p in m.named_parameters() if synth.is_trainable(n)) == 1275760
+    msg = m.load_state_dict({k: v for k, v in synth.make_state_dict(100, 64).items() if not synth.is_trainable(k)}, strict=False)
+    assert sorted(msg.missing_keys) == sorted(k for k in ref if synth.is_trainable(k))   # freeze rule main_image.py:250-256
+    assert float(m.blocks[3].adaptmlp.up_proj.weight.abs().max()) == 0.0                # LoRA-style init (dynamic_adapter.py:112-117)
+    assert m.blocks[0].adaptmlp.scale == 0.1 and m.blocks[0].mlp_token_select.tau == 5
+    assert hasattr(m.blocks[0], "count_flops") and m.head.weight.shape == (100, 768)
+
+
+def test_no_cpu_fallback():
+    from _lib import DyTError
+    m = _model()
+    with pytest.raises(DyTError):
+        m(torch.zeros(1, 3, 224, 224))
+
+
+def test_unsupported_configs_are_rejected():
+    from models.vision_transformer_IN21K import VisionTransformer
+    tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                 ffn_adapter_scalar="0.1", ffn_num=8, d_model=768)
+    with pytest.raises(NotImplementedError):
+        VisionTransformer(embed_dim=384, num_heads=6, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
+    with pytest.raises(NotImplementedError):
+        VisionTransformer(drop_path_rate=0.1, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
+    from models.dynamic_adapter import Adapter
+    with pytest.raises(NotImplementedError):
+        Adapter(d_model=768, bottleneck=8, adapter_layernorm_option="in")
+
+
+def test_key_mapping_covers_state_dict():
+    import _lib
+    seen = set()
+    for k in synth.param_shapes(10, 8):
+        pid, layer = _lib.key_to_param(k)
+        assert 0 <= pid < _lib.P_COUNT and 0 <= layer < 12
+        assert _lib.is_trainable_param(pid) == synth.is_trainable(k)
+        seen.add(pid)
+    assert seen == set(range(_lib.P_COUNT))
+
+
+def test_adaloss_mirror_equals_oracle():
+    from models.losses import AdaLoss
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(6, 10, generator=g)
+    y = torch.randint(0, 10, (6,), generator=g)
+    sel = (torch.rand(6, 12, 196, 1, generator=g) > 0.4).float()
+    for tmin, tw in ((0.0, 0.0), (0.1, 1.0)):
+        crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0, token_minimal=tmin, token_minimal_weight=tw)
+        loss, d = crit(dict(prediction=logits, token_select=sel, token_logits=None), y)
+        ref, dref = O.ada_loss(logits, sel, y, 0.5, 2.0, tmin, tw)
+        assert abs(float(loss) - float(ref)) < 1e-6 and abs(float(d["token_loss"]) - float(dref["token_loss"])) < 1e-6
+
+
+def test_lr_schedule_and_metrics_mirrors():
+    import util.lr_sched as lr_sched
+    from util.metrics import accuracy
+    args = types.SimpleNamespace(lr=1e-3, min_lr=1e-6, warmup_epochs=5, epochs=100)
+    opt = types.SimpleNamespace(param_groups=[dict(lr=0.0), dict(lr=0.0, lr_scale=0.5)])
+    for e in (0.0, 2.5, 5.0, 37.2, 99.9):
+        lr = lr_sched.adjust_learning_rate(opt, e, args)
+        assert abs(lr - O.lr_at(e, 1e-3, 1e-6, 5, 100)) < 1e-12
+        assert opt.param_groups[0]["lr"] == lr and opt.param_groups[1]["lr"] == lr * 0.5
+    g = torch.Generator().manual_seed(1)
+    out, tgt = torch.randn(50, 10, generator=g), torch.randint(0, 10, (50,), generator=g)
+    assert [float(a) for a in accuracy(out, tgt, (1, 5))] == [float(a) for a in O.accuracy(out, tgt, (1, 5))]
+
+
+def test_gumbel_sigmoid_utility_matches_oracle():
+    from models.dynamic_adapter import _gumbel_sigmoid
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(3, 196, 1, generator=g)
+    g1 = -torch.empty(3, 196, 1).exponential_(generator=g).log()
+    g2 = -torch.empty(3, 196, 1).exponential_(generator=g).log()
+    a = _gumbel_sigmoid(logits, 5, True, training=True, threshold=0.5, gumbels=(g1, g2))
+    b, _ = O.gumbel_sigmoid(logits, g1, g2, 5.0, 0.5, True)
+    assert torch.equal(a, b)
+    assert torch.equal(_gumbel_sigmoid(logits, 5, True, training=False), O.gumbel_sigmoid(logits, 0, 0, 5.0, 0.5, False)[0])

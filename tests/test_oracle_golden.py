@@ -27,7 +27,7 @@ def step64(golden_dir):
     x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
     keep = synth.make_dropout_masks(B, r, seed=int(g["meta_seed"]) + 3)
     g1, g2 = torch.from_numpy(g["s0_g1"]), torch.from_numpy(g["s0_g2"])
-    torch.set_num_threads(8)
+    pass
     d, grads, outs = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="masked",
                                   token_target_ratio=float(g["meta_target_ratio"]))
     return g, sd, d, grads, outs, (x, y, g1, g2, keep)
