@@ -96,6 +96,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DyTError("%s not found: build it with `make -C dynamic-tuning_amd/csrc` "
                            "(or __graft_entry__.build()); the DyT path has no fallback" % LIB_PATH)
+        # libdyt_hip.so is linked WITHOUT a HIP runtime (csrc/Makefile: -no-hip-rt): it must bind to the
+        # runtime PyTorch already loaded, so that torch's stream handles, allocations and synchronisation
+        # are the ones our launches see.  Promote that runtime to the global symbol scope first.
+        import torch
+        rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if not os.path.exists(rt):
+            raise DyTError("PyTorch-ROCm's HIP runtime not found at %s" % rt)
+        ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
