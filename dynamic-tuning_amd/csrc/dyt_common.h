@@ -58,6 +58,32 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
+// bf16-mode GELU: Abramowitz-Stegun 7.1.26 erfc polynomial (|err| <= 1.5e-7, far below bf16 output
+// rounding), written in the erfc form so 1+erf has no cancellation for x << 0; one v_exp + one v_rcp.
+//   cdf2(x) = 1 + erf(x/sqrt2) ;  e = exp(-x^2/2)
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf2, float& e) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    e = __expf(-u * u);
+    const float ye = y * t * e;          // erfc(u)
+    cdf2 = x >= 0.f ? 2.0f - ye : ye;
+}
+template <class AT> __device__ __forceinline__ float gelu_fwd(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_fwd<__bf16>(float x) {
+    float c, e;
+    gelu_parts_fast(x, c, e);
+    return 0.5f * x * c;
+}
+template <class AT> __device__ __forceinline__ float gelu_bwd(float x) { return gelu_erf_grad(x); }
+template <> __device__ __forceinline__ float gelu_bwd<__bf16>(float x) {
+    float c, e;
+    gelu_parts_fast(x, c, e);
+    return fmaf(x * 0.39894228040143268f, e, 0.5f * c);
+}
 // sigmoid exactly as 1/(1+exp(-x)) in fp32 (the form the reference's y_soft > 0.5 test sees)
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 

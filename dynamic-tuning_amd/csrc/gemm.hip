@@ -69,7 +69,7 @@ struct EpiFc1 {
         const float z0 = a[0] + bias[col], z1 = a[1] + bias[col + 1], z2 = a[2] + bias[col + 2],
                     z3 = a[3] + bias[col + 3];
         if (z) store4(z + o, z0, z1, z2, z3);
-        store4(h + o, gelu_erf(z0), gelu_erf(z1), gelu_erf(z2), gelu_erf(z3));
+        store4(h + o, gelu_fwd<AT>(z0), gelu_fwd<AT>(z1), gelu_fwd<AT>(z2), gelu_fwd<AT>(z3));
     }
 };
 
@@ -95,8 +95,8 @@ struct EpiGeluBwd {
         const size_t o = (size_t)row * ld + col;
         float zz[4];
         load4(z + o, zz);
-        store4(out + o, a[0] * gelu_erf_grad(zz[0]), a[1] * gelu_erf_grad(zz[1]), a[2] * gelu_erf_grad(zz[2]),
-               a[3] * gelu_erf_grad(zz[3]));
+        store4(out + o, a[0] * gelu_bwd<AT>(zz[0]), a[1] * gelu_bwd<AT>(zz[1]), a[2] * gelu_bwd<AT>(zz[2]),
+               a[3] * gelu_bwd<AT>(zz[3]));
     }
 };
 
@@ -272,17 +272,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
         }
     }
 
-    // ---- epilogue: acc[i][j][e] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + e] ----
+    // ---- epilogue through LDS: acc[i][j][e] = C[wm*WM + i*16 + (lane&15)][wn*WN + j*16 + (lane>>4)*4 + e].
+    // The fragment layout gives each store instruction 16 rows x 64 B; instead the tile is parked in the
+    // (now free) staging ring as fp32 [BM][BN] with the 16-B chunk index XOR-swizzled by (row & 7)
+    // (conflict-free ds_write_b128 / ds_read_b128) and read back row-major, so every global access of
+    // the epilogue functor is a full-row, 16-B-per-lane coalesced transaction.
+    __syncthreads();
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CH = BN / 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * WM + i * 16 + frow;
-        if (row < Mv) {
+        const int rl = wm * WM + i * 16 + frow;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
-                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epi(row, col, v);
-            }
+        for (int j = 0; j < TN; ++j) {
+            const int ch = ((wn * WN + j * 16) >> 2) + (lane >> 4);
+            *reinterpret_cast<f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2)) = acc[i][j];
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int t = tid; t < BM * CH; t += 256) {
+        const int rl = t / CH, ch = t - rl * CH;
+        const int row = m0 + rl;
+        if (row < Mv) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
+            const float v[4] = {c4[0], c4[1], c4[2], c4[3]};
+            epi(row, n0 + ch * 4, v);
         }
     }
 }

@@ -146,21 +146,24 @@ int launch_ln_bwd(const float* dy, const float* x, const float2* stats, const fl
 // ------------------------------------------------------------------------------------------
 // token dispatcher: logits, (Gumbel-)sigmoid, hard threshold, per-image index compaction in LDS
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
-    __shared__ float logit_s[NT];
+// (1) logits for every patch token: one wave per token, whole chip
+__global__ __launch_bounds__(256) void gate_logits_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ logit, int M) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= M) return;
+    if (t % NT == 0) return;  // cls token is never gated
+    Row12 wr, ur;
+    wr.load(w, lane);
+    ur.load(u + (size_t)t * D, lane);
+    const float l = dot12(ur, wr) + bias[0];
+    if (lane == 0) logit[t] = l;
+}
+// (2) per image: (Gumbel-)sigmoid, hard threshold, ballot/popcount compaction of the kept-token list
+__global__ __launch_bounds__(256) void gate_select_kernel(GateArgs a) {
     __shared__ int wave_cnt[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    Row12 wr;
-    wr.load(a.w, lane);
-    const float bias = a.b[0];
-    for (int n = 1 + wave; n < NT; n += 4) {
-        Row12 ur;
-        ur.load(a.u + ((size_t)b * NT + n) * D, lane);
-        const float l = dot12(ur, wr) + bias;
-        if (lane == 0) logit_s[n] = l;
-    }
-    __syncthreads();
     bool keep = false;
     const int n = tid;
     if (n < NT) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
             a.maskf[t] = 1.0f;
             a.soft[t] = 1.0f;
         } else {
-            const float l = logit_s[n];
+            const float l = a.soft[t];  // gate_logits_kernel parked the logit here
             float z = l;
             if (a.training) {
                 if (a.g1) {
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
 }
 
 int launch_gate(const GateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gate_kernel, dim3(a.batch), dim3(256), 0, s, a);
+    const int M = a.batch * NT;
+    hipLaunchKernelGGL(gate_logits_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.u, a.w, a.b, a.soft, M);
+    hipLaunchKernelGGL(gate_select_kernel, dim3(a.batch), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return 0;
 }
@@ -670,16 +675,30 @@ int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStre
     return 0;
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int stride, float* __restrict__ out,
-                                       int n, float alpha) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// 32 outputs x 8 partial-groups per workgroup; fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int stride,
+                                                              float* __restrict__ out, int n, float alpha) {
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
     float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * stride + i];
-    out[i] += alpha * acc;
+    if (i < n) {
+        const int per = (nparts + 7) / 8;
+        const int p0 = grp * per, p1 = min(nparts, p0 + per);
+#pragma unroll 4
+        for (int p = p0; p < p1; ++p) acc += partial[(size_t)p * stride + i];
+    }
+    red[grp][o] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][o];
+        out[i] += alpha * t;
+    }
 }
 int launch_reduce_partials(const float* partial, int nparts, int stride, float* out, int n, float alpha, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, stride, out, n, alpha);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, nparts, stride, out, n, alpha);
     LAUNCH_CHECK();
     return 0;
 }
