@@ -73,8 +73,9 @@ struct EpiFc1 {
     }
 };
 
+template <class AT>
 struct EpiFc2 {
-    const float* bias; float* x; const int* row_map; const float* row_mask; float* h_out;
+    const float* bias; float* x; const int* row_map; const float* row_mask; AT* h_out;
     __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
         const int dst = row_map ? row_map[row] : row;
         const float h0 = a[0] + bias[col], h1 = a[1] + bias[col + 1], h2 = a[2] + bias[col + 2],
@@ -184,10 +185,11 @@ struct EpiEmbed {
 // ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, class Epi>
+// ABL (measurement only): 0 = normal, 1 = no MFMA (loads + LDS reads only), 2 = no global loads
+template <int BM, int BN, class Epi, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                            int M, int N, int K, const int* __restrict__ m_dev,
-                                                           Epi epi) {
+                                                           const int* __restrict__ a_map, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
 #pragma unroll
     for (int t = 0; t < A_INSTR; ++t) {
         const int row = (t * 4 + wave) * 8 + lrow;
-        const int grow = min(m0 + row, Mv - 1);
+        int grow = min(m0 + row, Mv - 1);
+        if (a_map) grow = a_map[grow];  // gathered A rows (compacted MLP backward)
         a_src[t] = A + (size_t)grow * K + chunk * 8;
     }
 #pragma unroll
@@ -251,11 +254,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    stage(0, 0);
+    if (ABL != 2) stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (ABL != 2 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
+        if (ABL == 0 || ABL == 3 || ABL == 4) {
+            // variant: issue all 16 fragment reads of the K step, then the 32 MFMAs (one LDS-latency
+            // exposure per step instead of four); ABL 4 additionally raises the wave priority
+            bf16x8 af[2][TM], wf[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL == 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            if (ABL == 4) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int so = (ks == 0 ? fslot0 : fslot1) * 16;
@@ -267,8 +294,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (ABL == 1) {  // keep the fragment reads alive without the matrix pipe
+                        asm volatile("" ::"v"(wf[j]), "v"(af[i]));
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
         }
     }
 
@@ -308,7 +341,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
 template <class Epi>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                           int M, int N, int K, const int* __restrict__ m_dev,
-                                                          Epi epi) {
+                                                          const int* __restrict__ a_map, Epi epi) {
     constexpr int BM = 64, BN = 64, BK = 16;
     __shared__ float As[BK][BM + 4];
     __shared__ float Ws[BK][BN + 4];
@@ -320,7 +353,9 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
     const int tid = threadIdx.x;
     const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row, k offset
     const int ty = tid >> 4, tx = tid & 15;
-    const float* ap = A + (size_t)min(m0 + lr, Mv - 1) * K + lk;
+    int arow = min(m0 + lr, Mv - 1);
+    if (a_map) arow = a_map[arow];
+    const float* ap = A + (size_t)arow * K + lk;
     const float* wp = W + (size_t)(n0 + lr) * K + lk;
     float acc[4][4] = {};
     for (int k0 = 0; k0 < K; k0 += BK) {
@@ -368,13 +403,13 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, epi);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, a.a_map, epi);
     } else if (a.N % 64 == 0) {
         constexpr int BM = 128, BN = 64;
         const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
         const size_t lds = 2 * (BM + BN) * 64 * 2;
         auto kern = gemm_bf16_nt_kernel<BM, BN, Epi>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, epi);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, a.a_map, epi);
     } else {
         set_error("gemm_bf16: N=%d must be a multiple of 64", a.N);
         return -1;
@@ -391,7 +426,7 @@ static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     }
     const int grid = ((a.M + 63) / 64) * (a.N / 64);
     hipLaunchKernelGGL((gemm_f32_nt_kernel<Epi>), dim3(grid), dim3(256), 0, s, static_cast<const float*>(a.A),
-                       static_cast<const float*>(a.W), a.M, a.N, a.K, a.m_dev, epi);
+                       static_cast<const float*>(a.W), a.M, a.N, a.K, a.m_dev, a.a_map, epi);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -411,7 +446,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS_RESID:
             return run<AT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1: return run<AT>(a, EpiFc1<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
-        case EPI_FC2: return run<AT>(a, EpiFc2{a.bias, a.out_f32, a.row_map, a.row_mask, a.h_out}, s);
+        case EPI_FC2: return run<AT>(a, EpiFc2<AT>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out}, s);
         case EPI_GELU_BWD: return run<AT>(a, EpiGeluBwd<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.N}, s);
         case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
         case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
@@ -424,6 +459,35 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
     }
     set_error("gemm: unknown epilogue %d", (int)kind);
     return -1;
+}
+
+// measurement hook: plain bf16 GEMM into a bf16 C with a selectable kernel variant
+int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s) {
+    if (K % 64 != 0 || N % 128 != 0 || M <= 0) { set_error("gemm_raw: bad shape"); return -1; }
+    const bf16* a = static_cast<const bf16*>(A);
+    const bf16* w = static_cast<const bf16*>(W);
+    EpiStoreAT<bf16> epi{static_cast<bf16*>(C), N};
+    const int grid = ((M + 127) / 128) * (N / 128);
+    const size_t lds = 65536;
+#define RAW_CASE(v, ABLV)                                                                                          \
+    case v: {                                                                                                      \
+        auto kern = gemm_bf16_nt_kernel<128, 128, EpiStoreAT<bf16>, ABLV>;                                          \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, w, M, N, K, (const int*)nullptr, (const int*)nullptr, epi);          \
+        break;                                                                                                     \
+    }
+    switch (variant) {
+        RAW_CASE(0, 0)
+        RAW_CASE(1, 1)
+        RAW_CASE(2, 2)
+        RAW_CASE(3, 3)
+        RAW_CASE(4, 4)
+        RAW_CASE(5, 5)
+        default: set_error("gemm_raw: unknown variant %d", variant); return -1;
+    }
+#undef RAW_CASE
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {

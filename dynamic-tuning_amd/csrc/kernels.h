@@ -29,6 +29,7 @@ struct GemmArgs {
     const void* W = nullptr;      // [N,K]  AT
     int M = 0, N = 0, K = 0;
     const int* m_dev = nullptr;   // device-side count of valid rows (<= M), or null
+    const int* a_map = nullptr;   // gather: logical A row r is read from A[a_map[r]] (null = identity)
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -38,7 +39,7 @@ struct GemmArgs {
     const void* aux_at = nullptr;     // z (GELU_BWD) / d_act (AD_DGRAD_UP)
     const int* row_map = nullptr;     // FC2 scatter: compact row -> token row
     const float* row_mask = nullptr;  // FC2 masked-dense: per-token mask
-    float* h_out = nullptr;           // FC2: save h (fp32)
+    void* h_out = nullptr;            // FC2: save h (AT)
     const uint8_t* keep = nullptr;    // AD_DOWN injected keep mask [M, r]
     const float* pos = nullptr;       // EMBED
     int r = 0;                        // adapter rank (columns >= r of the padded bottleneck are dead)
@@ -51,6 +52,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
+int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // attention (N = 197, d = 64, 12 heads); q pre-scaled by 1/8 in the QKV epilogue
@@ -70,7 +72,7 @@ int launch_ln_fwd(int precision, const float* x, const float* w, const float* b,
                   int rows, hipStream_t s);
 int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s);
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
-int launch_ln_bwd(const float* dy, const float* x, const float2* stats, const float* w, const float* base,
+int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx_out, int rows, hipStream_t s);
 
 struct GateArgs {
@@ -134,7 +136,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 // dmask[token] = <g[token], h[r]> for kept rows (0 elsewhere)
 struct BwdPrepArgs {
     const float* g;         // [M,768]
-    const float* h;         // [K,768] saved MLP output (null: no gate gradient, e.g. teacher pass)
+    const void* h;          // [K,768] AT saved MLP output (null: no gate gradient, e.g. teacher pass)
     const int* dst_of;      // [M] token -> compact row (-1 = dropped), or null (dense: identity)
     const float* row_mask;  // masked-dense mode: per token mask (dH = mask*g), else null
     void* g_at;             // [M,768] AT (null when AT == float: g itself is used)
@@ -149,7 +151,7 @@ int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s);
 //   dlogit = (dmask[t] + dm_ext) * s(1-s)/tau + dtoken_logits ; partial dwg / dbg per block of rows
 struct TokBwdArgs {
     float* du;                 // [M,768] in/out (holds g + adapter dgrad on entry)
-    const float* dA2;          // [K,768] gradient w.r.t. LN2 output (null: skip MLP part)
+    const void* dA2;           // [K,768] AT gradient w.r.t. LN2 output (null: skip MLP part)
     const int* dst_of;         // [M] compact row of a token or -1 ; null = identity (dense)
     const float* u;            // [M,768]
     const float2* stats2;      // [M]

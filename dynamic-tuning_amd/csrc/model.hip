@@ -96,10 +96,16 @@ struct LayerW {  // frozen, library-owned
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
     void *q, *k, *v, *attn_o, *u_at, *z, *d_act;
-    float *lse, *u, *soft, *maskf, *h;
+    float *lse, *u, *soft, *maskf;
+    void* h;
     int *keep_local, *offsets, *total, *row_src, *dst_of;
 };
+struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
+    void *xn, *h1, *g_at, *dH, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn;
+    float *g, *delta, *dmask, *tok_partial, *wg_partial;
+};
 struct Slot {
+    Transients T;
     std::vector<LayerS> L;
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
     int* counts = nullptr;   // [depth*B]
@@ -127,10 +133,11 @@ struct dyt_ctx {
     // trainable flat layout
     int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
     std::vector<Slot> slots;
-    // transients
-    void *xn, *h1, *g_at, *dH, *dZ, *ddz, *du_at, *dO, *dqkv;
-    float *g, *dA2, *dxn, *delta, *dmask, *tok_partial, *wg_partial;
-    float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses;
+    float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses, *grad2;
+    // second stream: the student and the teacher pass of a step are independent and run concurrently
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -199,28 +206,32 @@ static void layout(dyt_ctx* c, bool dry) {
             L.u_at = c->prec == 0 ? (void*)L.u : carve_at(c, M * D, dry);
             L.z = carve_at(c, M * DM, dry);
             L.d_act = carve_at(c, M * RP, dry);
-            L.h = carve<float>(c, M * D, dry);
+            L.h = carve_at(c, M * D, dry);
             L.soft = carve<float>(c, M, dry); L.maskf = carve<float>(c, M, dry);
             L.keep_local = carve<int>(c, M, dry); L.offsets = carve<int>(c, B, dry);
             L.total = carve<int>(c, 4, dry); L.row_src = carve<int>(c, M, dry); L.dst_of = carve<int>(c, M, dry);
         }
     }
-    c->xn = carve_at(c, M * D, dry);
-    c->h1 = carve_at(c, M * DM, dry);
-    c->g_at = carve_at(c, M * D, dry);
-    c->dH = carve_at(c, M * D, dry);
-    c->dZ = carve_at(c, M * DM, dry);
-    c->ddz = carve_at(c, M * RP, dry);
-    c->du_at = carve_at(c, M * D, dry);
-    c->dO = carve_at(c, M * D, dry);
-    c->dqkv = carve_at(c, M * 3 * D, dry);
-    c->g = carve<float>(c, M * D, dry);
-    c->dA2 = carve<float>(c, M * D, dry);
-    c->dxn = carve<float>(c, M * D, dry);
-    c->delta = carve<float>(c, B * NH * NT, dry);
-    c->dmask = carve<float>(c, M, dry);
-    c->tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
-    c->wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)D * 80, dry);
+    for (int sl = 0; sl < cf.slots; ++sl) {
+        Transients& T = c->slots[sl].T;
+        T.xn = carve_at(c, M * D, dry);
+        T.h1 = carve_at(c, M * DM, dry);
+        T.g_at = carve_at(c, M * D, dry);
+        T.dH = carve_at(c, M * D, dry);
+        T.dZ = carve_at(c, M * DM, dry);
+        T.ddz = carve_at(c, M * RP, dry);
+        T.du_at = carve_at(c, M * D, dry);
+        T.dO = carve_at(c, M * D, dry);
+        T.dqkv = carve_at(c, M * 3 * D, dry);
+        T.dA2 = carve_at(c, M * D, dry);
+        T.dxn = carve_at(c, M * D, dry);
+        T.g = carve<float>(c, M * D, dry);
+        T.delta = carve<float>(c, B * NH * NT, dry);
+        T.dmask = carve<float>(c, M, dry);
+        T.tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
+        T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)D * 80, dry);
+    }
+    c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
     c->dl_s = carve<float>(c, B * C, dry); c->dl_t = carve<float>(c, B * C, dry);
     c->logits_s = carve<float>(c, B * C, dry); c->logits_t = carve<float>(c, B * C, dry);
     c->dtok = carve<float>(c, 4, dry);
@@ -283,6 +294,9 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
     if (!c) return DYT_OK;
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto e : c->pool) hipEventDestroy(e);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->arena) hipFree(c->arena);
     delete c;
     return DYT_OK;
@@ -460,13 +474,14 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     Slot& S = c->slots[slot];
+    Transients& T = S.T;
     S.valid = false;
     if (do_prep) { int rc = prep_adapters(c, trainable, s); if (rc) return rc; }
 
     // patch embedding: im2col + GEMM (+bias +pos_embed), cls rows
-    RUN(2, 0, launch_im2col(P, images, c->xn, B, s));
+    RUN(2, 0, launch_im2col(P, images, T.xn, B, s));
     {
-        GemmArgs a; a.A = c->xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
+        GemmArgs a; a.A = T.xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
         a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0];
         RUN_GEMM(EPI_EMBED, a);
     }
@@ -478,9 +493,9 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
-        RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, c->xn, L.st1, M, s));
+        RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s));
         {
-            GemmArgs a; a.A = c->xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
+            GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
             a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
             RUN_GEMM(EPI_QKV, a);
         }
@@ -507,10 +522,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         }
         if (!dense) {
             RUN(2, 0, launch_scan(counts, L.offsets, L.total, B, s));
-            RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.offsets, L.maskf, c->xn, L.st2,
+            RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.offsets, L.maskf, T.xn, L.st2,
                                        L.row_src, L.dst_of, B, s));
         } else {
-            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, c->xn, L.st2, M, s));
+            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s));
         }
         // adapter (all tokens): x_out = u + scale * up(dropout(relu(down(u))))
         {
@@ -529,12 +544,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // MLP on the kept (or all) tokens, scatter-add into the residual stream
         const int* kdev = dense ? nullptr : L.total;
         {
-            GemmArgs a; a.A = c->xn; a.W = W.fc1_w; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
-            a.out_at = c->h1; a.out_at2 = save ? L.z : nullptr;
+            GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
+            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr;
             RUN_GEMM(EPI_FC1, a);
         }
         {
-            GemmArgs a; a.A = c->h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
+            GemmArgs a; a.A = T.h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
             a.out_f32 = xo; a.row_map = dense ? nullptr : L.row_src; a.row_mask = masked_dense ? L.maskf : nullptr;
             a.h_out = (save && !complete) ? L.h : nullptr;
             RUN_GEMM(EPI_FC2, a);
@@ -561,6 +576,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                          const float* dtok, const float* dtoken_logits, float* grad, hipStream_t s) {
     if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
     Slot& S = c->slots[slot];
+    Transients& T = S.T;
     if (!S.valid) { set_error("slot %d holds no saved forward (call dyt_forward with DYT_F_SAVE)", slot); return DYT_ERR_STATE; }
     if (!dlogits || !grad || !trainable) { set_error("null argument"); return DYT_ERR_ARG; }
     const int P = c->prec, depth = c->cfg.depth, B = S.batch, M = B * NT, r = c->cfg.ffn_num;
@@ -572,7 +588,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const float scale = c->cfg.adapter_scale;
-    float* g = c->g;
+    float* g = T.g;
 
     RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw, g,
                               grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes, s));
@@ -586,81 +602,81 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         const int* kdev = dense ? nullptr : L.total;
 
         // ---- 1. prep: AT copy of g, gathered/masked MLP gradient rows, <g,h> per token ----
-        const bool need_dH = !dense || masked_dense;
-        void* g_at = P == 0 ? nullptr : c->g_at;
+        const bool need_dH = masked_dense;  // compact mode gathers rows of g_at inside the GEMM (a_map)
+        void* g_at = P == 0 ? nullptr : T.g_at;
         if (g_at || need_dH || student) {
             BwdPrepArgs a;
             a.g = g; a.h = student ? L.h : nullptr; a.dst_of = dense ? nullptr : L.dst_of;
             a.row_mask = masked_dense ? L.maskf : nullptr;
-            a.g_at = g_at; a.dH = (need_dH && !first) ? c->dH : nullptr; a.dmask = student ? c->dmask : nullptr; a.M = M;
+            a.g_at = g_at; a.dH = (need_dH && !first) ? T.dH : nullptr; a.dmask = student ? T.dmask : nullptr; a.M = M;
             RUN(2, 0, launch_bwd_prep(P, a, s));
         }
         const void* A_g = g_at ? g_at : (const void*)g;
         // ---- 2. MLP dgrad (frozen weights): dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
-            const void* A_dh = need_dH ? (const void*)c->dH : A_g;
+            const void* A_dh = need_dH ? (const void*)T.dH : A_g;
             {
                 GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
-                a.out_at = c->dZ;
+                a.a_map = dense ? nullptr : L.row_src; a.out_at = T.dZ;
                 RUN_GEMM(EPI_GELU_BWD, a);
             }
             {
-                GemmArgs a; a.A = c->dZ; a.W = W.fc1_wT; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.out_f32 = c->dA2;
-                RUN_GEMM(EPI_STORE_F32, a);
+                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
+                RUN_GEMM(EPI_STORE_AT, a);
             }
         }
         // ---- 3. adapter: dgrad through up_proj, both wgrads, dgrad through down_proj ----
         {
             GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
-            a.aux_at = L.d_act; a.out_at = c->ddz; a.scale = scale; a.inv_keep = inv_keep;
+            a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
             RUN_GEMM(EPI_AD_DGRAD_UP, a);
         }
         {
-            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = c->wg_partial;
+            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = T.wg_partial;
             a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
             a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
             RUN(2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
         }
         {
-            WgradArgs a; a.X = L.u_at; a.Y = c->ddz; a.M = M; a.r = r; a.partial = c->wg_partial;
+            WgradArgs a; a.X = L.u_at; a.Y = T.ddz; a.M = M; a.r = r; a.partial = T.wg_partial;
             a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
             a.out_xsum = nullptr; a.alpha_x = 0.f;
             RUN(2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
         }
-        RUN(2, 0, launch_colsum64(P, c->ddz, M, r, gbase + c->off_db, 1.0f, s));  // down_proj.bias
+        RUN(2, 0, launch_colsum64(P, T.ddz, M, r, gbase + c->off_db, 1.0f, s));  // down_proj.bias
         if (!first) {
-            GemmArgs a; a.A = c->ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
+            GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
             a.out_f32 = g; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
             RUN_GEMM(EPI_STORE_F32, a);
         }
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
         if (!first || student) {
             TokBwdArgs a;
-            a.du = g; a.dA2 = first ? nullptr : c->dA2; a.dst_of = dense ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
+            a.du = g; a.dA2 = first ? nullptr : T.dA2; a.dst_of = dense ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
             a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
-            a.dmask = c->dmask;
+            a.dmask = T.dmask;
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
-            a.du_at = (P != 0 && !first) ? c->du_at : nullptr; a.partial = c->tok_partial; a.M = M; a.write_du = !first;
+            a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = T.tok_partial; a.M = M; a.write_du = !first;
             int nblk = 0;
             RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
-            if (student) RUN(2, 0, launch_reduce_partials(c->tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s));
+            if (student) RUN(2, 0, launch_reduce_partials(T.tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s));
         }
         if (first) break;
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
-            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)c->du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
-            a.out_at = c->dO;
+            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
+            a.out_at = T.dO;
             RUN_GEMM(EPI_STORE_AT, a);
         }
         RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
-            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, c->dO, L.lse, c->delta, c->dqkv, B, s));
+            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s));
         {
-            GemmArgs a; a.A = c->dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_f32 = c->dxn;
-            RUN_GEMM(EPI_STORE_F32, a);
+            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
+            RUN_GEMM(EPI_STORE_AT, a);
         }
-        RUN(2, 0, launch_ln_bwd(c->dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, s));
+        RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, s));
     }
     return DYT_OK;
 }
@@ -715,24 +731,52 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     float* ls = logits_s ? logits_s : c->logits_s;
     float* lt = logits_t ? logits_t : c->logits_t;
     const int fl = (flags & DYT_F_MASKED_DENSE) | DYT_F_TRAINING | DYT_F_SAVE;
-    int rc = forward_impl(c, 0, images, batch, fl, trainable, g1, g2, keep_mask, seed, ls, token_select, nullptr, true, s);
+    // Two-stream schedule: student pass on the caller's stream, teacher pass on a side stream
+    // (fork/join with events; graph-capturable).  Profiling mode runs serially for clean per-kernel times.
+    const bool par = c->overlap && !c->prof;
+    if (par && !c->side) {
+        DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t s2 = par ? c->side : s;
+    int rc = prep_adapters(c, trainable, s);
+    if (rc) return rc;
+    if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
+    rc = forward_impl(c, 0, images, batch, fl, trainable, g1, g2, keep_mask, seed, ls, token_select, nullptr, false, s);
     if (rc) return rc;
     // the teacher pass draws its own noise in the reference (mask discarded): only the dropout stream matters
     rc = forward_impl(c, 1, images, batch, fl | DYT_F_COMPLETE, trainable, g1 ? g1 + nz : nullptr, g2 ? g2 + nz : nullptr,
-                      keep_mask ? keep_mask + kz : nullptr, seed, lt, nullptr, nullptr, false, s);
+                      keep_mask ? keep_mask + kz : nullptr, seed, lt, nullptr, nullptr, false, s2);
     if (rc) return rc;
+    if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_join, s2)); DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0)); }
     rc = dyt_loss(c, 0, ls, lt, targets, batch, token_target_ratio, token_loss_ratio, token_minimal, token_minimal_weight,
                   c->dl_s, c->dl_t, out_losses, c->dtok, stream);
     if (rc) return rc;
+    float* gt = par ? c->grad2 : grad_flat;  // teacher-pass gradients
+    if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
     DYT_HIP_CHECK(hipMemsetAsync(grad_flat, 0, (size_t)c->n_train * sizeof(float), s));
+    if (par) DYT_HIP_CHECK(hipMemsetAsync(c->grad2, 0, (size_t)c->n_train * sizeof(float), s2));
     rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s);
     if (rc) return rc;
-    return backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, grad_flat, s);
+    rc = backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, gt, s2);
+    if (rc) return rc;
+    if (par) {
+        DYT_HIP_CHECK(hipEventRecord(c->ev_join, s2));
+        DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+        rc = launch_reduce_partials(c->grad2, 1, 0, grad_flat, (int)c->n_train, 1.0f, s);  // grad_flat += grad2
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------
 // single-kernel entry points (unit tests).  These allocate scratch and synchronise: test-only.
 // ------------------------------------------------------------------------------------------
+extern "C" int dyt_gemm_bf16_raw(const void* a, const void* w, void* cmat, int M, int N, int K, int variant, void* stream) {
+    if (!a || !w || !cmat) { set_error("null argument"); return DYT_ERR_ARG; }
+    return launch_gemm_raw(a, w, cmat, M, N, K, variant, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int dyt_layernorm(const float* x, const float* w, const float* b, float* out, int rows, void* stream) {
     if (!x || !w || !b || !out || rows < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
     return launch_ln_fwd_f32out(x, w, b, out, rows, static_cast<hipStream_t>(stream));

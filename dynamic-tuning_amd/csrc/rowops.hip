@@ -103,14 +103,15 @@ __device__ __forceinline__ void ln_bwd_row(Row12& dy, const Row12& x, const Row1
     for (int i = 0; i < 12; ++i) dy.v[i] = st.y * (dy.v[i] - s1 - xh.v[i] * s2);
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <class AT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ w,
                                                      const float* __restrict__ base, float* __restrict__ dx, int rows) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     Row12 g, xr, wr;
-    g.load(dy + (size_t)row * D, lane);
+    g.load_at(dy + (size_t)row * D, lane);
     xr.load(x + (size_t)row * D, lane);
     wr.load(w, lane);
     ln_bwd_row(g, xr, wr, stats[row]);
@@ -136,9 +137,12 @@ int launch_ln_fwd(int precision, const float* x, const float* w, const float* b,
 int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s) {
     return launch_ln_fwd(0, x, w, b, out, nullptr, rows, s);
 }
-int launch_ln_bwd(const float* dy, const float* x, const float2* stats, const float* w, const float* base, float* dx,
-                  int rows, hipStream_t s) {
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, stats, w, base, dx, rows);
+int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
+                  float* dx, int rows, hipStream_t s) {
+    if (precision == 0)
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx, rows);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)dy, x, stats, w, base, dx, rows);
     LAUNCH_CHECK();
     return 0;
 }
@@ -555,7 +559,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 // backward prep of a block: AT copy of g, gathered MLP gradient rows, <g, h> per token
 // ------------------------------------------------------------------------------------------
 template <class AT>
-__global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ h,
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ g, const AT* __restrict__ h,
                                                        const int* __restrict__ dst_of, const float* __restrict__ row_mask,
                                                        AT* __restrict__ g_at, AT* __restrict__ dH,
                                                        float* __restrict__ dmask, int M) {
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     if (r >= 0) {
         if (h) {
             Row12 hr;
-            hr.load(h + (size_t)r * D, lane);
+            hr.load_at(h + (size_t)r * D, lane);
             dm = dot12(gr, hr);
         }
         if (dH) {
@@ -587,10 +591,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
 int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s) {
     const int grid = (a.M + 3) / 4;
     if (precision == 0)
-        hipLaunchKernelGGL(bwd_prep_kernel<float>, dim3(grid), dim3(256), 0, s, a.g, a.h, a.dst_of, a.row_mask,
+        hipLaunchKernelGGL(bwd_prep_kernel<float>, dim3(grid), dim3(256), 0, s, a.g, (const float*)a.h, a.dst_of, a.row_mask,
                            (float*)a.g_at, (float*)a.dH, a.dmask, a.M);
     else
-        hipLaunchKernelGGL(bwd_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, a.g, a.h, a.dst_of, a.row_mask,
+        hipLaunchKernelGGL(bwd_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, a.g, (const bf16*)a.h, a.dst_of, a.row_mask,
                            (bf16*)a.g_at, (bf16*)a.dH, a.dmask, a.M);
     LAUNCH_CHECK();
     return 0;
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
             const int r = a.dst_of ? a.dst_of[t] : t;
             if (r >= 0) {
                 Row12 dy;
-                dy.load(a.dA2 + (size_t)r * D, lane);
+                dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
                 ln_bwd_row(dy, ur, ln2w, a.stats2[t]);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i];

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the bf16 GEMM kernel variants on the path's shapes (MI355X)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
+from _lib import check, lib, ptr, stream_ptr  # noqa: E402
+
+SHAPES = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072), (25216, 768, 2304), (17690, 3072, 768)]
+
+
+def bench(M, N, K, variant, iters=20):
+    a = (torch.randn(M, K, device="cuda") * 1.0).bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        check(lib().dyt_gemm_bf16_raw(ptr(a), ptr(w), ptr(c), M, N, K, variant, stream_ptr()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        check(lib().dyt_gemm_bf16_raw(ptr(a), ptr(w), ptr(c), M, N, K, variant, stream_ptr()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    err = None
+    if variant in CHECKED:
+        ref = (a[:512].float() @ w.float().t())
+        err = float((c[:512].float() - ref).abs().max() / ref.abs().max())
+    return ms, err
+
+
+if __name__ == "__main__":
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2]
+    CHECKED = {v for v in variants if v not in (1, 2)}
+    print("%-22s" % "M,N,K" + "".join("  v%-2d us / TF/s (err)     " % v for v in variants))
+    for (M, N, K) in SHAPES:
+        line = "%-22s" % ("%d,%d,%d" % (M, N, K))
+        for v in variants:
+            ms, err = bench(M, N, K, v)
+            line += "  %7.1f / %6.1f %-9s" % (ms * 1e3, 2.0 * M * N * K / ms / 1e9, "" if err is None else "(%.1e)" % err)
+        print(line, flush=True)
