@@ -75,7 +75,7 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ src, int ld,
 // ------------------------------------------------------------------------------------------
 // forward, bf16
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+__global__ __launch_bounds__(448) void attn_fwd_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                             const bf16* __restrict__ v, bf16* __restrict__ out,
                                                             float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,13 +84,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
     const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
     const bf16* qb = q + (size_t)bh * NT * HD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_rows<256>(k + (size_t)bh * NT * HD, HD, Ks, nullptr, tid);
-    stage_rows<256>(v + (size_t)bh * NT * HD, HD, nullptr, Vt, tid);
+    stage_rows<448>(k + (size_t)bh * NT * HD, HD, Ks, nullptr, tid);
+    stage_rows<448>(v + (size_t)bh * NT * HD, HD, nullptr, Vt, tid);
     __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5;
 
-#pragma unroll 1
-    for (int qt = wave; qt < 7; qt += 4) {
+    {   // one 32-row query tile per wave (7 waves)
+        const int qt = wave;
         const int qrow = qt * 32 + l31;
         const int qr = min(qrow, NT - 1);
         bf16x8 qf[4];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
 // ------------------------------------------------------------------------------------------
 // backward, bf16: dQ (+ delta = rowsum(dO * O)) per query tile
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+__global__ __launch_bounds__(448) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                                const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ dout,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
@@ -176,13 +176,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16* __
     const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
     const bf16* qb = q + (size_t)bh * NT * HD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_rows<256>(k + (size_t)bh * NT * HD, HD, Ks, Kt, tid);
-    stage_rows<256>(v + (size_t)bh * NT * HD, HD, Vs, nullptr, tid);
+    stage_rows<448>(k + (size_t)bh * NT * HD, HD, Ks, Kt, tid);
+    stage_rows<448>(v + (size_t)bh * NT * HD, HD, Vs, nullptr, tid);
     __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5;
 
-#pragma unroll 1
-    for (int qt = wave; qt < 7; qt += 4) {
+    {   // one 32-row query tile per wave (7 waves)
+        const int qt = wave;
         const int qrow = qt * 32 + l31;
         const int qr = min(qrow, NT - 1);
         const size_t trow = ((size_t)b * NT + qr) * D + h * HD;
@@ -513,7 +513,7 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
                            (const float*)v, (float*)out, lse);
     } else {
         const size_t lds = ROW_IMG + TR_IMG;
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(grid), dim3(256), lds, s, (const bf16*)q, (const bf16*)k,
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(grid), dim3(448), lds, s, (const bf16*)q, (const bf16*)k,
                            (const bf16*)v, (bf16*)out, lse);
     }
     DYT_HIP_CHECK(hipGetLastError());
@@ -545,7 +545,7 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
             if (set_lds((const void*)attn_bwd_dkv_bf16_kernel, lds2)) return -2;
             once = true;
         }
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(grid), dim3(256), lds1, s, (const bf16*)q, (const bf16*)k,
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(grid), dim3(448), lds1, s, (const bf16*)q, (const bf16*)k,
                            (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv);
         hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(grid), dim3(512), lds2, s, (const bf16*)q, (const bf16*)k,
                            (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dqkv);

@@ -185,16 +185,25 @@ struct EpiEmbed {
 // ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------
-// ABL (measurement only): 0 = normal, 1 = no MFMA (loads + LDS reads only), 2 = no global loads
-template <int BM, int BN, class Epi, int ABL = 0>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                                           int M, int N, int K, const int* __restrict__ m_dev,
-                                                           const int* __restrict__ a_map, Epi epi) {
+// Tile BM x BN x 64, WAVES_M x WAVES_N waves of 64 lanes (each wave owns a (BM/WAVES_M) x (BN/WAVES_N)
+// block of 16x16 MFMA tiles).  Shipped configurations:
+//   128x128, 2x2 waves, 64 KB LDS, 2 workgroups / CU  -- N = 768 GEMMs (tile quantisation) and default
+//   256x256, 2x4 waves, 128 KB LDS, 1 workgroup / CU  -- wide-N GEMMs: half the L2->LDS bytes per FLOP
+//   128x64,  2x2 waves                                 -- adapter bottleneck (N = 64)
+// ABL (measurement only): 0 = product, 1 = no MFMA (loads + LDS reads only), 2 = no global loads,
+// 5 = per-k-step fragment loads (the first version's ordering)
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_nt_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
+    const int* __restrict__ a_map, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = 64;
+    constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // 1 KiB (8 rows) per wave-instruction
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // 1 KiB (8 rows x 128 B) per wave-instruction
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
+    constexpr bool BOTH_KS = (TM + TN) * 2 * 4 <= 72;  // hold both k-substeps' fragments when registers allow
 
     const int Mv = m_dev ? min(*m_dev, M) : M;
     // XCD-aware block remap (bijective): consecutive logical tiles share an A row panel and
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
     if (m0 >= Mv) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
 
     // ---- staging: lane -> (row-in-8, 16B slot); source chunk = slot ^ row ----
     const int lrow = lane >> 3, slot = lane & 7, chunk = slot ^ lrow;
@@ -216,14 +225,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
     const bf16* b_src[B_INSTR];
 #pragma unroll
     for (int t = 0; t < A_INSTR; ++t) {
-        const int row = (t * 4 + wave) * 8 + lrow;
+        const int row = (t * NW + wave) * 8 + lrow;
         int grow = min(m0 + row, Mv - 1);
         if (a_map) grow = a_map[grow];  // gathered A rows (compacted MLP backward)
         a_src[t] = A + (size_t)grow * K + chunk * 8;
     }
 #pragma unroll
     for (int t = 0; t < B_INSTR; ++t) {
-        const int row = (t * 4 + wave) * 8 + lrow;
+        const int row = (t * NW + wave) * 8 + lrow;
         b_src[t] = W + (size_t)(n0 + row) * K + chunk * 8;
     }
     auto stage = [&](int buf, int kt) {
@@ -231,12 +240,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
 #pragma unroll
         for (int t = 0; t < A_INSTR; ++t)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[t] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(base + (t * 4 + wave) * 1024),
+                                             (__attribute__((address_space(3))) void*)(base + (t * NW + wave) * 1024),
                                              16, 0, 0);
 #pragma unroll
         for (int t = 0; t < B_INSTR; ++t)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[t] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (t * 4 + wave) * 1024),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (t * NW + wave) * 1024),
                                              16, 0, 0);
     };
 
@@ -259,9 +268,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
         __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
         if (ABL != 2 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
-        if (ABL == 0 || ABL == 3 || ABL == 4) {
-            // variant: issue all 16 fragment reads of the K step, then the 32 MFMAs (one LDS-latency
-            // exposure per step instead of four); ABL 4 additionally raises the wave priority
+        if (BOTH_KS && ABL != 5 && ABL != 1) {
+            // issue all fragment reads of the K step, then the MFMAs: one LDS-latency exposure per step
             bf16x8 af[2][TM], wf[2][TN];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -272,7 +280,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
                 for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ABL == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -280,57 +287,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16* __restric
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-            if (ABL == 4) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int so = (ks == 0 ? fslot0 : fslot1) * 16;
-            bf16x8 af[TM], wf[TN];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+                bf16x8 af[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
+                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (ABL == 1) {  // keep the fragment reads alive without the matrix pipe
-                        asm volatile("" ::"v"(wf[j]), "v"(af[i]));
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if (ABL == 1) {  // keep the fragment reads alive without the matrix pipe
+                            asm volatile("" ::"v"(wf[j]), "v"(af[i]));
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                        }
                     }
-                }
-        }
+            }
         }
     }
 
-    // ---- epilogue through LDS: acc[i][j][e] = C[wm*WM + i*16 + (lane&15)][wn*WN + j*16 + (lane>>4)*4 + e].
-    // The fragment layout gives each store instruction 16 rows x 64 B; instead the tile is parked in the
-    // (now free) staging ring as fp32 [BM][BN] with the 16-B chunk index XOR-swizzled by (row & 7)
-    // (conflict-free ds_write_b128 / ds_read_b128) and read back row-major, so every global access of
-    // the epilogue functor is a full-row, 16-B-per-lane coalesced transaction.
-    __syncthreads();
-    float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int CH = BN / 4;
+    if constexpr (BM * BN * 4 <= 2 * STAGE) {
+        // ---- epilogue through LDS: acc[i][j][e] = C[wm*WM + i*16 + (lane&15)][wn*WN + j*16 + (lane>>4)*4 + e].
+        // The fragment layout gives each store instruction 16 rows x 64 B; instead the tile is parked in the
+        // (now free) staging ring as fp32 [BM][BN] with the 16-B chunk index XOR-swizzled by (row & 7)
+        // (conflict-free ds_write_b128 / ds_read_b128) and read back row-major, so every global access of
+        // the epilogue functor is a full-row, 16-B-per-lane coalesced transaction.
+        __syncthreads();
+        float* Cs = reinterpret_cast<float*>(smem);
+        constexpr int CH = BN / 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int rl = wm * WM + i * 16 + frow;
+        for (int i = 0; i < TM; ++i) {
+            const int rl = wm * WM + i * 16 + frow;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ch = ((wn * WN + j * 16) >> 2) + (lane >> 4);
-            *reinterpret_cast<f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2)) = acc[i][j];
+            for (int j = 0; j < TN; ++j) {
+                const int ch = ((wn * WN + j * 16) >> 2) + (lane >> 4);
+                *reinterpret_cast<f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2)) = acc[i][j];
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll 4
-    for (int t = tid; t < BM * CH; t += 256) {
-        const int rl = t / CH, ch = t - rl * CH;
-        const int row = m0 + rl;
-        if (row < Mv) {
-            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
-            const float v[4] = {c4[0], c4[1], c4[2], c4[3]};
-            epi(row, n0 + ch * 4, v);
+        for (int t = tid; t < BM * CH; t += NTHR) {
+            const int rl = t / CH, ch = t - rl * CH;
+            const int row = m0 + rl;
+            if (row < Mv) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
+                const float v[4] = {c4[0], c4[1], c4[2], c4[3]};
+                epi(row, n0 + ch * 4, v);
+            }
+        }
+    } else {
+        // ---- big tiles: the fp32 tile does not fit the ring; store straight from the fragments
+        // (each lane owns 4 consecutive columns of 16 rows) ----
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * WM + i * 16 + frow;
+            if (row < Mv) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    epi(row, n0 + wn * WN + j * 16 + (lane >> 4) * 4, v);
+                }
+            }
         }
     }
 }
@@ -387,35 +409,35 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi>
+static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const size_t lds = 2 * (BM + BN) * 64 * 2;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
+                       a.M, a.N, a.K, a.m_dev, a.a_map, epi);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int g_big_tile_min_n = 1 << 30;  // 256x256 tiles measured SLOWER with this loop structure (1 WG/CU: no
+                                         // cross-workgroup overlap of barrier stalls / epilogue) -- kept for later rounds
+
 template <class Epi>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
-    const bf16* A = static_cast<const bf16*>(a.A);
-    const bf16* W = static_cast<const bf16*>(a.W);
-    if (a.N % 128 == 0) {
-        constexpr int BM = 128, BN = 128;
-        const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-        const size_t lds = 2 * (BM + BN) * 64 * 2;
-        auto kern = gemm_bf16_nt_kernel<BM, BN, Epi>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, a.a_map, epi);
-    } else if (a.N % 64 == 0) {
-        constexpr int BM = 128, BN = 64;
-        const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-        const size_t lds = 2 * (BM + BN) * 64 * 2;
-        auto kern = gemm_bf16_nt_kernel<BM, BN, Epi>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, A, W, a.M, a.N, a.K, a.m_dev, a.a_map, epi);
-    } else {
-        set_error("gemm_bf16: N=%d must be a multiple of 64", a.N);
-        return -1;
-    }
-    DYT_HIP_CHECK(hipGetLastError());
-    return 0;
+    if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
+    if (a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
+    if (a.N % 64 == 0) return launch_bf16_cfg<128, 64, 2, 2, 0>(a, epi, s);
+    set_error("gemm_bf16: N=%d must be a multiple of 64", a.N);
+    return -1;
 }
 
 template <class Epi>
@@ -461,33 +483,40 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
     return -1;
 }
 
+template <int NOUT>
+struct EpiProbe {  // measurement only
+    bf16* out; int ld; size_t plane;
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const size_t o = (size_t)row * ld + col;
+        const float g0 = gelu_fwd<bf16>(a[0]), g1 = gelu_fwd<bf16>(a[1]), g2 = gelu_fwd<bf16>(a[2]), g3 = gelu_fwd<bf16>(a[3]);
+        if (NOUT >= 1) store4(out + o, g0, g1, g2, g3);
+        if (NOUT >= 2) store4(out + plane + o, a[0], a[1], a[2], a[3]);
+        if (NOUT == 0) asm volatile("" ::"v"(g0), "v"(g1), "v"(g2), "v"(g3));
+    }
+};
+
 // measurement hook: plain bf16 GEMM into a bf16 C with a selectable kernel variant
 int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s) {
-    if (K % 64 != 0 || N % 128 != 0 || M <= 0) { set_error("gemm_raw: bad shape"); return -1; }
-    const bf16* a = static_cast<const bf16*>(A);
-    const bf16* w = static_cast<const bf16*>(W);
+    if (K % 64 != 0 || N % 256 != 0 || M <= 0) { set_error("gemm_raw: bad shape"); return -1; }
+    GemmArgs a; a.A = A; a.W = W; a.M = M; a.N = N; a.K = K;
     EpiStoreAT<bf16> epi{static_cast<bf16*>(C), N};
-    const int grid = ((M + 127) / 128) * (N / 128);
-    const size_t lds = 65536;
-#define RAW_CASE(v, ABLV)                                                                                          \
-    case v: {                                                                                                      \
-        auto kern = gemm_bf16_nt_kernel<128, 128, EpiStoreAT<bf16>, ABLV>;                                          \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, w, M, N, K, (const int*)nullptr, (const int*)nullptr, epi);          \
-        break;                                                                                                     \
-    }
     switch (variant) {
-        RAW_CASE(0, 0)
-        RAW_CASE(1, 1)
-        RAW_CASE(2, 2)
-        RAW_CASE(3, 3)
-        RAW_CASE(4, 4)
-        RAW_CASE(5, 5)
-        default: set_error("gemm_raw: unknown variant %d", variant); return -1;
+        case 0: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
+        case 1: return launch_bf16_cfg<128, 128, 2, 2, 1>(a, epi, s);
+        case 2: return launch_bf16_cfg<128, 128, 2, 2, 2>(a, epi, s);
+        case 5: return launch_bf16_cfg<128, 128, 2, 2, 5>(a, epi, s);
+        case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
+        case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);
+        case 12: return launch_bf16_cfg<128, 256, 2, 4, 0>(a, epi, s);
+        case 13: return launch_bf16_cfg<256, 256, 2, 4, 1>(a, epi, s);
+        case 14: return launch_bf16_cfg<256, 256, 2, 4, 2>(a, epi, s);
+        // epilogue-traffic probes (C must hold 2*M*N bf16): FC1-style epilogue with 2 / 1 / 0 output streams
+        case 20: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiProbe<2>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
+        case 21: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiProbe<1>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
+        case 22: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiProbe<0>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
     }
-#undef RAW_CASE
-    DYT_HIP_CHECK(hipGetLastError());
-    return 0;
+    set_error("gemm_raw: unknown variant %d", variant);
+    return -1;
 }
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {

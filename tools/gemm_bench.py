@@ -9,13 +9,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
 from _lib import check, lib, ptr, stream_ptr  # noqa: E402
 
-SHAPES = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072), (25216, 768, 2304), (17690, 3072, 768)]
+SHAPES = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072), (17690, 3072, 768)]
 
 
 def bench(M, N, K, variant, iters=20):
     a = (torch.randn(M, K, device="cuda") * 1.0).bfloat16()
     w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    c = torch.empty(2 * M, N, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
         check(lib().dyt_gemm_bf16_raw(ptr(a), ptr(w), ptr(c), M, N, K, variant, stream_ptr()))
     torch.cuda.synchronize()
@@ -35,7 +35,7 @@ def bench(M, N, K, variant, iters=20):
 
 if __name__ == "__main__":
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2]
-    CHECKED = {v for v in variants if v not in (1, 2)}
+    CHECKED = {v for v in variants if v in (0, 5, 10, 11, 12)}
     print("%-22s" % "M,N,K" + "".join("  v%-2d us / TF/s (err)     " % v for v in variants))
     for (M, N, K) in SHAPES:
         line = "%-22s" % ("%d,%d,%d" % (M, N, K))
