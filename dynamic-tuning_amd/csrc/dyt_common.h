@@ -61,28 +61,28 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // bf16-mode GELU: Abramowitz-Stegun 7.1.26 erfc polynomial (|err| <= 1.5e-7, far below bf16 output
 // rounding), written in the erfc form so 1+erf has no cancellation for x << 0; one v_exp + one v_rcp.
 //   cdf2(x) = 1 + erf(x/sqrt2) ;  e = exp(-x^2/2)
-__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf2, float& e) {
-    const float u = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
-    float y = fmaf(1.061405429f, t, -1.453152027f);
-    y = fmaf(y, t, 1.421413741f);
-    y = fmaf(y, t, -0.284496736f);
-    y = fmaf(y, t, 0.254829592f);
-    e = __expf(-u * u);
-    const float ye = y * t * e;          // erfc(u)
-    cdf2 = x >= 0.f ? 2.0f - ye : ye;
+// Normal CDF by Abramowitz-Stegun 26.2.19: Phi(a) = 1 - (1/2)(1 + d1 a + ... + d6 a^6)^-16 for a >= 0,
+// |err| < 1.5e-7 (9e-7 in fp32 arithmetic, checked against scipy.erf on [-8,8]); for x < 0 the tail
+// (1/2) p^-16 is used directly (no cancellation).  One v_rcp, no v_exp: ~2/3 the issue cost of the
+// erfc-polynomial form, and the GELU math is what bounds the fc1 / GELU' epilogues (tools/gemm_bench.py 20-22).
+__device__ __forceinline__ float normal_cdf_fast(float x) {
+    const float a = fabsf(x);
+    float p = fmaf(0.0000053830f, a, 0.0000488906f);
+    p = fmaf(p, a, 0.0000380036f);
+    p = fmaf(p, a, 0.0032776263f);
+    p = fmaf(p, a, 0.0211410061f);
+    p = fmaf(p, a, 0.0498673470f);
+    p = fmaf(p, a, 1.0f);
+    float q = __frcp_rn(p);
+    q *= q; q *= q; q *= q; q *= q;      // p^-16
+    const float half = 0.5f * q;
+    return x >= 0.f ? 1.0f - half : half;
 }
 template <class AT> __device__ __forceinline__ float gelu_fwd(float x) { return gelu_erf(x); }
-template <> __device__ __forceinline__ float gelu_fwd<__bf16>(float x) {
-    float c, e;
-    gelu_parts_fast(x, c, e);
-    return 0.5f * x * c;
-}
+template <> __device__ __forceinline__ float gelu_fwd<__bf16>(float x) { return x * normal_cdf_fast(x); }
 template <class AT> __device__ __forceinline__ float gelu_bwd(float x) { return gelu_erf_grad(x); }
 template <> __device__ __forceinline__ float gelu_bwd<__bf16>(float x) {
-    float c, e;
-    gelu_parts_fast(x, c, e);
-    return fmaf(x * 0.39894228040143268f, e, 0.5f * c);
+    return fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), normal_cdf_fast(x));
 }
 // sigmoid exactly as 1/(1+exp(-x)) in fp32 (the form the reference's y_soft > 0.5 test sees)
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -193,7 +193,7 @@ struct EpiEmbed {
 // ABL (measurement only): 0 = product, 1 = no MFMA (loads + LDS reads only), 2 = no global loads,
 // 5 = per-k-step fragment loads (the first version's ordering)
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_nt_kernel(
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -263,6 +263,54 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_nt_kernel(
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
+    if constexpr (ABL == 8 && BOTH_KS) {
+        // ---- software-pipelined main loop: the fragments of K step kt+1 are read from LDS into a second
+        // register set WHILE the 32 MFMAs of step kt run, so a wave hides its own LDS latency; still one
+        // barrier per step.  Invariant at the top of iteration kt: F[kt&1] holds step kt's fragments,
+        // ring slot (kt+1)&1 holds (or is receiving) stage kt+1, slot kt&1 is free once every wave has
+        // passed the barrier (its reads of that slot were waited for by the barrier's lgkmcnt(0)).
+        bf16x8 fa[2][2][TM], fw[2][2][TN];
+        auto read_frags = [&](int set, int buf) {
+            const char* base = smem + buf * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[set][ks][i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fw[set][ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
+            }
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][ks][j], fa[set][ks][i], acc[i][j], 0, 0, 0);
+        };
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        __syncthreads();
+        read_frags(0, 0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            __syncthreads();                                  // stage kt+1 landed; slot 0 free
+            if (kt + 2 < nk) stage(0, kt + 2);
+            if (kt + 1 < nk) read_frags(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                __syncthreads();                              // stage kt+2 landed; slot 1 free
+                if (kt + 3 < nk) stage(1, kt + 3);
+                if (kt + 2 < nk) read_frags(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
     if (ABL != 2) stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
@@ -311,6 +359,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_nt_kernel(
         }
     }
 
+    }  // main-loop variants
+
     if constexpr (BM * BN * 4 <= 2 * STAGE) {
         // ---- epilogue through LDS: acc[i][j][e] = C[wm*WM + i*16 + (lane&15)][wn*WN + j*16 + (lane>>4)*4 + e].
         // The fragment layout gives each store instruction 16 rows x 64 B; instead the tile is parked in the
@@ -330,14 +380,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_nt_kernel(
             }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int t = tid; t < BM * CH; t += NTHR) {
-            const int rl = t / CH, ch = t - rl * CH;
-            const int row = m0 + rl;
-            if (row < Mv) {
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
-                const float v[4] = {c4[0], c4[1], c4[2], c4[3]};
-                epi(row, n0 + ch * 4, v);
+        // fully unrolled in batches of 8 chunks: all LDS reads of a batch are issued first, and the functor's
+        // own global loads (residual / z / d_act) of the batch overlap instead of 16 serial round trips
+        constexpr int ITERS = BM * CH / NTHR;
+        constexpr int BATCH = ITERS % 8 == 0 ? 8 : ITERS;
+#pragma unroll 1
+        for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+            f32x4 c4[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int t = tid + (it0 + u) * NTHR;
+                const int rl = t / CH, ch = t - rl * CH;
+                c4[u] = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int t = tid + (it0 + u) * NTHR;
+                const int rl = t / CH, ch = t - rl * CH;
+                const int row = m0 + rl;
+                if (row < Mv) {
+                    const float v[4] = {c4[u][0], c4[u][1], c4[u][2], c4[u][3]};
+                    epi(row, n0 + ch * 4, v);
+                }
             }
         }
     } else {
@@ -505,6 +569,7 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 1: return launch_bf16_cfg<128, 128, 2, 2, 1>(a, epi, s);
         case 2: return launch_bf16_cfg<128, 128, 2, 2, 2>(a, epi, s);
         case 5: return launch_bf16_cfg<128, 128, 2, 2, 5>(a, epi, s);
+        case 8: return launch_bf16_cfg<128, 128, 2, 2, 8>(a, epi, s);
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
         case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);
         case 12: return launch_bf16_cfg<128, 256, 2, 4, 0>(a, epi, s);

@@ -106,6 +106,8 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
 };
 struct Slot {
     Transients T;
+    hipStream_t branch = nullptr;        // side stream for the adapter branch of this pass
+    hipEvent_t ev_f = nullptr, ev_j = nullptr;
     std::vector<LayerS> L;
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
     int* counts = nullptr;   // [depth*B]
@@ -294,6 +296,11 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
     if (!c) return DYT_OK;
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto e : c->pool) hipEventDestroy(e);
+    for (auto& S : c->slots) {
+        if (S.ev_f) hipEventDestroy(S.ev_f);
+        if (S.ev_j) hipEventDestroy(S.ev_j);
+        if (S.branch) hipStreamDestroy(S.branch);
+    }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side) hipStreamDestroy(c->side);
@@ -458,6 +465,31 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     return 0;
 }
 
+// adapter-branch side stream of a pass (created on first use); null when overlap is off / profiling
+static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
+    *out = nullptr;
+    if (!c->overlap || c->prof) return 0;
+    if (!S.branch) {
+        DYT_HIP_CHECK(hipStreamCreateWithFlags(&S.branch, hipStreamNonBlocking));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&S.ev_f, hipEventDisableTiming));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&S.ev_j, hipEventDisableTiming));
+    }
+    *out = S.branch;
+    return 0;
+}
+#define FORK(sb)  do { if (sb) { DYT_HIP_CHECK(hipEventRecord(S.ev_f, s)); DYT_HIP_CHECK(hipStreamWaitEvent(sb, S.ev_f, 0)); } } while (0)
+#define JOIN(sb)  do { if (sb) { DYT_HIP_CHECK(hipEventRecord(S.ev_j, sb)); DYT_HIP_CHECK(hipStreamWaitEvent(s, S.ev_j, 0)); } } while (0)
+// run a launch on the branch stream when there is one
+#define RUN_ON(sb, cat, flops, call)           \
+    do {                                       \
+        hipStream_t _keep = s;                 \
+        if (sb) s = sb;                        \
+        ProfScope _ps(c, s, (cat), (flops));   \
+        int _rc = (call);                      \
+        s = _keep;                             \
+        if (_rc) return _rc;                   \
+    } while (0)
+
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 
 static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int flags, const float* trainable,
@@ -477,6 +509,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     Transients& T = S.T;
     S.valid = false;
     if (do_prep) { int rc = prep_adapters(c, trainable, s); if (rc) return rc; }
+    hipStream_t sb = nullptr;
+    { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
     // patch embedding: im2col + GEMM (+bias +pos_embed), cls rows
     RUN(2, 0, launch_im2col(P, images, T.xn, B, s));
@@ -505,6 +539,22 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
             RUN_GEMM(EPI_BIAS_RESID, a);
         }
+        // ---- adapter branch (all tokens): x_out = u + scale * up(dropout(relu(down(u)))) -- independent of
+        //      the gate / gather / fc1 chain below, so it runs on the pass's side stream until fc2 needs x_out
+        FORK(sb);
+        {
+            GemmArgs a; a.A = L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
+            a.bias = c->ad_down_b + l * RP; a.out_at = L.d_act; a.r = r; a.drop_p = drop_p;
+            a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+            a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
+            a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1);
+            RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
+        }
+        {
+            GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
+            a.bias = base + c->off_ub; a.resid = L.u; a.out_f32 = xo; a.scale = c->cfg.adapter_scale;
+            RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_UP, a, s));
+        }
         int* counts = S.counts + (size_t)l * B;
         if (use_gate) {
             GateArgs ga;
@@ -527,20 +577,6 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         } else {
             RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s));
         }
-        // adapter (all tokens): x_out = u + scale * up(dropout(relu(down(u))))
-        {
-            GemmArgs a; a.A = L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
-            a.bias = c->ad_down_b + l * RP; a.out_at = L.d_act; a.r = r; a.drop_p = drop_p;
-            a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-            a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
-            a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1);
-            RUN_GEMM(EPI_AD_DOWN, a);
-        }
-        {
-            GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
-            a.bias = base + c->off_ub; a.resid = L.u; a.out_f32 = xo; a.scale = c->cfg.adapter_scale;
-            RUN_GEMM(EPI_AD_UP, a);
-        }
         // MLP on the kept (or all) tokens, scatter-add into the residual stream
         const int* kdev = dense ? nullptr : L.total;
         {
@@ -548,6 +584,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr;
             RUN_GEMM(EPI_FC1, a);
         }
+        JOIN(sb);  // x_out now holds u + adapter(u)
         {
             GemmArgs a; a.A = T.h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
             a.out_f32 = xo; a.row_map = dense ? nullptr : L.row_src; a.row_mask = masked_dense ? L.maskf : nullptr;
@@ -589,6 +626,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const float scale = c->cfg.adapter_scale;
     float* g = T.g;
+    hipStream_t sb = nullptr;
+    { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
     RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw, g,
                               grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes, s));
@@ -612,7 +651,27 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             RUN(2, 0, launch_bwd_prep(P, a, s));
         }
         const void* A_g = g_at ? g_at : (const void*)g;
-        // ---- 2. MLP dgrad (frozen weights): dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
+        // ---- 2. adapter branch on the side stream: dgrad through up_proj, both wgrads, bias grads ----
+        FORK(sb);
+        {
+            GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
+            a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
+            RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s));
+        }
+        {
+            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = T.wg_partial;
+            a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
+            a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
+            RUN_ON(sb, 2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
+        }
+        {
+            WgradArgs a; a.X = L.u_at; a.Y = T.ddz; a.M = M; a.r = r; a.partial = T.wg_partial;
+            a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
+            a.out_xsum = nullptr; a.alpha_x = 0.f;
+            RUN_ON(sb, 2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
+        }
+        RUN_ON(sb, 2, 0, launch_colsum64(P, T.ddz, M, r, gbase + c->off_db, 1.0f, s));  // down_proj.bias
+        // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
             const void* A_dh = need_dH ? (const void*)T.dH : A_g;
             {
@@ -625,25 +684,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 RUN_GEMM(EPI_STORE_AT, a);
             }
         }
-        // ---- 3. adapter: dgrad through up_proj, both wgrads, dgrad through down_proj ----
-        {
-            GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
-            a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
-            RUN_GEMM(EPI_AD_DGRAD_UP, a);
-        }
-        {
-            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = T.wg_partial;
-            a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
-            a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
-            RUN(2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
-        }
-        {
-            WgradArgs a; a.X = L.u_at; a.Y = T.ddz; a.M = M; a.r = r; a.partial = T.wg_partial;
-            a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
-            a.out_xsum = nullptr; a.alpha_x = 0.f;
-            RUN(2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
-        }
-        RUN(2, 0, launch_colsum64(P, T.ddz, M, r, gbase + c->off_db, 1.0f, s));  // down_proj.bias
+        JOIN(sb);
         if (!first) {
             GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
             a.out_f32 = g; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
