@@ -185,6 +185,16 @@ struct EpiEmbed {
 // ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------
+// LDS-DMA (global_load_lds) completion is tracked by vmcnt.  hipcc usually drains it before a
+// __syncthreads(), but NOT reliably (the software-pipelined loop below was compiled with only
+// lgkmcnt(0) in front of s_barrier -> stale tiles at full occupancy).  Every barrier that publishes
+// DMA'd data is therefore preceded by this explicit wait.
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// phase timers (measurement builds only, ABL == 9): cycles of prologue / main loop / epilogue summed over
+// workgroups (wave 0 lane 0), [3] = workgroups counted
+__device__ unsigned long long g_gemm_dbg[4];
+
 // Tile BM x BN x 64, WAVES_M x WAVES_N waves of 64 lanes (each wave owns a (BM/WAVES_M) x (BN/WAVES_N)
 // block of 16x16 MFMA tiles).  Shipped configurations:
 //   128x128, 2x2 waves, 64 KB LDS, 2 workgroups / CU  -- N = 768 GEMMs (tile quantisation) and default
@@ -218,6 +228,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    unsigned long long t_start = 0, t_loop0 = 0, t_loop1 = 0;
+    if (ABL == 9) t_start = __builtin_readcyclecounter();
 
     // ---- staging: lane -> (row-in-8, 16B slot); source chunk = slot ^ row ----
     const int lrow = lane >> 3, slot = lane & 7, chunk = slot ^ lrow;
@@ -235,6 +247,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
         const int row = (t * NW + wave) * 8 + lrow;
         b_src[t] = W + (size_t)(n0 + row) * K + chunk * 8;
     }
+    // one 1-KiB DMA piece (idx < A_INSTR: A rows, else W rows) -- issued interleaved with the MFMAs so the
+    // in-order wave never sits behind a burst of LDS-DMA issues (each costs ~100+ cycles back-to-back)
+    auto stage_one = [&](int buf, int kt, int idx) {
+        char* base = smem + buf * STAGE;
+        if (idx < A_INSTR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[idx] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(base + (idx * NW + wave) * 1024),
+                                             16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(b_src[idx - A_INSTR] + kt * BK),
+                (__attribute__((address_space(3))) void*)(base + A_BYTES + ((idx - A_INSTR) * NW + wave) * 1024), 16, 0, 0);
+    };
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
 #pragma unroll
@@ -263,61 +288,103 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    if constexpr (ABL == 8 && BOTH_KS) {
-        // ---- software-pipelined main loop: the fragments of K step kt+1 are read from LDS into a second
-        // register set WHILE the 32 MFMAs of step kt run, so a wave hides its own LDS latency; still one
-        // barrier per step.  Invariant at the top of iteration kt: F[kt&1] holds step kt's fragments,
-        // ring slot (kt+1)&1 holds (or is receiving) stage kt+1, slot kt&1 is free once every wave has
-        // passed the barrier (its reads of that slot were waited for by the barrier's lgkmcnt(0)).
-        bf16x8 fa[2][2][TM], fw[2][2][TN];
-        auto read_frags = [&](int set, int buf) {
+    if (ABL == 9) t_loop0 = __builtin_readcyclecounter();
+    if constexpr (!BOTH_KS) {
+        // ---- big wave tiles (128x64 per wave): half-stage software pipeline.  Two fragment sets, one per
+        // k-substep; every LDS fragment read is issued one MFMA block (32 MFMAs) ahead of its use, the
+        // single barrier of a stage sits between the two MFMA blocks, and the DMA of stage kt+2 is issued
+        // right after it.  Invariant at the top of iteration kt: Fa holds (kt, ks=0); slot kt&1 holds
+        // stage kt; slot (kt+1)&1 holds or is receiving stage kt+1.
+        bf16x8 faA[TM], fwA[TN], faB[TM], fwB[TN];
+        auto read_a = [&](int buf) {   // (stage in `buf`, ks = 0) -> set A
             const char* base = smem + buf * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+            for (int i = 0; i < TM; ++i) faA[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + fslot0 * 16);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[set][ks][i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fw[set][ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
-            }
+            for (int j = 0; j < TN; ++j) fwA[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + fslot0 * 16);
         };
-        auto mma = [&](int set) {
+        auto read_b = [&](int buf) {   // (stage in `buf`, ks = 1) -> set B
+            const char* base = smem + buf * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < TM; ++i) faB[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + fslot1 * 16);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][ks][j], fa[set][ks][i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) fwB[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + fslot1 * 16);
         };
         stage(0, 0);
         if (nk > 1) stage(1, 1);
+        dma_wait_all();
         __syncthreads();
-        read_frags(0, 0);
-        for (int kt = 0; kt < nk; kt += 2) {
-            __syncthreads();                                  // stage kt+1 landed; slot 0 free
-            if (kt + 2 < nk) stage(0, kt + 2);
-            if (kt + 1 < nk) read_frags(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) {
-                __syncthreads();                              // stage kt+2 landed; slot 1 free
-                if (kt + 3 < nk) stage(1, kt + 3);
-                if (kt + 2 < nk) read_frags(0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(1);
-                __builtin_amdgcn_sched_barrier(0);
+        read_a(0);
+        constexpr int NDMA = A_INSTR + B_INSTR;
+        static_assert(TM == 8 && TN == 4 && NDMA == 8, "interleave pattern written for the 128x64 wave tile, 8 DMA pieces");
+#define DYT_MMA(FW, FA)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[j], FA[i], acc[i][j], 0, 0, 0);
+#define DYT_SG3R __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define DYT_SG2R __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define DYT_SGB /* per 8 MFMAs: M2 R M2 R M1 D M2 R M1 D */                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            // ---- block A: 32 MFMAs on set A, the 12 fragment reads of (kt, ks=1) -> set B slotted in between
+            read_b(kt & 1);
+            DYT_MMA(fwA, faA)
+            if (ABL != 3) {
+                DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R   // 24 MFMA, 8 reads
+                DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R                                       //  8 MFMA, 4 reads
             }
+            __builtin_amdgcn_sched_barrier(0);
+            dma_wait_all();   // this wave's pieces of stage kt+1 have landed ...
+            __syncthreads();  // ... everywhere; every wave's reads of slot kt&1 have returned
+            // ---- block B: 32 MFMAs on set B; the reads of (kt+1, ks=0) -> set A and the 8 DMA pieces of stage
+            //      kt+2 -> slot kt&1 slotted in between.  (Past the end the last stage is simply re-fetched
+            //      into the free slot: keeps this a single basic block for the scheduler.)
+            // source order = issue order (LDS-DMA writes and ds_reads are kept in program order by the
+            // scheduler's memory dependencies): R R D R D, four times = 12 reads + 8 DMA pieces
+            const int nxt = min(kt + 2, nk - 1);
+            {
+                const char* base = smem + ((kt + 1) & 1) * STAGE;
+                const int so = fslot0 * 16;
+#define DYT_RA(i) faA[i] = *reinterpret_cast<const bf16x8*>(base + a_off + (i) * 2048 + so);
+#define DYT_RW(j) fwA[j] = *reinterpret_cast<const bf16x8*>(base + b_off + (j) * 2048 + so);
+                DYT_RA(0) DYT_RA(1) stage_one(kt & 1, nxt, 0); DYT_RA(2) stage_one(kt & 1, nxt, 1);
+                DYT_RA(3) DYT_RA(4) stage_one(kt & 1, nxt, 2); DYT_RA(5) stage_one(kt & 1, nxt, 3);
+                DYT_RA(6) DYT_RA(7) stage_one(kt & 1, nxt, 4); DYT_RW(0) stage_one(kt & 1, nxt, 5);
+                DYT_RW(1) DYT_RW(2) stage_one(kt & 1, nxt, 6); DYT_RW(3) stage_one(kt & 1, nxt, 7);
+#undef DYT_RA
+#undef DYT_RW
+            }
+            DYT_MMA(fwB, faB)
+            if (ABL != 3) { DYT_SGB DYT_SGB DYT_SGB DYT_SGB }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        {   // last stage: nothing left to prefetch
+            read_b((nk - 1) & 1);
+            DYT_MMA(fwA, faA)
+            if (ABL != 3) {
+                DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R
+                DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            DYT_MMA(fwB, faB)
+        }
+#undef DYT_MMA
+#undef DYT_SG3R
+#undef DYT_SG2R
+#undef DYT_SGB
     } else {
     if (ABL != 2) stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
+        dma_wait_all();
         __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
-        if (ABL != 2 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (ABL != 2 && ABL != 4 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
         if (BOTH_KS && ABL != 5 && ABL != 1) {
             // issue all fragment reads of the K step, then the MFMAs: one LDS-latency exposure per step
+            // (ABL 4: the next stage's DMA pieces are issued one per few MFMAs instead of in a burst)
             bf16x8 af[2][TM], wf[2][TN];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -328,13 +395,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
                 for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
             }
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int NDMA = A_INSTR + B_INSTR, PER = 2 * TM * TN / NDMA;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                        if (ABL == 4) {
+                            const int q = (ks * TM + i) * TN + j;
+                            if (PER > 0 && q % PER == PER - 1 && q / PER < NDMA) {
+                                if (kt + 1 < nk) stage_one((kt + 1) & 1, kt + 1, q / PER);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
             __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
@@ -360,64 +436,69 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
     }
 
     }  // main-loop variants
+    if (ABL == 9) t_loop1 = __builtin_readcyclecounter();
 
-    if constexpr (BM * BN * 4 <= 2 * STAGE) {
+    {
         // ---- epilogue through LDS: acc[i][j][e] = C[wm*WM + i*16 + (lane&15)][wn*WN + j*16 + (lane>>4)*4 + e].
         // The fragment layout gives each store instruction 16 rows x 64 B; instead the tile is parked in the
-        // (now free) staging ring as fp32 [BM][BN] with the 16-B chunk index XOR-swizzled by (row & 7)
-        // (conflict-free ds_write_b128 / ds_read_b128) and read back row-major, so every global access of
-        // the epilogue functor is a full-row, 16-B-per-lane coalesced transaction.
-        __syncthreads();
+        // (now free) staging ring as fp32 with the 16-B chunk index XOR-swizzled by (row & 7) (conflict-free
+        // ds_write_b128 / ds_read_b128) and read back row-major, so every global access of the epilogue
+        // functor is a full-row, 16-B-per-lane coalesced transaction.  If the whole fp32 tile does not fit
+        // the ring it goes through in WAVES_M passes of WM rows.
+        constexpr bool ONE_PASS = BM * BN * 4 <= 2 * STAGE;
+        constexpr int PASSES = ONE_PASS ? 1 : WAVES_M;
+        constexpr int PROWS = BM / PASSES;
+        static_assert(PROWS * BN * 4 <= 2 * STAGE, "epilogue staging does not fit the LDS ring");
         float* Cs = reinterpret_cast<float*>(smem);
         constexpr int CH = BN / 4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rl = wm * WM + i * 16 + frow;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ch = ((wn * WN + j * 16) >> 2) + (lane >> 4);
-                *reinterpret_cast<f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2)) = acc[i][j];
-            }
-        }
-        __syncthreads();
-        // fully unrolled in batches of 8 chunks: all LDS reads of a batch are issued first, and the functor's
-        // own global loads (residual / z / d_act) of the batch overlap instead of 16 serial round trips
-        constexpr int ITERS = BM * CH / NTHR;
+        constexpr int ITERS = PROWS * CH / NTHR;
         constexpr int BATCH = ITERS % 8 == 0 ? 8 : ITERS;
+        dma_wait_all();  // nothing may still be landing in the ring when it is reused as staging
 #pragma unroll 1
-        for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
-            f32x4 c4[BATCH];
+        for (int p = 0; p < PASSES; ++p) {
+            __syncthreads();
+            if (ONE_PASS || wm == p) {
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int t = tid + (it0 + u) * NTHR;
-                const int rl = t / CH, ch = t - rl * CH;
-                c4[u] = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
+                for (int i = 0; i < TM; ++i) {
+                    const int rl = (ONE_PASS ? wm * WM : 0) + i * 16 + frow;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int ch = ((wn * WN + j * 16) >> 2) + (lane >> 4);
+                        *reinterpret_cast<f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2)) = acc[i][j];
+                    }
+                }
             }
+            __syncthreads();
+            // batches of 8 chunks: all LDS reads of a batch are issued first, and the functor's own global
+            // loads (residual / z / d_act) of the batch overlap instead of serial round trips
+#pragma unroll 1
+            for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+                f32x4 c4[BATCH];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int t = tid + (it0 + u) * NTHR;
-                const int rl = t / CH, ch = t - rl * CH;
-                const int row = m0 + rl;
-                if (row < Mv) {
-                    const float v[4] = {c4[u][0], c4[u][1], c4[u][2], c4[u][3]};
-                    epi(row, n0 + ch * 4, v);
+                for (int u = 0; u < BATCH; ++u) {
+                    const int t = tid + (it0 + u) * NTHR;
+                    const int rl = t / CH, ch = t - rl * CH;
+                    c4[u] = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int t = tid + (it0 + u) * NTHR;
+                    const int rl = t / CH, ch = t - rl * CH;
+                    const int row = m0 + p * PROWS + rl;
+                    if (row < Mv) {
+                        const float v[4] = {c4[u][0], c4[u][1], c4[u][2], c4[u][3]};
+                        epi(row, n0 + ch * 4, v);
+                    }
                 }
             }
         }
-    } else {
-        // ---- big tiles: the fp32 tile does not fit the ring; store straight from the fragments
-        // (each lane owns 4 consecutive columns of 16 rows) ----
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * WM + i * 16 + frow;
-            if (row < Mv) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    epi(row, n0 + wn * WN + j * 16 + (lane >> 4) * 4, v);
-                }
-            }
-        }
+    }
+    if (ABL == 9 && tid == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        atomicAdd(&g_gemm_dbg[0], t_loop0 - t_start);
+        atomicAdd(&g_gemm_dbg[1], t_loop1 - t_loop0);
+        atomicAdd(&g_gemm_dbg[2], t_end - t_loop1);
+        atomicAdd(&g_gemm_dbg[3], 1ull);
     }
 }
 
@@ -491,8 +572,7 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     return 0;
 }
 
-static int g_big_tile_min_n = 1 << 30;  // 256x256 tiles measured SLOWER with this loop structure (1 WG/CU: no
-                                         // cross-workgroup overlap of barrier stalls / epilogue) -- kept for later rounds
+static int g_big_tile_min_n = 2304;  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
 
 template <class Epi>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
@@ -568,9 +648,12 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 0: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
         case 1: return launch_bf16_cfg<128, 128, 2, 2, 1>(a, epi, s);
         case 2: return launch_bf16_cfg<128, 128, 2, 2, 2>(a, epi, s);
+        case 4: return launch_bf16_cfg<128, 128, 2, 2, 4>(a, epi, s);
         case 5: return launch_bf16_cfg<128, 128, 2, 2, 5>(a, epi, s);
-        case 8: return launch_bf16_cfg<128, 128, 2, 2, 8>(a, epi, s);
+        case 9: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, epi, s);
+        case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
+        case 15: return launch_bf16_cfg<256, 256, 2, 4, 3>(a, epi, s);
         case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);
         case 12: return launch_bf16_cfg<128, 256, 2, 4, 0>(a, epi, s);
         case 13: return launch_bf16_cfg<256, 256, 2, 4, 1>(a, epi, s);
@@ -582,6 +665,16 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
     }
     set_error("gemm_raw: unknown variant %d", variant);
     return -1;
+}
+
+int gemm_debug_counters(unsigned long long* out4, int reset) {
+    DYT_HIP_CHECK(hipDeviceSynchronize());
+    DYT_HIP_CHECK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_gemm_dbg), 4 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        DYT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), z, sizeof(z)));
+    }
+    return 0;
 }
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {

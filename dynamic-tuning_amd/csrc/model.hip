@@ -818,6 +818,11 @@ extern "C" int dyt_gemm_bf16_raw(const void* a, const void* w, void* cmat, int M
     return launch_gemm_raw(a, w, cmat, M, N, K, variant, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dyt_debug_counters(uint64_t* out4, int reset) {
+    if (!out4) { set_error("null argument"); return DYT_ERR_ARG; }
+    return gemm_debug_counters(reinterpret_cast<unsigned long long*>(out4), reset);
+}
+
 extern "C" int dyt_layernorm(const float* x, const float* w, const float* b, float* out, int rows, void* stream) {
     if (!x || !w || !b || !out || rows < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
     return launch_ln_fwd_f32out(x, w, b, out, rows, static_cast<hipStream_t>(stream));

@@ -184,6 +184,9 @@ int dyt_gate_compact(const float* u, const float* w, const float* b, const float
 /* C[M,N] (bf16) = A[M,K] (bf16) @ W[N,K]^T (bf16), fp32 accumulate; `variant` selects a kernel build
  * (0 = product kernel; others are ablations used to attribute time, see csrc/gemm.hip) */
 int dyt_gemm_bf16_raw(const void* a, const void* w, void* c, int M, int N, int K, int variant, void* stream);
+/* phase timers of the instrumented GEMM variants: cycles {prologue, main loop, epilogue} summed over
+ * workgroups and the workgroup count; synchronises; optionally resets */
+int dyt_debug_counters(uint64_t* out4, int reset);
 /* bracket every kernel launch with hipEvents on `stream` and accumulate per category */
 int dyt_profile_enable(dyt_ctx* ctx, int on);
 /* categories: 0 gemm (big MFMA GEMMs), 1 attention, 2 everything else.  Returns accumulated
