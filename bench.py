@@ -180,6 +180,12 @@ def main():
 
     # dominant-kernel roofline: HIP events around every GEMM launch of ONE step (same stream)
     roof = None
+    traffic = None
+    try:  # HBM bytes per GEMM launch from the committed PMC passes of this same command (tools/pmc_traffic.py)
+        with open(os.path.join(ROOT, "profiles", "round1", "gemm_traffic.json")) as f:
+            traffic = json.load(f)
+    except Exception:
+        pass
     if rank == 0:
         eng.profile(True)
         one_step(10 ** 6)
@@ -190,7 +196,11 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_%s_nt_kernel (all epilogues)" % ("bf16" if args.precision == "bf16" else "f32"),
                 "achieved": round(ach, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK[args.precision], 4),
-                "traffic": None, "launches_per_step": n, "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                "traffic": round(traffic["hbm_bytes_per_launch"]) if traffic and args.precision == "bf16" else None,
+                "traffic_source": "profiles/round1/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 "
+                                  "gfx950 correction), bytes per launch" if traffic else None,
+                "timing_note": "per-kernel durations are taken with the multi-stream overlap switched off (serial launches), "
+                               "so they are clean but pessimistic w.r.t. the overlapped schedule that `value` is measured on", "launches_per_step": n, "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                 "avg_launch_ms": round(ms / max(n, 1), 4), "gemm_ms_per_step": round(ms, 3),
                 "attention_ms_per_step": round(ms_a, 3), "attention_tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2) if ms_a else None,
                 "other_kernels_ms_per_step": round(ms_o, 3), "other_launches": n_o}

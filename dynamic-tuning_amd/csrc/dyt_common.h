@@ -84,6 +84,19 @@ template <class AT> __device__ __forceinline__ float gelu_bwd(float x) { return 
 template <> __device__ __forceinline__ float gelu_bwd<__bf16>(float x) {
     return fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), normal_cdf_fast(x));
 }
+// GELU and its derivative in one go (they share Phi(x)): h = x Phi(x), gp = Phi(x) + x pdf(x).
+// The fc1 epilogue stores gp (instead of the pre-activation) for the backward pass, whose epilogue is then
+// a plain multiply -- the transcendental work is done once, where Phi is already being computed.
+template <class AT> __device__ __forceinline__ void gelu_both(float x, float& h, float& gp) {
+    const float phi = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    h = x * phi;
+    gp = phi + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+template <> __device__ __forceinline__ void gelu_both<__bf16>(float x, float& h, float& gp) {
+    const float phi = normal_cdf_fast(x);
+    h = x * phi;
+    gp = fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), phi);
+}
 // sigmoid exactly as 1/(1+exp(-x)) in fp32 (the form the reference's y_soft > 0.5 test sees)
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -63,13 +63,19 @@ struct EpiBiasResid {
 
 template <class AT>
 struct EpiFc1 {
-    const float* bias; AT* h; AT* z; int ld;
+    const float* bias; AT* h; AT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
     __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
         const size_t o = (size_t)row * ld + col;
-        const float z0 = a[0] + bias[col], z1 = a[1] + bias[col + 1], z2 = a[2] + bias[col + 2],
-                    z3 = a[3] + bias[col + 3];
-        if (z) store4(z + o, z0, z1, z2, z3);
-        store4(h + o, gelu_fwd<AT>(z0), gelu_fwd<AT>(z1), gelu_fwd<AT>(z2), gelu_fwd<AT>(z3));
+        float hv[4], gv[4];
+        if (gp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gelu_both<AT>(a[i] + bias[col + i], hv[i], gv[i]);
+            store4(gp + o, gv[0], gv[1], gv[2], gv[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + bias[col + i]);
+        }
+        store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
 };
 
@@ -91,13 +97,12 @@ struct EpiFc2 {
 
 template <class AT>
 struct EpiGeluBwd {
-    const AT* z; AT* out; int ld;
+    const AT* gp; AT* out; int ld;   // gp = gelu'(z) saved by the fc1 epilogue
     __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
         const size_t o = (size_t)row * ld + col;
-        float zz[4];
-        load4(z + o, zz);
-        store4(out + o, a[0] * gelu_bwd<AT>(zz[0]), a[1] * gelu_bwd<AT>(zz[1]), a[2] * gelu_bwd<AT>(zz[2]),
-               a[3] * gelu_bwd<AT>(zz[3]));
+        float g[4];
+        load4(gp + o, g);
+        store4(out + o, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
     }
 };
 
@@ -350,14 +355,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
                 const int so = fslot0 * 16;
 #define DYT_RA(i) faA[i] = *reinterpret_cast<const bf16x8*>(base + a_off + (i) * 2048 + so);
 #define DYT_RW(j) fwA[j] = *reinterpret_cast<const bf16x8*>(base + b_off + (j) * 2048 + so);
+                if (ABL == 6) {   // probe: all DMA pieces early in the block (more time to land), reads after
+#pragma unroll
+                    for (int d = 0; d < NDMA; ++d) stage_one(kt & 1, nxt, d);
+                    DYT_RA(0) DYT_RA(1) DYT_RA(2) DYT_RA(3) DYT_RA(4) DYT_RA(5) DYT_RA(6) DYT_RA(7)
+                    DYT_RW(0) DYT_RW(1) DYT_RW(2) DYT_RW(3)
+                } else {
                 DYT_RA(0) DYT_RA(1) stage_one(kt & 1, nxt, 0); DYT_RA(2) stage_one(kt & 1, nxt, 1);
                 DYT_RA(3) DYT_RA(4) stage_one(kt & 1, nxt, 2); DYT_RA(5) stage_one(kt & 1, nxt, 3);
                 DYT_RA(6) DYT_RA(7) stage_one(kt & 1, nxt, 4); DYT_RW(0) stage_one(kt & 1, nxt, 5);
                 DYT_RW(1) DYT_RW(2) stage_one(kt & 1, nxt, 6); DYT_RW(3) stage_one(kt & 1, nxt, 7);
+                }
 #undef DYT_RA
 #undef DYT_RW
             }
             DYT_MMA(fwB, faB)
+            if (ABL == 6) {
+#define DYT_SGD __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
+#define DYT_SGR1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+#define DYT_SGR2 __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD                  // 16 MFMA, 8 DMA
+                DYT_SGR1 DYT_SGR1 DYT_SGR2 DYT_SGR1 DYT_SGR1 DYT_SGR2 DYT_SGR1 DYT_SGR1 DYT_SGR2 DYT_SGR1 DYT_SGR1 DYT_SGR2  // 16 MFMA, 12 reads
+#undef DYT_SGD
+#undef DYT_SGR1
+#undef DYT_SGR2
+            } else
             if (ABL != 3) { DYT_SGB DYT_SGB DYT_SGB DYT_SGB }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -654,6 +676,7 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
         case 15: return launch_bf16_cfg<256, 256, 2, 4, 3>(a, epi, s);
+        case 16: return launch_bf16_cfg<256, 256, 2, 4, 6>(a, epi, s);
         case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);
         case 12: return launch_bf16_cfg<128, 256, 2, 4, 0>(a, epi, s);
         case 13: return launch_bf16_cfg<256, 256, 2, 4, 1>(a, epi, s);

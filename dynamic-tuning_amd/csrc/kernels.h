@@ -13,9 +13,9 @@ enum EpiKind {
     EPI_BIAS_F32 = 0,   // out_f32 = acc + bias                                   (generic nn.Linear)
     EPI_QKV,            // +bias, q*0.125, scatter to q/k/v [B,12,197,64]          (Attention.qkv)
     EPI_BIAS_RESID,     // out_f32 = acc + bias + resid ; optional AT copy          (Attention.proj + residual)
-    EPI_FC1,            // z = acc + bias -> out_at2 (optional) ; gelu(z) -> out_at (Mlp.fc1 + GELU)
+    EPI_FC1,            // z = acc + bias ; gelu(z) -> out_at ; gelu'(z) -> out_at2 (optional, for backward) (Mlp.fc1 + GELU)
     EPI_FC2,            // h = acc + bias ; x[row_map[r]] += mask*h ; optional h save (Mlp.fc2 + scatter + residual)
-    EPI_GELU_BWD,       // out_at = acc * gelu'(z)                                  (dgrad through fc2, GELU)
+    EPI_GELU_BWD,       // out_at = acc * aux (aux = gelu'(z) saved by EPI_FC1)        (dgrad through fc2, GELU)
     EPI_STORE_F32,      // out_f32 (+)= acc
     EPI_STORE_AT,       // out_at = acc
     EPI_AD_DOWN,        // out_at = dropout(relu(acc + bias))                       (Adapter.down_proj)
@@ -181,9 +181,10 @@ int launch_reduce_partials(const float* partial, int nparts, int stride, float* 
 //   out_w[c*sc + j*sj] += alpha * C[c][j]  (j < r) ;  out_xsum[c] += alpha_x * sum_m X[m][c] (optional)
 struct WgradArgs {
     const void* X; const void* Y; int M; int r;
-    float* partial;            // scratch [nchunks][768][80]
+    float* partial;            // scratch [nchunks][768 + 8][80]
     float* out_w; int sc, sj; float alpha;
     float* out_xsum; float alpha_x;
+    float* out_ysum = nullptr; float alpha_y = 0.f;   // out_ysum[j] += alpha_y * sum_m Y[m][j], j < r
 };
 int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s);
 // out[j] += alpha * sum_m Y[m][j], j < r  (Y [M,64] AT)

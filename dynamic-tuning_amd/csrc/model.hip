@@ -231,7 +231,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.delta = carve<float>(c, B * NH * NT, dry);
         T.dmask = carve<float>(c, M, dry);
         T.tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
-        T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)D * 80, dry);
+        T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
     c->dl_s = carve<float>(c, B * C, dry); c->dl_t = carve<float>(c, B * C, dry);
@@ -668,9 +668,9 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             WgradArgs a; a.X = L.u_at; a.Y = T.ddz; a.M = M; a.r = r; a.partial = T.wg_partial;
             a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
             a.out_xsum = nullptr; a.alpha_x = 0.f;
+            a.out_ysum = gbase + c->off_db; a.alpha_y = 1.0f;                       // down_proj.bias
             RUN_ON(sb, 2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
         }
-        RUN_ON(sb, 2, 0, launch_colsum64(P, T.ddz, M, r, gbase + c->off_db, 1.0f, s));  // down_proj.bias
         // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
             const void* A_dh = need_dH ? (const void*)T.dH : A_g;

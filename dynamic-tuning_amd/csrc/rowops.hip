@@ -713,70 +713,96 @@ int launch_reduce_partials(const float* partial, int nparts, int stride, float* 
 constexpr int WG_J = 80;        // 64 adapter columns + the ones column (+ pad)
 constexpr int WG_CHUNK = 512;   // tokens per workgroup
 
-// bf16: MFMA 16x16x32 with the token dimension as K; tiles are transposed while staged to LDS
+// bf16: MFMA 16x16x32 with the token dimension as K; tiles are transposed while staged to LDS.
+// 64 tokens per step; the next step's rows are prefetched into registers while the current step's
+// fragments are read and multiplied (the loads were fully exposed before: 1.3 TB/s).  The column sums
+// of X ride along as a ones COLUMN of the B operand (-> partial[..][c][64]); the column sums of Y as a
+// ones ROW of the A operand, computed by wave 0 of the first channel block (-> partial[..][768][j]).
+constexpr int WG_ROWS = D + 8;  // partial rows per chunk: 768 channels + 1 row of Y column sums (+pad)
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Y, int M,
                                                          float* __restrict__ partial) {
-    constexpr int LDT = 40;  // bf16 per LDS row: 32 tokens + 8 pad (80 B, 16-B aligned rows)
+    constexpr int TS = 64;        // tokens per step
+    constexpr int LDT = TS + 8;   // bf16 per LDS row (144 B: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) bf16 Xt[128 * LDT];
     __shared__ __attribute__((aligned(16))) bf16 Yt[64 * LDT];
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * 128;
     const int m0 = blockIdx.y * WG_CHUNK;
-    f32x4 acc[2][5];
+    const int mend = min(m0 + WG_CHUNK, M);
+    f32x4 acc[2][5], accy[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (lane & 15) == 0 ? (bf16)1.0f : (bf16)0.0f;
+    const bool do_ysum = blockIdx.x == 0 && wave == 0;
 
-    const int xp = tid >> 4, xc = tid & 15;  // token pair, 8-channel chunk
-    const int yp = (tid & 127) >> 3, yc = tid & 7;
-    for (int step = 0; step < WG_CHUNK / 32; ++step) {
-        const int tb = m0 + step * 32;
-        if (tb >= M) break;
-        bf16x8 xa, xb, ya, yb;
+    // loader roles: X tile = 32 token pairs x 16 channel chunks = 512 tasks (2 / thread); Y = 32 x 8 (1 / thread)
+    const int xp0 = tid >> 4, xc = tid & 15;
+    const int yp = tid >> 3, yc = tid & 7;
+    bf16x8 xr[2][2], yr[2];
+    auto zero = [](bf16x8& v) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { xa[i] = (bf16)0.f; xb[i] = (bf16)0.f; ya[i] = (bf16)0.f; yb[i] = (bf16)0.f; }
-        const int tx = tb + 2 * xp;
-        if (tx < M) xa = *reinterpret_cast<const bf16x8*>(X + (size_t)tx * D + c0 + xc * 8);
-        if (tx + 1 < M) xb = *reinterpret_cast<const bf16x8*>(X + (size_t)(tx + 1) * D + c0 + xc * 8);
-        const int ty = tb + 2 * yp;
-        if (tid < 128) {
-            if (ty < M) ya = *reinterpret_cast<const bf16x8*>(Y + (size_t)ty * RP + yc * 8);
-            if (ty + 1 < M) yb = *reinterpret_cast<const bf16x8*>(Y + (size_t)(ty + 1) * RP + yc * 8);
+        for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+    };
+    auto load_step = [&](int tb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = tb + 2 * (xp0 + 16 * h);
+            zero(xr[h][0]); zero(xr[h][1]);
+            if (t < mend) xr[h][0] = *reinterpret_cast<const bf16x8*>(X + (size_t)t * D + c0 + xc * 8);
+            if (t + 1 < mend) xr[h][1] = *reinterpret_cast<const bf16x8*>(X + (size_t)(t + 1) * D + c0 + xc * 8);
         }
+        const int ty = tb + 2 * yp;
+        zero(yr[0]); zero(yr[1]);
+        if (ty < mend) yr[0] = *reinterpret_cast<const bf16x8*>(Y + (size_t)ty * RP + yc * 8);
+        if (ty + 1 < mend) yr[1] = *reinterpret_cast<const bf16x8*>(Y + (size_t)(ty + 1) * RP + yc * 8);
+    };
+    if (m0 < mend) load_step(m0);
+    for (int tb = m0; tb < mend; tb += TS) {
         __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            bf16x2 pv = {xa[i], xb[i]};
-            *reinterpret_cast<bf16x2*>(&Xt[(xc * 8 + i) * LDT + 2 * xp]) = pv;
-        }
-        if (tid < 128) {
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                bf16x2 pv = {ya[i], yb[i]};
-                *reinterpret_cast<bf16x2*>(&Yt[(yc * 8 + i) * LDT + 2 * yp]) = pv;
+                bf16x2 pv = {xr[h][0][i], xr[h][1][i]};
+                *reinterpret_cast<bf16x2*>(&Xt[(xc * 8 + i) * LDT + 2 * (xp0 + 16 * h)]) = pv;
             }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf16x2 pv = {yr[0][i], yr[1][i]};
+            *reinterpret_cast<bf16x2*>(&Yt[(yc * 8 + i) * LDT + 2 * yp]) = pv;
         }
         __syncthreads();
+        if (tb + TS < mend) load_step(tb + TS);  // in flight during the reads + MFMAs below
         const int kg = lane >> 4, fr = lane & 15;
-        bf16x8 xf[2], yf[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(&Xt[(wave * 32 + i * 16 + fr) * LDT + kg * 8]);
+        for (int kk = 0; kk < 2; ++kk) {  // two 32-token k blocks
+            bf16x8 xf[2], yf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 16 + fr) * LDT + kg * 8]);
+            for (int i = 0; i < 2; ++i)
+                xf[i] = *reinterpret_cast<const bf16x8*>(&Xt[(wave * 32 + i * 16 + fr) * LDT + kk * 32 + kg * 8]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int j = 0; j < 4; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 16 + fr) * LDT + kk * 32 + kg * 8]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
-            acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], ones, acc[i][4], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+                acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], ones, acc[i][4], 0, 0, 0);
+            }
+            if (do_ysum) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accy[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[j], accy[j], 0, 0, 0);
+            }
         }
     }
     // D[c][j]: col j = lane & 15, row c = (lane >> 4) * 4 + reg
-    float* pp = partial + (size_t)blockIdx.y * D * WG_J;
+    float* pp = partial + (size_t)blockIdx.y * WG_ROWS * WG_J;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -786,6 +812,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict_
                 const int c = c0 + wave * 32 + i * 16 + (lane >> 4) * 4 + e;
                 pp[(size_t)c * WG_J + j * 16 + (lane & 15)] = acc[i][j][e];
             }
+    if (do_ysum && lane < 16) {  // ones row 0 of the A operand: D row 0 = lanes 0..15, register 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pp[(size_t)D * WG_J + j * 16 + lane] = accy[j][0];
+    }
 }
 
 // fp32 exact variant: 64 channels x 64 columns per workgroup, 4x4 outputs per thread
@@ -800,6 +830,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
     const int lr = tid >> 4, lc = (tid & 15) * 4;
     float acc[4][4] = {};
     float xs[4] = {0.f, 0.f, 0.f, 0.f};
+    float ys[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tb = m0; tb < min(m0 + WG_CHUNK, M); tb += 16) {
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yv = xv;
         if (tb + lr < M) {
@@ -822,9 +853,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
                 xs[i] += av[i];
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ys[j] += bv[j];
         }
     }
-    float* pp = partial + (size_t)blockIdx.y * D * WG_J;
+    float* pp = partial + (size_t)blockIdx.y * WG_ROWS * WG_J;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty * 4 + i;
@@ -832,17 +865,24 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
         for (int j = 0; j < 4; ++j) pp[(size_t)c * WG_J + tx * 4 + j] = acc[i][j];
         if (tx == 0) pp[(size_t)c * WG_J + 64] = xs[i];
     }
+    if (blockIdx.x == 0 && ty == 0) {  // column sums of Y
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pp[(size_t)D * WG_J + tx * 4 + j] = ys[j];
+    }
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int r, float* __restrict__ out_w,
-                                    int sc, int sj, float alpha, float* __restrict__ out_xsum, float alpha_x) {
+                                    int sc, int sj, float alpha, float* __restrict__ out_xsum, float alpha_x,
+                                    float* __restrict__ out_ysum, float alpha_y) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= D * (r + 1)) return;
+    if (idx >= (D + 1) * (r + 1)) return;
     const int c = idx / (r + 1), j = idx - c * (r + 1);
     const int col = j < r ? j : 64;
+    if (c == D && j == r) return;
     float acc = 0.f;
-    for (int p = 0; p < nchunks; ++p) acc += partial[((size_t)p * D + c) * WG_J + col];
-    if (j < r) out_w[(size_t)c * sc + (size_t)j * sj] += alpha * acc;
+    for (int p = 0; p < nchunks; ++p) acc += partial[((size_t)p * WG_ROWS + c) * WG_J + col];
+    if (c == D) { if (out_ysum) out_ysum[j] += alpha_y * acc; }
+    else if (j < r) out_w[(size_t)c * sc + (size_t)j * sj] += alpha * acc;
     else if (out_xsum) out_xsum[c] += alpha_x * acc;
 }
 
@@ -854,8 +894,8 @@ int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
     else
         hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks), dim3(256), 0, s, (const bf16*)a.X, (const bf16*)a.Y,
                            a.M, a.partial);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((D * (a.r + 1) + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.r,
-                       a.out_w, a.sc, a.sj, a.alpha, a.out_xsum, a.alpha_x);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (a.r + 1) + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.r,
+                       a.out_w, a.sc, a.sj, a.alpha, a.out_xsum, a.alpha_x, a.out_ysum, a.alpha_y);
     LAUNCH_CHECK();
     return 0;
 }
