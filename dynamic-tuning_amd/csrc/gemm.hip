@@ -133,7 +133,9 @@ struct EpiAdDown {
     const float* bias;  // padded to RP
     AT* out;            // [M, RP]
     const uint8_t* keep; int r; float inv_keep; float drop_p; uint64_t seed, subseq;
+    const int* row_map;  // token row of compact row `row` (mask / RNG are indexed by token), or null
     __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+        const int trow = row_map ? row_map[row] : row;
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[i] + bias[col + i], 0.0f);
@@ -141,9 +143,9 @@ struct EpiAdDown {
             if (keep) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    v[i] = (col + i < r && keep[(size_t)row * r + col + i]) ? v[i] * inv_keep : 0.0f;
+                    v[i] = (col + i < r && keep[(size_t)trow * r + col + i]) ? v[i] * inv_keep : 0.0f;
             } else {
-                Philox ph(seed, subseq, (uint64_t)row * (RP / 4) + (col >> 2));
+                Philox ph(seed, subseq, (uint64_t)trow * (RP / 4) + (col >> 2));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ph.u01(i) >= drop_p ? v[i] * inv_keep : 0.0f;
             }
@@ -153,9 +155,9 @@ struct EpiAdDown {
 };
 
 struct EpiAdUp {
-    const float* bias; const float* u; float* out; float scale;
+    const float* bias; const float* u; float* out; float scale; const int* row_map;
     __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const size_t o = (size_t)row * D + col;
+        const size_t o = (size_t)(row_map ? row_map[row] : row) * D + col;
         float r[4];
         load4(u + o, r);
         store4(out + o, r[0] + scale * (a[0] + bias[col]), r[1] + scale * (a[1] + bias[col + 1]),
@@ -639,8 +641,8 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
         case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
-            return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq}, s);
-        case EPI_AD_UP: return run<AT>(a, EpiAdUp{a.bias, a.resid, a.out_f32, a.scale}, s);
+            return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map}, s);
+        case EPI_AD_UP: return run<AT>(a, EpiAdUp{a.bias, a.resid, a.out_f32, a.scale, a.row_map}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
         case EPI_EMBED: return run<AT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);

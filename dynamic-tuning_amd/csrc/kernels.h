@@ -37,7 +37,7 @@ struct GemmArgs {
     void* out_at3 = nullptr;
     const float* resid = nullptr;
     const void* aux_at = nullptr;     // z (GELU_BWD) / d_act (AD_DGRAD_UP)
-    const int* row_map = nullptr;     // FC2 scatter: compact row -> token row
+    const int* row_map = nullptr;     // FC2 / AD_UP scatter, AD_DOWN mask index: compact row -> token row
     const float* row_mask = nullptr;  // FC2 masked-dense: per-token mask
     void* h_out = nullptr;            // FC2: save h (AT)
     const uint8_t* keep = nullptr;    // AD_DOWN injected keep mask [M, r]
@@ -102,6 +102,11 @@ int launch_ln_gather(int precision, const float* u, const float* w, const float*
                      const int* counts, const int* offsets, const float* maskf, void* out, float2* stats,
                      int* row_src, int* dst_of, int batch, hipStream_t s);
 
+// last block: LayerNorm of the cls rows only (out[b] = LN(u[b*197])), stats[b*197], u_cls[b] = AT(u[b*197])
+int launch_ln_cls(int precision, const float* u, const float* w, const float* b, void* out, float2* stats, void* u_cls,
+                  int batch, hipStream_t s);
+int launch_cls_index(int* cls_rows, int batch, hipStream_t s);
+
 int launch_im2col(int precision, const float* images, void* out, int batch, hipStream_t s);
 int launch_cls_rows(const float* cls, const float* pos, float* x0, int batch, hipStream_t s);
 // fp32 -> AT copy (n elements)
@@ -119,7 +124,7 @@ int launch_head_fwd(const float* x, const float* nw, const float* nb, const floa
 // g (all rows) = 0 except cls rows = LNbwd(dlogits @ Wh); dWh += dlogits^T cls_n ; dbh += colsum(dlogits)
 int launch_head_bwd(const float* dlogits, const float* x, const float* cls_n, const float2* stats,
                     const float* nw, const float* hw, float* g, float* dWh, float* dbh, int batch, int C,
-                    hipStream_t s);
+                    int compact, hipStream_t s);  // compact: g is [B,768] (cls rows only), no zero fill
 
 struct LossArgs {
     const float* logits_s; const float* logits_t; const int64_t* targets;
@@ -171,6 +176,8 @@ struct TokBwdArgs {
     float* partial;            // [nblocks][769] dwg / dbg partials
     int M;
     int write_du;              // 0 for block 0 (du itself is not needed)
+    const float* g_cls = nullptr;  // last block: incoming gradient exists for the cls rows only ([B,768]);
+                                   // du/dA2 are then read as (n == 0 ? g_cls[b] / dA2[b] : 0)
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
 // out[i] += alpha * sum_p partial[p*stride + i], i < n

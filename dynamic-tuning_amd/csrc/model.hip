@@ -111,6 +111,8 @@ struct Slot {
     std::vector<LayerS> L;
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
     int* counts = nullptr;   // [depth*B]
+    void* ucls_at = nullptr; // last block: AT(u[cls rows]) [B,768] (adapter-down operand, kept for its wgrad)
+    float* gcls = nullptr;   // last block backward: gradient at the cls rows [B,768]
     float* cls_n = nullptr;
     float2* head_stats = nullptr;
     int batch = 0, flags = 0;
@@ -136,6 +138,8 @@ struct dyt_ctx {
     int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
     std::vector<Slot> slots;
     float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses, *grad2;
+    int* cls_rows = nullptr;   // [max_batch] token row of each image's cls token (b*197)
+    bool cls_tail = true;      // last block: MLP/adapter on the cls rows only (only they reach the head)
     // second stream: the student and the teacher pass of a step are independent and run concurrently
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -196,6 +200,8 @@ static void layout(dyt_ctx* c, bool dry) {
         S.xs.resize(depth + 1);
         for (size_t l = 0; l <= depth; ++l) S.xs[l] = carve<float>(c, M * D, dry);
         S.counts = carve<int>(c, depth * B, dry);
+        S.ucls_at = carve_at(c, B * D, dry);
+        S.gcls = carve<float>(c, B * D, dry);
         S.cls_n = carve<float>(c, B * D, dry);
         S.head_stats = carve<float2>(c, B, dry);
         for (size_t l = 0; l < depth; ++l) {
@@ -234,6 +240,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
+    c->cls_rows = carve<int>(c, B, dry);
     c->dl_s = carve<float>(c, B * C, dry); c->dl_t = carve<float>(c, B * C, dry);
     c->logits_s = carve<float>(c, B * C, dry); c->logits_t = carve<float>(c, B * C, dry);
     c->dtok = carve<float>(c, 4, dry);
@@ -288,6 +295,9 @@ extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
     layout(c, false);
     e = hipMemset(c->arena, 0, c->arena_size);
     if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); hipFree(c->arena); delete c; return DYT_ERR_HIP; }
+    if (launch_cls_index(c->cls_rows, cfg->max_batch, nullptr) || hipDeviceSynchronize() != hipSuccess) {
+        hipFree(c->arena); delete c; return DYT_ERR_HIP;
+    }
     *out = c;
     return DYT_OK;
 }
@@ -539,20 +549,26 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
             RUN_GEMM(EPI_BIAS_RESID, a);
         }
-        // ---- adapter branch (all tokens): x_out = u + scale * up(dropout(relu(down(u)))) -- independent of
-        //      the gate / gather / fc1 chain below, so it runs on the pass's side stream until fc2 needs x_out
+        const bool tail = c->cls_tail && l == depth - 1;  // only the cls rows of the last block reach the head
+        const int Mr = tail ? B : M;                       // rows the adapter / MLP of this block run on
+        if (tail)   // LN2 of the cls rows + their AT copy (adapter operand); everything below works on B rows
+            RUN(2, 0, launch_ln_cls(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, S.ucls_at, B, s));
+        // ---- adapter branch: x_out = u + scale * up(dropout(relu(down(u)))) -- independent of the
+        //      gate / gather / fc1 chain below, so it runs on the pass's side stream until fc2 needs x_out
         FORK(sb);
         {
-            GemmArgs a; a.A = L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
+            GemmArgs a; a.A = tail ? S.ucls_at : L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
             a.bias = c->ad_down_b + l * RP; a.out_at = L.d_act; a.r = r; a.drop_p = drop_p;
             a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
             a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
+            a.row_map = tail ? c->cls_rows : nullptr;
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1);
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
         {
-            GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
+            GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
             a.bias = base + c->off_ub; a.resid = L.u; a.out_f32 = xo; a.scale = c->cfg.adapter_scale;
+            a.row_map = tail ? c->cls_rows : nullptr;
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_UP, a, s));
         }
         int* counts = S.counts + (size_t)l * B;
@@ -570,25 +586,29 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             ga.keep_local = L.keep_local; ga.counts = counts;
             RUN(2, 0, launch_gate(ga, s));
         }
-        if (!dense) {
+        if (tail) {
+            // nothing: T.xn already holds LN2 of the cls rows
+        } else if (!dense) {
             RUN(2, 0, launch_scan(counts, L.offsets, L.total, B, s));
             RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.offsets, L.maskf, T.xn, L.st2,
                                        L.row_src, L.dst_of, B, s));
         } else {
             RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s));
         }
-        // MLP on the kept (or all) tokens, scatter-add into the residual stream
-        const int* kdev = dense ? nullptr : L.total;
+        // MLP on the kept (or all / cls) tokens, scatter-add into the residual stream
+        const int* kdev = (dense || tail) ? nullptr : L.total;
         {
-            GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
+            GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr;
             RUN_GEMM(EPI_FC1, a);
         }
         JOIN(sb);  // x_out now holds u + adapter(u)
         {
-            GemmArgs a; a.A = T.h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
-            a.out_f32 = xo; a.row_map = dense ? nullptr : L.row_src; a.row_mask = masked_dense ? L.maskf : nullptr;
-            a.h_out = (save && !complete) ? L.h : nullptr;
+            GemmArgs a; a.A = T.h1; a.W = W.fc2_w; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
+            a.out_f32 = xo;
+            a.row_map = tail ? c->cls_rows : (dense ? nullptr : L.row_src);
+            a.row_mask = (masked_dense && !tail) ? L.maskf : nullptr;   // the cls token is never gated
+            a.h_out = (save && !complete && !tail) ? L.h : nullptr;     // cls rows carry no gate gradient
             RUN_GEMM(EPI_FC2, a);
         }
     }
@@ -629,8 +649,10 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
-    RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw, g,
-                              grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes, s));
+    const bool cls_tail = c->cls_tail;
+    RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw,
+                              cls_tail ? S.gcls : g, grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes,
+                              cls_tail ? 1 : 0, s));
 
     for (int l = depth - 1; l >= 0; --l) {
         const LayerW& W = c->W[l];
@@ -638,64 +660,69 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* gbase = grad + (int64_t)l * c->layer_stride;
         const bool first = l == 0;
-        const int* kdev = dense ? nullptr : L.total;
 
+        const bool tail = cls_tail && l == depth - 1;  // incoming gradient lives at the cls rows only (S.gcls)
+        const int Mr = tail ? B : M;
+        float* gin = tail ? S.gcls : g;
         // ---- 1. prep: AT copy of g, gathered/masked MLP gradient rows, <g,h> per token ----
-        const bool need_dH = masked_dense;  // compact mode gathers rows of g_at inside the GEMM (a_map)
+        const bool need_dH = masked_dense && !tail;  // compact mode gathers rows of g_at inside the GEMM (a_map)
         void* g_at = P == 0 ? nullptr : T.g_at;
-        if (g_at || need_dH || student) {
+        if (g_at || need_dH || (student && !tail)) {
             BwdPrepArgs a;
-            a.g = g; a.h = student ? L.h : nullptr; a.dst_of = dense ? nullptr : L.dst_of;
-            a.row_mask = masked_dense ? L.maskf : nullptr;
-            a.g_at = g_at; a.dH = (need_dH && !first) ? T.dH : nullptr; a.dmask = student ? T.dmask : nullptr; a.M = M;
+            a.g = gin; a.h = (student && !tail) ? L.h : nullptr; a.dst_of = (dense || tail) ? nullptr : L.dst_of;
+            a.row_mask = need_dH ? L.maskf : nullptr;
+            a.g_at = g_at; a.dH = (need_dH && !first) ? T.dH : nullptr; a.dmask = (student && !tail) ? T.dmask : nullptr;
+            a.M = Mr;
             RUN(2, 0, launch_bwd_prep(P, a, s));
         }
-        const void* A_g = g_at ? g_at : (const void*)g;
+        const void* A_g = g_at ? g_at : (const void*)gin;
+        const int* kdev = (dense || tail) ? nullptr : L.total;
         // ---- 2. adapter branch on the side stream: dgrad through up_proj, both wgrads, bias grads ----
         FORK(sb);
         {
-            GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = M; a.N = RP; a.K = D;
+            GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
             a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s));
         }
         {
-            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = M; a.r = r; a.partial = T.wg_partial;
+            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = T.wg_partial;
             a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
             a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
-            RUN_ON(sb, 2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
+            RUN_ON(sb, 2, 2.0 * Mr * D * (double)RP, launch_wgrad(P, a, s));
         }
         {
-            WgradArgs a; a.X = L.u_at; a.Y = T.ddz; a.M = M; a.r = r; a.partial = T.wg_partial;
+            WgradArgs a; a.X = tail ? S.ucls_at : L.u_at; a.Y = T.ddz; a.M = Mr; a.r = r; a.partial = T.wg_partial;
             a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
             a.out_xsum = nullptr; a.alpha_x = 0.f;
             a.out_ysum = gbase + c->off_db; a.alpha_y = 1.0f;                       // down_proj.bias
-            RUN_ON(sb, 2, 2.0 * M * D * (double)RP, launch_wgrad(P, a, s));
+            RUN_ON(sb, 2, 2.0 * Mr * D * (double)RP, launch_wgrad(P, a, s));
         }
         // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
             const void* A_dh = need_dH ? (const void*)T.dH : A_g;
             {
-                GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.M = M; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
-                a.a_map = dense ? nullptr : L.row_src; a.out_at = T.dZ;
+                GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
+                a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;
                 RUN_GEMM(EPI_GELU_BWD, a);
             }
             {
-                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.M = M; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
+                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
                 RUN_GEMM(EPI_STORE_AT, a);
             }
         }
         JOIN(sb);
         if (!first) {
-            GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = M; a.N = D; a.K = RP;
-            a.out_f32 = g; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
+            GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
+            a.out_f32 = gin; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
             RUN_GEMM(EPI_STORE_F32, a);
         }
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
         if (!first || student) {
             TokBwdArgs a;
-            a.du = g; a.dA2 = first ? nullptr : T.dA2; a.dst_of = dense ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
+            a.du = g; a.dA2 = first ? nullptr : T.dA2; a.dst_of = (dense || tail) ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
             a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
-            a.dmask = T.dmask;
+            a.dmask = tail ? nullptr : T.dmask;
+            a.g_cls = tail ? S.gcls : nullptr;
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;

@@ -273,6 +273,45 @@ int launch_ln_gather(int precision, const float* u, const float* w, const float*
     return 0;
 }
 
+template <class AT>
+__global__ __launch_bounds__(256) void ln_cls_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                     const float* __restrict__ bb, AT* __restrict__ out,
+                                                     float2* __restrict__ stats, AT* __restrict__ u_cls, int batch) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const size_t t = (size_t)b * NT;
+    Row12 xr, wr, br;
+    xr.load(u + t * D, lane);
+    wr.load(w, lane);
+    br.load(bb, lane);
+    if (u_cls) xr.store(u_cls + (size_t)b * D, lane);
+    const float2 st = ln_stats(xr);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - st.x) * st.y * wr.v[i] + br.v[i];
+    xr.store(out + (size_t)b * D, lane);
+    if (lane == 0) stats[t] = st;
+}
+int launch_ln_cls(int precision, const float* u, const float* w, const float* b, void* out, float2* stats, void* u_cls,
+                  int batch, hipStream_t s) {
+    const int grid = (batch + 3) / 4;
+    if (precision == 0)
+        hipLaunchKernelGGL(ln_cls_kernel<float>, dim3(grid), dim3(256), 0, s, u, w, b, (float*)out, stats, (float*)u_cls, batch);
+    else
+        hipLaunchKernelGGL(ln_cls_kernel<bf16>, dim3(grid), dim3(256), 0, s, u, w, b, (bf16*)out, stats, (bf16*)u_cls, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+__global__ void cls_index_kernel(int* __restrict__ cls_rows, int batch) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < batch) cls_rows[b] = b * NT;
+}
+int launch_cls_index(int* cls_rows, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(cls_index_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, cls_rows, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // patch embedding prologue
 // ------------------------------------------------------------------------------------------
@@ -405,7 +444,8 @@ int launch_head_fwd(const float* x, const float* nw, const float* nb, const floa
 
 __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
                                                           const float2* __restrict__ stats, const float* __restrict__ nw,
-                                                          const float* __restrict__ hw, float* __restrict__ g, int C) {
+                                                          const float* __restrict__ hw, float* __restrict__ g, int C,
+                                                          int g_stride) {
     __shared__ float red[4];
     __shared__ float dl[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -427,7 +467,7 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
     s1 = block_sum256(s1, red) * (1.0f / D);
     s2 = block_sum256(s2, red) * (1.0f / D);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g[(size_t)b * NT * D + tid + 256 * i] = st.y * (dy[i] - s1 - xh[i] * s2);
+    for (int i = 0; i < 3; ++i) g[(size_t)b * g_stride + tid + 256 * i] = st.y * (dy[i] - s1 - xh[i] * s2);
 }
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ dlogits, const float* __restrict__ cls_n,
                                                           float* __restrict__ dW, float* __restrict__ db, int batch, int C) {
@@ -445,10 +485,11 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
     if (tid == 0) db[c] += sb;
 }
 int launch_head_bwd(const float* dlogits, const float* x, const float* cls_n, const float2* stats, const float* nw,
-                    const float* hw, float* g, float* dWh, float* dbh, int batch, int C, hipStream_t s) {
+                    const float* hw, float* g, float* dWh, float* dbh, int batch, int C, int compact, hipStream_t s) {
     if (C > 1024) { set_error("head_bwd: num_classes %d > 1024 unsupported", C); return -1; }
-    DYT_HIP_CHECK(hipMemsetAsync(g, 0, (size_t)batch * NT * D * sizeof(float), s));
-    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(batch), dim3(256), 0, s, dlogits, x, stats, nw, hw, g, C);
+    if (!compact) DYT_HIP_CHECK(hipMemsetAsync(g, 0, (size_t)batch * NT * D * sizeof(float), s));
+    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(batch), dim3(256), 0, s, dlogits, x, stats, nw, hw, g, C,
+                       compact ? D : NT * D);
     hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(C), dim3(256), 0, s, dlogits, cls_n, dWh, dbh, batch, C);
     LAUNCH_CHECK();
     return 0;
@@ -623,13 +664,14 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         Row12 du, ur;
         const bool need_u = a.dA2 || a.gate_w;
         if (need_u) ur.load(a.u + (size_t)t * D, lane);
-        if (a.write_du) du.load(a.du + (size_t)t * D, lane);
+        if (a.write_du && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
+        else if (a.write_du && n == 0) du.load(a.g_cls + (size_t)b * D, lane);
         else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] = 0.f;
         }
         if (a.dA2 && a.write_du) {
-            const int r = a.dst_of ? a.dst_of[t] : t;
+            const int r = a.g_cls ? (n == 0 ? b : -1) : (a.dst_of ? a.dst_of[t] : t);
             if (r >= 0) {
                 Row12 dy;
                 dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
@@ -644,7 +686,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
             if (a.dtoken_select) ext = a.dtoken_select[oi];
             else if (a.dtok) ext = a.dtok[0] + (a.maskf[t] != 0.f ? a.dtok[2] : a.dtok[1]);
             const float sf = a.soft[t];
-            float dlogit = (a.dmask[t] + ext) * sf * (1.0f - sf);
+            float dlogit = ((a.dmask ? a.dmask[t] : 0.f) + ext) * sf * (1.0f - sf);
             if (a.training) dlogit /= a.tau;
             if (a.dtoken_logits) dlogit += a.dtoken_logits[oi];
 #pragma unroll
