@@ -430,6 +430,16 @@ struct ProfScope {
         if (_rc) return _rc;                                             \
     } while (0)
 
+extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    switch (option) {
+        case DYT_OPT_STREAM_OVERLAP: c->overlap = value != 0; return DYT_OK;
+        case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0; for (auto& S : c->slots) S.valid = false; return DYT_OK;
+    }
+    set_error("unknown option %d", option);
+    return DYT_ERR_ARG;
+}
+
 extern "C" int dyt_profile_enable(dyt_ctx* c, int on) {
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
     c->prof = on != 0;

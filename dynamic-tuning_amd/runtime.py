@@ -149,6 +149,10 @@ class DyTEngine:
             check(self.L.dyt_adamw(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_train,
                                    self.opt_step, lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr()))
 
+    def set_option(self, option, value):
+        """_lib.OPT_STREAM_OVERLAP / OPT_CLS_TAIL (scheduling only; results do not change)."""
+        check(self.L.dyt_ctx_set_option(self.h, int(option), int(bool(value))))
+
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on):
         check(self.L.dyt_profile_enable(self.h, 1 if on else 0))

@@ -92,6 +92,15 @@ int dyt_ctx_destroy(dyt_ctx* ctx);
 /* bytes of device memory the context holds (weights + workspace) */
 int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
 
+/* Scheduling options (results are identical either way; both default to on):
+ *   DYT_OPT_STREAM_OVERLAP  run the student / teacher passes and the adapter branch of every block on
+ *                           internal side streams (fork/join with events on the caller's stream)
+ *   DYT_OPT_CLS_TAIL        last block: evaluate MLP + adapter (forward and backward) for the cls rows
+ *                           only -- only x[:,0] reaches forward_head (vision_transformer_IN21K.py:375-380) */
+#define DYT_OPT_STREAM_OVERLAP 1
+#define DYT_OPT_CLS_TAIL 2
+int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
+
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library
  * keeps its own copies in the layouts/dtypes its kernels want (incl. transposes for dgrad).
  * Replaces load_state_dict(...) for the frozen keys -- main_image.py:245. */

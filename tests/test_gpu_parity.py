@@ -176,3 +176,35 @@ def test_gemm_variants_full_occupancy_bitwise():
             assert torch.equal(o, outs[0]), (M, N, K, int((o != outs[0]).sum()))
         ref = a.float() @ w.float().t()
         assert float((outs[0].float() - ref).abs().max() / ref.abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_scheduling_options_do_not_change_results(precision):
+    """Stream overlap (4 HIP streams) and the cls-only tail of the last block are pure scheduling / dead-work
+    elimination: losses, logits, masks and all 74 gradients must equal the plain serial, all-rows schedule."""
+    import _lib
+    B = 6
+    x, y = synth.make_batch(B, 100, seed=21)
+    g1, g2 = synth.make_noise(B, seed=22)
+    keep = synth.make_dropout_masks(B, 64, seed=23)
+    res = []
+    for overlap, tail in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        m = _bench_model(precision, "compact", B, 0.85)
+        m.train()
+        eng = m.engine(B, torch.device("cuda", 0))
+        eng.set_option(_lib.OPT_STREAM_OVERLAP, overlap)
+        eng.set_option(_lib.OPT_CLS_TAIL, tail)
+        ls = torch.empty(B, 100, device="cuda")
+        ts = torch.zeros(B, 12, 196, device="cuda")
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(),
+                                  keep_mask=keep.cuda().contiguous(), logits_s=ls, token_select=ts).clone()
+        torch.cuda.synchronize()
+        res.append((losses.cpu(), ls.cpu(), ts.cpu(), eng.grad.clone().cpu()))
+        del m, eng
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    base = res[0]
+    for r in res[1:]:
+        assert torch.equal(r[2], base[2])                                   # masks
+        assert float((r[1] - base[1]).abs().max()) < tol                    # logits
+        assert float((r[0][:5] - base[0][:5]).abs().max()) < tol * 10       # losses
+        assert float((r[3] - base[3]).norm() / base[3].norm()) < tol * 10   # flat gradient
