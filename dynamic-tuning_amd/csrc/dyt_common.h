@@ -58,9 +58,9 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
-// bf16-mode GELU: Abramowitz-Stegun 7.1.26 erfc polynomial (|err| <= 1.5e-7, far below bf16 output
-// rounding), written in the erfc form so 1+erf has no cancellation for x << 0; one v_exp + one v_rcp.
-//   cdf2(x) = 1 + erf(x/sqrt2) ;  e = exp(-x^2/2)
+
+
+
 // Normal CDF by Abramowitz-Stegun 26.2.19: Phi(a) = 1 - (1/2)(1 + d1 a + ... + d6 a^6)^-16 for a >= 0,
 // |err| < 1.5e-7 (9e-7 in fp32 arithmetic, checked against scipy.erf on [-8,8]); for x < 0 the tail
 // (1/2) p^-16 is used directly (no cancellation).  One v_rcp, no v_exp: ~2/3 the issue cost of the
