@@ -148,6 +148,9 @@ def main():
     model.train()
     opt = FusedAdamW(model, lr=1e-3 * args.batch * world / 256, weight_decay=0.01)
     eng = model._engine
+    if os.environ.get("DYT_NO_OVERLAP"):   # profiling aid: serial launches give clean per-kernel durations
+        import _lib
+        eng.set_option(_lib.OPT_STREAM_OVERLAP, 0)
     losses = torch.zeros(8, device=device)
     acc = torch.zeros(8, device=device)
 

@@ -132,6 +132,7 @@ struct LossArgs {
     int batch, C, depth;
     float target_ratio, loss_ratio, token_minimal, token_minimal_weight;
     float* dlogits_s; float* dlogits_t; float* out_losses; float* dtok;
+    float* scratch = nullptr;   // [4*B] per-image partial terms
 };
 int launch_loss(const LossArgs& a, hipStream_t s);
 

@@ -137,7 +137,7 @@ struct dyt_ctx {
     // trainable flat layout
     int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
     std::vector<Slot> slots;
-    float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses, *grad2;
+    float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses, *grad2, *loss_part;
     int* cls_rows = nullptr;   // [max_batch] token row of each image's cls token (b*197)
     bool cls_tail = true;      // last block: MLP/adapter on the cls rows only (only they reach the head)
     // second stream: the student and the teacher pass of a step are independent and run concurrently
@@ -244,6 +244,7 @@ static void layout(dyt_ctx* c, bool dry) {
     c->dl_s = carve<float>(c, B * C, dry); c->dl_t = carve<float>(c, B * C, dry);
     c->logits_s = carve<float>(c, B * C, dry); c->logits_t = carve<float>(c, B * C, dry);
     c->dtok = carve<float>(c, 4, dry);
+    c->loss_part = carve<float>(c, 4 * B, dry);
     c->losses = carve<float>(c, 8, dry);
 }
 
@@ -783,6 +784,8 @@ extern "C" int dyt_loss(dyt_ctx* c, int slot_student, const float* logits_s, con
     a.target_ratio = token_target_ratio; a.loss_ratio = token_loss_ratio; a.token_minimal = token_minimal;
     a.token_minimal_weight = token_minimal_weight;
     a.dlogits_s = dlogits_s; a.dlogits_t = dlogits_t; a.out_losses = out_losses; a.dtok = dtok;
+    a.scratch = c->loss_part;
+    if (batch > c->cfg.max_batch) { set_error("batch %d exceeds max_batch", batch); return DYT_ERR_ARG; }
     return launch_loss(a, s);
 }
 

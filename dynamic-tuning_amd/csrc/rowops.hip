@@ -498,51 +498,60 @@ int launch_head_bwd(const float* dlogits, const float* x, const float* cls_n, co
 // ------------------------------------------------------------------------------------------
 // step loss (one workgroup; B x C is tiny)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
-    __shared__ float red[4][4];
-    __shared__ float redk[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// stage 1: one wave per image (4 per workgroup): log-softmax of both logit rows, their gradients, and the
+// per-image CE / KL terms into part[b] = {ce_s, ce_t, kl}
+__global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int C = a.C, B = a.batch;
-    float ce_s = 0.f, ce_t = 0.f, kl = 0.f;
+    if (b >= B) return;
     const float invB = 1.0f / B;
-    for (int b = wave; b < B; b += 4) {
-        const float* ls = a.logits_s + (size_t)b * C;
-        const float* lt = a.logits_t + (size_t)b * C;
-        float ms = -INFINITY, mt = -INFINITY;
-        for (int c = lane; c < C; c += 64) { ms = fmaxf(ms, ls[c]); mt = fmaxf(mt, lt[c]); }
-        ms = wave_max(ms); mt = wave_max(mt);
-        float ss = 0.f, st = 0.f;
-        for (int c = lane; c < C; c += 64) { ss += expf(ls[c] - ms); st += expf(lt[c] - mt); }
-        const float lse_s = ms + logf(wave_sum(ss)), lse_t = mt + logf(wave_sum(st));
-        const int y = (int)a.targets[b];
-        float klb = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float lps = ls[c] - lse_s, lpt = lt[c] - lse_t;
-            const float ps = expf(lps), pt = expf(lpt);
-            klb += pt * (lpt - lps);
-            const float oh = c == y ? 1.0f : 0.0f;
-            a.dlogits_s[(size_t)b * C + c] = ((ps - oh) + (ps - pt)) * invB;
-            a.dlogits_t[(size_t)b * C + c] = (pt - oh) * invB;
-        }
-        klb = wave_sum(klb);
-        ce_s += -(ls[y] - lse_s);
-        ce_t += -(lt[y] - lse_t);
-        kl += klb;
+    const float* ls = a.logits_s + (size_t)b * C;
+    const float* lt = a.logits_t + (size_t)b * C;
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int c = lane; c < C; c += 64) { ms = fmaxf(ms, ls[c]); mt = fmaxf(mt, lt[c]); }
+    ms = wave_max(ms); mt = wave_max(mt);
+    float ss = 0.f, st = 0.f;
+    for (int c = lane; c < C; c += 64) { ss += expf(ls[c] - ms); st += expf(lt[c] - mt); }
+    const float lse_s = ms + logf(wave_sum(ss)), lse_t = mt + logf(wave_sum(st));
+    const int y = (int)a.targets[b];
+    float klb = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float lps = ls[c] - lse_s, lpt = lt[c] - lse_t;
+        const float ps = expf(lps), pt = expf(lpt);
+        klb += pt * (lpt - lps);
+        const float oh = c == y ? 1.0f : 0.0f;
+        a.dlogits_s[(size_t)b * C + c] = ((ps - oh) + (ps - pt)) * invB;
+        a.dlogits_t[(size_t)b * C + c] = (pt - oh) * invB;
     }
-    float kept = 0.f;
+    klb = wave_sum(klb);
+    if (lane == 0) {
+        part[b * 4 + 0] = -(ls[y] - lse_s);
+        part[b * 4 + 1] = -(lt[y] - lse_t);
+        part[b * 4 + 2] = klb;
+    }
+}
+// stage 2: one workgroup reduces the per-image terms (fixed order) and the kept-token counts
+__global__ __launch_bounds__(256) void loss_final_kernel(LossArgs a, const float* __restrict__ part) {
+    __shared__ float red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.batch;
+    float ce_s = 0.f, ce_t = 0.f, kl = 0.f, kept = 0.f;
+    for (int b = tid; b < B; b += 256) { ce_s += part[b * 4]; ce_t += part[b * 4 + 1]; kl += part[b * 4 + 2]; }
     if (a.counts)
         for (int i = tid; i < a.depth * B; i += 256) kept += (float)(a.counts[i] - 1);
-    kept = wave_sum(kept);
-    if (lane == 0) { red[wave][0] = ce_s; red[wave][1] = ce_t; red[wave][2] = kl; redk[wave] = kept; }
+    ce_s = wave_sum(ce_s); ce_t = wave_sum(ce_t); kl = wave_sum(kl); kept = wave_sum(kept);
+    if (lane == 0) { red[wave][0] = ce_s; red[wave][1] = ce_t; red[wave][2] = kl; red[wave][3] = kept; }
     __syncthreads();
     if (tid == 0) {
+        const float invB = 1.0f / B;
         const float base = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * invB;
         const float teacher = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * invB;
         const float klv = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * invB;
         float tok = 0.f, mean = 0.f, keptv = 0.f;
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
         if (a.counts) {
-            keptv = redk[0] + redk[1] + redk[2] + redk[3];
+            keptv = red[0][3] + red[1][3] + red[2][3] + red[3][3];
             const float N = (float)a.depth * B * NP;
             mean = keptv / N;
             const float diff = mean - a.target_ratio;
@@ -567,7 +576,9 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     }
 }
 int launch_loss(const LossArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, a);
+    if (!a.scratch) { set_error("loss: scratch missing"); return -1; }
+    hipLaunchKernelGGL(loss_rows_kernel, dim3((a.batch + 3) / 4), dim3(256), 0, s, a, a.scratch);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a, a.scratch);
     LAUNCH_CHECK();
     return 0;
 }
