@@ -131,3 +131,34 @@ def test_gumbel_sigmoid_utility_matches_oracle():
     b, _ = O.gumbel_sigmoid(logits, g1, g2, 5.0, 0.5, True)
     assert torch.equal(a, b)
     assert torch.equal(_gumbel_sigmoid(logits, 5, True, training=False), O.gumbel_sigmoid(logits, 0, 0, 5.0, 0.5, False)[0])
+
+
+def test_flops_accounting_closed_form():
+    """block_flops_dict mirror: dense ViT-B/16 comes out at the reference's 17.6 GMACs (engine_finetune.py:268)
+    and dropping tokens removes exactly 2*768*3072 MACs per token per block."""
+    import block_flops_dict as F
+    table = F.get_block_flops(ffn_num=64)
+    assert table.shape == (198,)
+    full = torch.ones(2, 12, 196, 1)
+    f = F.batch_select_flops(2, table, full, 12, F.get_base_flops())
+    adapters = 12 * 2 * 197 * 768 * 64 / 1e9 + 12 * 196 * 768 / 1e9
+    assert abs(float(f[0]) - adapters - 17.56) < 0.05, float(f[0])          # 17.6 "GFlops" in the reference's comments
+    half = full.clone(); half[:, :, ::2] = 0
+    g = F.batch_select_flops(2, table, half, 12, F.get_base_flops())
+    assert abs(float(f[0] - g[0]) - 12 * 98 * 2 * 768 * 3072 / 1e9) < 1e-4
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    import types
+    import misc
+    m = _model(num_classes=10, ffn_num=8)
+    args = types.SimpleNamespace(output_dir=str(tmp_path), epochs=3, save_freq=1, auto_remove=True, resume=None)
+    misc.save_model(args, 0, m, m, None)
+    misc.save_model(args, 1, m, m, None)
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint-1.pth"]                 # auto_remove keeps the newest
+    m2 = _model(num_classes=10, ffn_num=8)
+    args.resume = str(tmp_path / "checkpoint-1.pth")
+    misc.load_model(args, m2, None)
+    assert args.start_epoch == 2
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
