@@ -74,7 +74,8 @@ int launch_ln_fwd(int precision, const float* x, const float* w, const float* b,
 int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s);
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
-                  float* dx_out, int rows, hipStream_t s);
+                  float* dx_out, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
+                  hipStream_t s);
 
 struct GateArgs {
     const float* u;          // [B*197,768] residual stream after attention
@@ -97,9 +98,10 @@ struct GateArgs {
 int launch_gate(const GateArgs& a, hipStream_t s);
 // offsets[b] = exclusive prefix of counts, total[0] = sum
 int launch_scan(const int* counts, int* offsets, int* total, int batch, hipStream_t s);
-// LN2 of the kept rows into the compact A operand; row_src[dst]=src token row, dst_of[src]=dst or -1
+// LN2 of the kept rows into the compact A operand; row_src[dst]=src token row, dst_of[src]=dst or -1;
+// also computes the row offsets (prefix of counts) itself and publishes total[0] = sum(counts)
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
-                     const int* counts, const int* offsets, const float* maskf, void* out, float2* stats,
+                     const int* counts, int* total, const float* maskf, void* out, float2* stats,
                      int* row_src, int* dst_of, int batch, hipStream_t s);
 
 // last block: LayerNorm of the cls rows only (out[b] = LN(u[b*197])), stats[b*197], u_cls[b] = AT(u[b*197])

@@ -107,6 +107,7 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
 struct Slot {
     Transients T;
     hipStream_t branch = nullptr;        // side stream for the adapter branch of this pass
+    float* u0_own = nullptr; void* u0_at_own = nullptr;  // block-0 buffers (slot 1 may alias slot 0's, see step)
     hipEvent_t ev_f = nullptr, ev_j = nullptr;
     std::vector<LayerS> L;
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
@@ -142,8 +143,9 @@ struct dyt_ctx {
     bool cls_tail = true;      // last block: MLP/adapter on the cls rows only (only they reach the head)
     // second stream: the student and the teacher pass of a step are independent and run concurrently
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_b0 = nullptr;
     bool overlap = true;
+    bool share_block0 = true;  // step: the teacher pass reuses the student's embedding + block-0 attention branch
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -294,6 +296,7 @@ extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
         return DYT_ERR_HIP;
     }
     layout(c, false);
+    for (auto& S : c->slots) { S.u0_own = S.L[0].u; S.u0_at_own = S.L[0].u_at; }
     e = hipMemset(c->arena, 0, c->arena_size);
     if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); hipFree(c->arena); delete c; return DYT_ERR_HIP; }
     if (launch_cls_index(c->cls_rows, cfg->max_batch, nullptr) || hipDeviceSynchronize() != hipSuccess) {
@@ -312,6 +315,7 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
         if (S.ev_j) hipEventDestroy(S.ev_j);
         if (S.branch) hipStreamDestroy(S.branch);
     }
+    if (c->ev_b0) hipEventDestroy(c->ev_b0);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side) hipStreamDestroy(c->side);
@@ -436,6 +440,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
     switch (option) {
         case DYT_OPT_STREAM_OVERLAP: c->overlap = value != 0; return DYT_OK;
         case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0; for (auto& S : c->slots) S.valid = false; return DYT_OK;
+        case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
     }
     set_error("unknown option %d", option);
     return DYT_ERR_ARG;
@@ -515,7 +520,10 @@ static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return 
 
 static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int flags, const float* trainable,
                         const float* g1, const float* g2, const uint8_t* keep_mask, uint64_t seed, float* logits,
-                        float* token_select, float* token_logits, bool do_prep, hipStream_t s) {
+                        float* token_select, float* token_logits, bool do_prep, hipStream_t s,
+                        const Slot* share0 = nullptr, hipEvent_t ev_b0_record = nullptr, hipEvent_t ev_b0_wait = nullptr) {
+    // share0: reuse another pass's embedding + block-0 attention branch (same images, same frozen weights):
+    //         its u / u_at of block 0 become this pass's (the step function aliases the pointers).
     if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
     if (B < 1 || B > c->cfg.max_batch) { set_error("batch %d exceeds max_batch %d", B, c->cfg.max_batch); return DYT_ERR_ARG; }
     if (!images || !trainable || !logits) { set_error("null argument"); return DYT_ERR_ARG; }
@@ -533,14 +541,18 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
-    // patch embedding: im2col + GEMM (+bias +pos_embed), cls rows
-    RUN(2, 0, launch_im2col(P, images, T.xn, B, s));
-    {
-        GemmArgs a; a.A = T.xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
-        a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0];
-        RUN_GEMM(EPI_EMBED, a);
+    if (!share0) {
+        // patch embedding: im2col + GEMM (+bias +pos_embed), cls rows
+        RUN(2, 0, launch_im2col(P, images, T.xn, B, s));
+        {
+            GemmArgs a; a.A = T.xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
+            a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0];
+            RUN_GEMM(EPI_EMBED, a);
+        }
+        RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
+    } else if (ev_b0_wait) {
+        DYT_HIP_CHECK(hipStreamWaitEvent(s, ev_b0_wait, 0));  // the other pass's block-0 `u` is complete
     }
-    RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
 
     for (int l = 0; l < depth; ++l) {
         const LayerW& W = c->W[l];
@@ -548,17 +560,20 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
-        RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s));
-        {
-            GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
-            a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
-            RUN_GEMM(EPI_QKV, a);
-        }
-        RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
-        {
-            GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
-            a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
-            RUN_GEMM(EPI_BIAS_RESID, a);
+        if (!(share0 && l == 0)) {
+            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s));
+            {
+                GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
+                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
+                RUN_GEMM(EPI_QKV, a);
+            }
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
+            {
+                GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
+                a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
+                RUN_GEMM(EPI_BIAS_RESID, a);
+            }
+            if (l == 0 && ev_b0_record) DYT_HIP_CHECK(hipEventRecord(ev_b0_record, s));
         }
         const bool tail = c->cls_tail && l == depth - 1;  // only the cls rows of the last block reach the head
         const int Mr = tail ? B : M;                       // rows the adapter / MLP of this block run on
@@ -600,8 +615,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         if (tail) {
             // nothing: T.xn already holds LN2 of the cls rows
         } else if (!dense) {
-            RUN(2, 0, launch_scan(counts, L.offsets, L.total, B, s));
-            RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.offsets, L.maskf, T.xn, L.st2,
+            RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.total, L.maskf, T.xn, L.st2,
                                        L.row_src, L.dst_of, B, s));
         } else {
             RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s));
@@ -633,6 +647,10 @@ extern "C" int dyt_forward(dyt_ctx* c, int slot, const float* images, int batch,
                            const float* g1, const float* g2, const uint8_t* keep_mask, uint64_t seed, float* logits,
                            float* token_select, float* token_logits, void* stream) {
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    if (slot >= 0 && slot < c->cfg.slots) {  // a stand-alone pass owns its block-0 buffers
+        Slot& S = c->slots[slot];
+        S.L[0].u = S.u0_own; S.L[0].u_at = S.u0_at_own;
+    }
     return forward_impl(c, slot, images, batch, flags, trainable, g1, g2, keep_mask, seed, logits, token_select,
                         token_logits, true, static_cast<hipStream_t>(stream));
 }
@@ -665,6 +683,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                               cls_tail ? S.gcls : g, grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes,
                               cls_tail ? 1 : 0, s));
 
+    bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
     for (int l = depth - 1; l >= 0; --l) {
         const LayerW& W = c->W[l];
         LayerS& L = S.L[l];
@@ -678,7 +697,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // ---- 1. prep: AT copy of g, gathered/masked MLP gradient rows, <g,h> per token ----
         const bool need_dH = masked_dense && !tail;  // compact mode gathers rows of g_at inside the GEMM (a_map)
         void* g_at = P == 0 ? nullptr : T.g_at;
-        if (g_at || need_dH || (student && !tail)) {
+        if (!prepped && (g_at || need_dH || (student && !tail))) {
             BwdPrepArgs a;
             a.g = gin; a.h = (student && !tail) ? L.h : nullptr; a.dst_of = (dense || tail) ? nullptr : L.dst_of;
             a.row_mask = need_dH ? L.maskf : nullptr;
@@ -755,7 +774,14 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
             RUN_GEMM(EPI_STORE_AT, a);
         }
-        RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, s));
+        {   // LN1 backward; fused with the next block's prep unless that block needs the masked dH copy
+            const bool fuse = !masked_dense;
+            const LayerS& Ln = S.L[l - 1];
+            RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, fuse ? g_at : nullptr,
+                                    (fuse && student) ? Ln.h : nullptr, (fuse && !dense) ? Ln.dst_of : nullptr,
+                                    (fuse && student) ? T.dmask : nullptr, s));
+            prepped = fuse;
+        }
     }
     return DYT_OK;
 }
@@ -824,11 +850,24 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     int rc = prep_adapters(c, trainable, s);
     if (rc) return rc;
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
-    rc = forward_impl(c, 0, images, batch, fl, trainable, g1, g2, keep_mask, seed, ls, token_select, nullptr, false, s);
+    // The two passes see the same images and the same frozen weights, and nothing trainable or random sits
+    // in front of block 0's attention branch: the teacher pass reuses the student's embedding, LN1, qkv,
+    // attention and proj of block 0 (its block-0 `u` pointers alias the student's for this step).
+    const bool share = c->share_block0;
+    if (share && !c->ev_b0) DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_b0, hipEventDisableTiming));
+    {
+        Slot& S0 = c->slots[0]; Slot& S1 = c->slots[1];
+        S0.L[0].u = S0.u0_own; S0.L[0].u_at = S0.u0_at_own;
+        S1.L[0].u = share ? S0.u0_own : S1.u0_own;
+        S1.L[0].u_at = share ? S0.u0_at_own : S1.u0_at_own;
+    }
+    rc = forward_impl(c, 0, images, batch, fl, trainable, g1, g2, keep_mask, seed, ls, token_select, nullptr, false, s,
+                      nullptr, share ? c->ev_b0 : nullptr, nullptr);
     if (rc) return rc;
     // the teacher pass draws its own noise in the reference (mask discarded): only the dropout stream matters
     rc = forward_impl(c, 1, images, batch, fl | DYT_F_COMPLETE, trainable, g1 ? g1 + nz : nullptr, g2 ? g2 + nz : nullptr,
-                      keep_mask ? keep_mask + kz : nullptr, seed, lt, nullptr, nullptr, false, s2);
+                      keep_mask ? keep_mask + kz : nullptr, seed, lt, nullptr, nullptr, false, s2,
+                      share ? &c->slots[0] : nullptr, nullptr, (share && par) ? c->ev_b0 : nullptr);
     if (rc) return rc;
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_join, s2)); DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0)); }
     rc = dyt_loss(c, 0, ls, lt, targets, batch, token_target_ratio, token_loss_ratio, token_minimal, token_minimal_weight,

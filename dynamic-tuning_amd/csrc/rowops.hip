@@ -103,10 +103,14 @@ __device__ __forceinline__ void ln_bwd_row(Row12& dy, const Row12& x, const Row1
     for (int i = 0; i < 12; ++i) dy.v[i] = st.y * (dy.v[i] - s1 - xh.v[i] * s2);
 }
 
+// dx = base + LNbwd(dy).  Optionally also does the NEXT (lower) block's backward prep on the row it just
+// produced (saves re-reading the 77 MB gradient): AT copy of dx, and <dx, h_next> for the gate gradient.
 template <class AT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ w,
-                                                     const float* __restrict__ base, float* __restrict__ dx, int rows) {
+                                                     const float* __restrict__ base, float* __restrict__ dx, int rows,
+                                                     AT* __restrict__ g_at, const AT* __restrict__ h_next,
+                                                     const int* __restrict__ dst_of_next, float* __restrict__ dmask_next) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -122,6 +126,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
     g.store(dx + (size_t)row * D, lane);
+    if (g_at) g.store(g_at + (size_t)row * D, lane);
+    if (dmask_next) {
+        float dm = 0.f;
+        const int r = dst_of_next ? dst_of_next[row] : row;
+        if (h_next && r >= 0) {
+            Row12 hr;
+            hr.load_at(h_next + (size_t)r * D, lane);
+            dm = dot12(g, hr);
+        }
+        if (lane == 0) dmask_next[row] = dm;
+    }
 }
 
 int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats, int rows,
@@ -138,11 +153,14 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
     return launch_ln_fwd(0, x, w, b, out, nullptr, rows, s);
 }
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
-                  float* dx, int rows, hipStream_t s) {
+                  float* dx, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
+                  hipStream_t s) {
     if (precision == 0)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx, rows);
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx,
+                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)dy, x, stats, w, base, dx, rows);
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)dy, x, stats, w, base, dx,
+                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next);
     LAUNCH_CHECK();
     return 0;
 }
@@ -229,7 +247,7 @@ int launch_scan(const int* counts, int* offsets, int* total, int batch, hipStrea
 template <class AT>
 __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict__ u, const float* __restrict__ w,
                                                         const float* __restrict__ bb, const int* __restrict__ keep_local,
-                                                        const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                        const int* __restrict__ counts, int* __restrict__ total,
                                                         const float* __restrict__ maskf, AT* __restrict__ out,
                                                         float2* __restrict__ stats, int* __restrict__ row_src,
                                                         int* __restrict__ dst_of, int batch) {
@@ -238,12 +256,24 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
     if (slot >= batch * NT) return;
     const int b = slot / NT, j = slot - b * NT;
     const int cnt = counts[b];
+    // exclusive prefix of the per-image counts, recomputed by every wave (B <= 1024 ints: cheaper than a
+    // separate single-thread scan kernel on the critical path); wave 0 also publishes the grand total
+    int off = 0;
+    {
+        const int lim = slot == 0 ? batch : b;
+        int part = 0;
+        for (int i = lane; i < lim; i += 64) part += counts[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (slot == 0) { if (lane == 0) total[0] = part; }
+        else off = part;
+    }
     // role 1: this wave owns TOKEN `slot`: a dropped token has no compact row
     if (lane == 0 && maskf[slot] == 0.f) dst_of[slot] = -1;
     // role 2: this wave owns COMPACT slot j of image b
     if (j >= cnt) return;
     const int src = b * NT + keep_local[(size_t)b * NT + j];
-    const int dst = offsets[b] + j;
+    const int dst = off + j;
     Row12 xr, wr, br;
     xr.load(u + (size_t)src * D, lane);
     wr.load(w, lane);
@@ -260,14 +290,14 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
 }
 
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
-                     const int* counts, const int* offsets, const float* maskf, void* out, float2* stats,
+                     const int* counts, int* total, const float* maskf, void* out, float2* stats,
                      int* row_src, int* dst_of, int batch, hipStream_t s) {
     const int grid = (batch * NT + 3) / 4;
     if (precision == 0)
-        hipLaunchKernelGGL(ln_gather_kernel<float>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, offsets,
+        hipLaunchKernelGGL(ln_gather_kernel<float>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, total,
                            maskf, (float*)out, stats, row_src, dst_of, batch);
     else
-        hipLaunchKernelGGL(ln_gather_kernel<bf16>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, offsets,
+        hipLaunchKernelGGL(ln_gather_kernel<bf16>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, total,
                            maskf, (bf16*)out, stats, row_src, dst_of, batch);
     LAUNCH_CHECK();
     return 0;

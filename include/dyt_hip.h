@@ -96,9 +96,12 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *   DYT_OPT_STREAM_OVERLAP  run the student / teacher passes and the adapter branch of every block on
  *                           internal side streams (fork/join with events on the caller's stream)
  *   DYT_OPT_CLS_TAIL        last block: evaluate MLP + adapter (forward and backward) for the cls rows
- *                           only -- only x[:,0] reaches forward_head (vision_transformer_IN21K.py:375-380) */
+ *                           only -- only x[:,0] reaches forward_head (vision_transformer_IN21K.py:375-380)
+ *   DYT_OPT_SHARE_BLOCK0    dyt_step_fwd_bwd: the teacher pass reuses the student pass's patch embedding and
+ *                           block-0 attention branch (same images, frozen weights, nothing random before it) */
 #define DYT_OPT_STREAM_OVERLAP 1
 #define DYT_OPT_CLS_TAIL 2
+#define DYT_OPT_SHARE_BLOCK0 3
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library

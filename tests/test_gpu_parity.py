@@ -180,20 +180,21 @@ def test_gemm_variants_full_occupancy_bitwise():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_scheduling_options_do_not_change_results(precision):
-    """Stream overlap (4 HIP streams) and the cls-only tail of the last block are pure scheduling / dead-work
-    elimination: losses, logits, masks and all 74 gradients must equal the plain serial, all-rows schedule."""
+    """Stream overlap (4 HIP streams), the cls-only tail of the last block and the shared block-0 attention
+    branch are pure scheduling / dead- or duplicate-work elimination: losses, logits, masks and all 74 gradients must equal the plain serial, all-rows schedule."""
     import _lib
     B = 6
     x, y = synth.make_batch(B, 100, seed=21)
     g1, g2 = synth.make_noise(B, seed=22)
     keep = synth.make_dropout_masks(B, 64, seed=23)
     res = []
-    for overlap, tail in ((0, 0), (1, 0), (0, 1), (1, 1)):
+    for overlap, tail, share in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)):
         m = _bench_model(precision, "compact", B, 0.85)
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
         eng.set_option(_lib.OPT_STREAM_OVERLAP, overlap)
         eng.set_option(_lib.OPT_CLS_TAIL, tail)
+        eng.set_option(_lib.OPT_SHARE_BLOCK0, share)
         ls = torch.empty(B, 100, device="cuda")
         ts = torch.zeros(B, 12, 196, device="cuda")
         losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(),
