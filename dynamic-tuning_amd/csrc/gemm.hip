@@ -677,6 +677,7 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 9: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, epi, s);
         case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
+        case 52: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, EpiProbe<2>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
         case 15: return launch_bf16_cfg<256, 256, 2, 4, 3>(a, epi, s);
         case 16: return launch_bf16_cfg<256, 256, 2, 4, 6>(a, epi, s);
         case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);

@@ -4,6 +4,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
 from _lib import check, lib, ptr, stream_ptr
+VAR = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 
 def run(a, w, M, N, K, v):
     c = torch.zeros(2 * M, N, device="cuda", dtype=torch.bfloat16)
@@ -18,7 +19,7 @@ for (M, N, K) in [(25216, 2304, 768), (25216, 3072, 768), (17690, 3072, 768), (4
     ref = run(a, w, M, N, K, 0)
     bad_rows_total = 0
     for rep in range(6):
-        c = run(a, w, M, N, K, 10)
+        c = run(a, w, M, N, K, VAR)
         diff = (c != ref)
         nbad = int(diff.sum())
         if nbad:
@@ -28,4 +29,4 @@ for (M, N, K) in [(25216, 2304, 768), (25216, 3072, 768), (17690, 3072, 768), (4
                 rep, nbad, int(rows.min()), int(rows.max()), rows.numel(), int(cols.min()), int(cols.max()),
                 float((c.float() - ref.float()).abs().max())))
             bad_rows_total += nbad
-    print("M=%d N=%d K=%d: v10 vs v0 bitwise %s" % (M, N, K, "EQUAL (6 reps)" if bad_rows_total == 0 else "DIFFERENT"))
+    print("M=%d N=%d K=%d: v%d vs v0 bitwise %s" % (M, N, K, VAR, "EQUAL (6 reps)" if bad_rows_total == 0 else "DIFFERENT"))
