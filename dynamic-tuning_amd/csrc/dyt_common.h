@@ -73,7 +73,7 @@ __device__ __forceinline__ float normal_cdf_fast(float x) {
     p = fmaf(p, a, 0.0211410061f);
     p = fmaf(p, a, 0.0498673470f);
     p = fmaf(p, a, 1.0f);
-    float q = __frcp_rn(p);
+    float q = __builtin_amdgcn_rcpf(p);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
     q *= q; q *= q; q *= q; q *= q;      // p^-16
     const float half = 0.5f * q;
     return x >= 0.f ? 1.0f - half : half;

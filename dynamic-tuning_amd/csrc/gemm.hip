@@ -20,112 +20,189 @@
 namespace dyt {
 
 // ------------------------------------------------------------------------------------------
-// epilogues: operator()(row, col, v[4]) handles 4 consecutive columns of one output row
+// epilogues.  One functor call handles 4 consecutive columns of one output row, in three parts so that
+// the MFMA kernel can keep memory latency off the critical path:
+//   col_init(col)            per-lane column constants (bias ...): a lane's column is the same for every
+//                            chunk it handles, so this is loaded ONCE per tile
+//   pre(row, col)            the functor's own global loads (residual, gelu', row maps), returned RAW so
+//                            that a whole pass worth of them is in flight before the first use
+//   apply(row, col, v, c, p) the arithmetic and the stores
+// operator()(row, col, v) chains the three (the fp32 exact kernel's per-thread 4x4 tile uses that).
 // ------------------------------------------------------------------------------------------
+struct NoCtx {};
+struct Bias4 { float b[4]; };
+__device__ __forceinline__ Bias4 load_bias4(const float* bias, int col) {
+    Bias4 r;
+    if (bias) { r.b[0] = bias[col]; r.b[1] = bias[col + 1]; r.b[2] = bias[col + 2]; r.b[3] = bias[col + 3]; }
+    else { r.b[0] = r.b[1] = r.b[2] = r.b[3] = 0.f; }
+    return r;
+}
+template <class T> struct Raw4;   // 4 consecutive activations as loaded (conversion deferred to the use)
+template <> struct Raw4<float> {
+    float4 v;
+    __device__ __forceinline__ void get(float (&o)[4]) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+template <> struct Raw4<bf16> {
+    bf16x4 v;
+    __device__ __forceinline__ void get(float (&o)[4]) const {
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+};
+__device__ __forceinline__ Raw4<float> load_raw4(const float* p) { return {*reinterpret_cast<const float4*>(p)}; }
+__device__ __forceinline__ Raw4<bf16> load_raw4(const bf16* p) { return {*reinterpret_cast<const bf16x4*>(p)}; }
+// streaming store: the value is not read again soon (gelu' is consumed by the backward pass) -- keeps the
+// write burst out of the L2 lines the main loops of the other workgroups are hitting
+__device__ __forceinline__ void store4_nt(float* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
+__device__ __forceinline__ void store4_nt(bf16* p, float a, float b, float c, float d) {
+    bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+    __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
+}
+#define DYT_EPI_CHAIN                                                                            \
+    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {     \
+        apply(row, col, a, col_init(col), pre(row, col));                                        \
+    }
+
 struct EpiBiasF32 {
     const float* bias; float* out; int ld;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (bias) { b0 = bias[col]; b1 = bias[col + 1]; b2 = bias[col + 2]; b3 = bias[col + 3]; }
-        store4(out + (size_t)row * ld + col, a[0] + b0, a[1] + b1, a[2] + b2, a[3] + b3);
+    typedef Bias4 Col; typedef NoCtx Pre;
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre&) const {
+        store4(out + (size_t)row * ld + col, a[0] + c.b[0], a[1] + c.b[1], a[2] + c.b[2], a[3] + c.b[3]);
     }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
 struct EpiQKV {
     const float* bias; AT* q; AT* k; AT* v;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+    struct Col { Bias4 b; AT* base; float s; };
+    typedef NoCtx Pre;
+    __device__ __forceinline__ Col col_init(int col) const {
         const int which = col / D;
         const int c = col - which * D;
         const int h = c >> 6, d = c & 63;
-        const int b = row / NT, n = row - b * NT;
-        const float s = which == 0 ? 0.125f : 1.0f;  // head_dim ** -0.5, exact in every dtype
-        AT* base = which == 0 ? q : (which == 1 ? k : v);
-        AT* dst = base + ((((size_t)b * NH + h) * NT + n) << 6) + d;
-        store4(dst, (a[0] + bias[col]) * s, (a[1] + bias[col + 1]) * s, (a[2] + bias[col + 2]) * s,
-               (a[3] + bias[col + 3]) * s);
+        Col r;
+        r.b = load_bias4(bias, col);
+        r.s = which == 0 ? 0.125f : 1.0f;  // head_dim ** -0.5, exact in every dtype
+        r.base = (which == 0 ? q : (which == 1 ? k : v)) + (((size_t)h * NT) << 6) + d;
+        return r;
     }
+    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
+    __device__ __forceinline__ void apply(int row, int, const float (&a)[4], const Col& c, const Pre&) const {
+        const int b = row / NT, n = row - b * NT;
+        AT* dst = c.base + (((size_t)b * NH * NT + n) << 6);
+        store4(dst, (a[0] + c.b.b[0]) * c.s, (a[1] + c.b.b[1]) * c.s, (a[2] + c.b.b[2]) * c.s, (a[3] + c.b.b[3]) * c.s);
+    }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
 struct EpiBiasResid {
     const float* bias; const float* resid; float* out; AT* out_at; int ld;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+    typedef Bias4 Col; typedef Raw4<float> Pre;
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(resid + (size_t)row * ld + col); }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         const size_t o = (size_t)row * ld + col;
         float r[4];
-        load4(resid + o, r);
-        const float v0 = a[0] + bias[col] + r[0], v1 = a[1] + bias[col + 1] + r[1];
-        const float v2 = a[2] + bias[col + 2] + r[2], v3 = a[3] + bias[col + 3] + r[3];
+        p.get(r);
+        const float v0 = a[0] + c.b[0] + r[0], v1 = a[1] + c.b[1] + r[1];
+        const float v2 = a[2] + c.b[2] + r[2], v3 = a[3] + c.b[3] + r[3];
         store4(out + o, v0, v1, v2, v3);
         if (out_at) store4(out_at + o, v0, v1, v2, v3);
     }
+    DYT_EPI_CHAIN
 };
 
-template <class AT>
+template <class AT, bool HAS_GP>
 struct EpiFc1 {
     const float* bias; AT* h; AT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+    typedef Bias4 Col; typedef NoCtx Pre;
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre&) const {
         const size_t o = (size_t)row * ld + col;
         float hv[4], gv[4];
-        if (gp) {
+        if (HAS_GP) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gelu_both<AT>(a[i] + bias[col + i], hv[i], gv[i]);
-            store4(gp + o, gv[0], gv[1], gv[2], gv[3]);
+            for (int i = 0; i < 4; ++i) gelu_both<AT>(a[i] + c.b[i], hv[i], gv[i]);
+            store4_nt(gp + o, gv[0], gv[1], gv[2], gv[3]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + bias[col + i]);
+            for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + c.b[i]);
         }
         store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
 struct EpiFc2 {
     const float* bias; float* x; const int* row_map; const float* row_mask; AT* h_out;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const int dst = row_map ? row_map[row] : row;
-        const float h0 = a[0] + bias[col], h1 = a[1] + bias[col + 1], h2 = a[2] + bias[col + 2],
-                    h3 = a[3] + bias[col + 3];
-        if (h_out) store4(h_out + (size_t)row * D + col, h0, h1, h2, h3);
-        const float m = row_mask ? row_mask[dst] : 1.0f;
-        float* p = x + (size_t)dst * D + col;
-        float r[4];
-        load4(p, r);
-        store4(p, r[0] + m * h0, r[1] + m * h1, r[2] + m * h2, r[3] + m * h3);
+    typedef Bias4 Col;
+    struct Pre { int dst; float m; Raw4<float> r; };
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int row, int col) const {
+        Pre p;
+        p.dst = row_map ? row_map[row] : row;
+        p.m = row_mask ? row_mask[p.dst] : 1.0f;
+        p.r = load_raw4(x + (size_t)p.dst * D + col);   // in place: this chunk is the only writer of these 4 values
+        return p;
     }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
+        const float h0 = a[0] + c.b[0], h1 = a[1] + c.b[1], h2 = a[2] + c.b[2], h3 = a[3] + c.b[3];
+        if (h_out) store4(h_out + (size_t)row * D + col, h0, h1, h2, h3);
+        float r[4];
+        p.r.get(r);
+        store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);
+    }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
 struct EpiGeluBwd {
     const AT* gp; AT* out; int ld;   // gp = gelu'(z) saved by the fc1 epilogue
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const size_t o = (size_t)row * ld + col;
+    typedef NoCtx Col; typedef Raw4<AT> Pre;
+    __device__ __forceinline__ Col col_init(int) const { return {}; }
+    __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(gp + (size_t)row * ld + col); }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre& p) const {
         float g[4];
-        load4(gp + o, g);
-        store4(out + o, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
+        p.get(g);
+        store4(out + (size_t)row * ld + col, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
     }
+    DYT_EPI_CHAIN
 };
 
 struct EpiStoreF32 {
     float* out; int ld; int accumulate;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        float* p = out + (size_t)row * ld + col;
-        if (accumulate) {
-            float r[4];
-            load4(p, r);
-            store4(p, r[0] + a[0], r[1] + a[1], r[2] + a[2], r[3] + a[3]);
-        } else {
-            store4(p, a[0], a[1], a[2], a[3]);
-        }
+    typedef NoCtx Col; typedef Raw4<float> Pre;
+    __device__ __forceinline__ Col col_init(int) const { return {}; }
+    __device__ __forceinline__ Pre pre(int row, int col) const {
+        if (accumulate) return load_raw4(out + (size_t)row * ld + col);
+        return {make_float4(0.f, 0.f, 0.f, 0.f)};
     }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre& p) const {
+        float r[4];
+        p.get(r);
+        store4(out + (size_t)row * ld + col, r[0] + a[0], r[1] + a[1], r[2] + a[2], r[3] + a[3]);
+    }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
 struct EpiStoreAT {
     AT* out; int ld;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+    typedef NoCtx Col; typedef NoCtx Pre;
+    __device__ __forceinline__ Col col_init(int) const { return {}; }
+    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre&) const {
         store4(out + (size_t)row * ld + col, a[0], a[1], a[2], a[3]);
     }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -134,11 +211,15 @@ struct EpiAdDown {
     AT* out;            // [M, RP]
     const uint8_t* keep; int r; float inv_keep; float drop_p; uint64_t seed, subseq;
     const int* row_map;  // token row of compact row `row` (mask / RNG are indexed by token), or null
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const int trow = row_map ? row_map[row] : row;
+    typedef Bias4 Col;
+    struct Pre { int trow; };
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int row, int) const { return {row_map ? row_map[row] : row}; }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
+        const int trow = p.trow;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[i] + bias[col + i], 0.0f);
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[i] + c.b[i], 0.0f);
         if (drop_p > 0.f) {
             if (keep) {
 #pragma unroll
@@ -152,41 +233,61 @@ struct EpiAdDown {
         }
         store4(out + (size_t)row * RP + col, v[0], v[1], v[2], v[3]);
     }
+    DYT_EPI_CHAIN
 };
 
 struct EpiAdUp {
     const float* bias; const float* u; float* out; float scale; const int* row_map;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const size_t o = (size_t)(row_map ? row_map[row] : row) * D + col;
-        float r[4];
-        load4(u + o, r);
-        store4(out + o, r[0] + scale * (a[0] + bias[col]), r[1] + scale * (a[1] + bias[col + 1]),
-               r[2] + scale * (a[2] + bias[col + 2]), r[3] + scale * (a[3] + bias[col + 3]));
+    typedef Bias4 Col;
+    struct Pre { int dst; Raw4<float> r; };
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int row, int col) const {
+        Pre p;
+        p.dst = row_map ? row_map[row] : row;
+        p.r = load_raw4(u + (size_t)p.dst * D + col);
+        return p;
     }
+    __device__ __forceinline__ void apply(int, int col, const float (&a)[4], const Col& c, const Pre& p) const {
+        float r[4];
+        p.r.get(r);
+        store4(out + (size_t)p.dst * D + col, r[0] + scale * (a[0] + c.b[0]), r[1] + scale * (a[1] + c.b[1]),
+               r[2] + scale * (a[2] + c.b[2]), r[3] + scale * (a[3] + c.b[3]));
+    }
+    DYT_EPI_CHAIN
 };
 
 template <class AT>
 struct EpiAdDgradUp {
     const AT* dact; AT* out; float scale; float inv_keep;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const size_t o = (size_t)row * RP + col;
+    typedef NoCtx Col; typedef Raw4<AT> Pre;
+    __device__ __forceinline__ Col col_init(int) const { return {}; }
+    __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(dact + (size_t)row * RP + col); }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre& p) const {
         float d[4];
-        load4(dact + o, d);
+        p.get(d);
         const float s = scale * inv_keep;
-        store4(out + o, d[0] != 0.f ? a[0] * s : 0.f, d[1] != 0.f ? a[1] * s : 0.f, d[2] != 0.f ? a[2] * s : 0.f,
-               d[3] != 0.f ? a[3] * s : 0.f);
+        store4(out + (size_t)row * RP + col, d[0] != 0.f ? a[0] * s : 0.f, d[1] != 0.f ? a[1] * s : 0.f,
+               d[2] != 0.f ? a[2] * s : 0.f, d[3] != 0.f ? a[3] * s : 0.f);
     }
+    DYT_EPI_CHAIN
 };
 
 struct EpiEmbed {
     const float* bias; const float* pos; float* x0;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
+    typedef Bias4 Col; typedef Raw4<float> Pre;
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int row, int col) const {
+        const int p = row % NP;
+        return load_raw4(pos + (size_t)(1 + p) * D + col);
+    }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& pr) const {
         const int b = row / NP, p = row - b * NP;
         const size_t o = ((size_t)b * NT + 1 + p) * D + col;
-        const float* ps = pos + (size_t)(1 + p) * D + col;
-        store4(x0 + o, a[0] + bias[col] + ps[0], a[1] + bias[col + 1] + ps[1], a[2] + bias[col + 2] + ps[2],
-               a[3] + bias[col + 3] + ps[3]);
+        float ps[4];
+        pr.get(ps);
+        store4(x0 + o, a[0] + c.b[0] + ps[0], a[1] + c.b[1] + ps[1], a[2] + c.b[2] + ps[2], a[3] + c.b[3] + ps[3]);
     }
+    DYT_EPI_CHAIN
 };
 
 // ------------------------------------------------------------------------------------------
@@ -474,12 +575,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
         constexpr int PROWS = BM / PASSES;
         static_assert(PROWS * BN * 4 <= 2 * STAGE, "epilogue staging does not fit the LDS ring");
         float* Cs = reinterpret_cast<float*>(smem);
-        constexpr int CH = BN / 4;
-        constexpr int ITERS = PROWS * CH / NTHR;
+        constexpr int CH = BN / 4;                 // 16-B chunks per tile row
+        static_assert(NTHR % CH == 0, "a lane must keep one column chunk for the whole tile");
+        constexpr int RSTEP = NTHR / CH;           // rows covered by one sweep of the workgroup
+        constexpr int ITERS = PROWS / RSTEP;
         constexpr int BATCH = ITERS % 8 == 0 ? 8 : ITERS;
+        const int ch = tid % CH, rl0 = tid / CH;
+        const int col = n0 + ch * 4;
+        const typename Epi::Col cc = epi.col_init(col);   // bias etc.: once per tile, not once per chunk
         dma_wait_all();  // nothing may still be landing in the ring when it is reused as staging
 #pragma unroll 1
         for (int p = 0; p < PASSES; ++p) {
+            // the functor's own global loads for the whole pass go out first: their latency overlaps the
+            // staging write, the barriers and the LDS read-back instead of serialising chunk by chunk
+            typename Epi::Pre pr[ITERS];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                pr[it] = epi.pre(min(m0 + p * PROWS + rl0 + it * RSTEP, Mv - 1), col);
             __syncthreads();
             if (ONE_PASS || wm == p) {
 #pragma unroll
@@ -487,31 +599,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
                     const int rl = (ONE_PASS ? wm * WM : 0) + i * 16 + frow;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const int ch = ((wn * WN + j * 16) >> 2) + (lane >> 4);
-                        *reinterpret_cast<f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2)) = acc[i][j];
+                        const int chw = ((wn * WN + j * 16) >> 2) + (lane >> 4);
+                        *reinterpret_cast<f32x4*>(Cs + rl * BN + ((chw ^ (rl & 7)) << 2)) = acc[i][j];
                     }
                 }
             }
             __syncthreads();
-            // batches of 8 chunks: all LDS reads of a batch are issued first, and the functor's own global
-            // loads (residual / z / d_act) of the batch overlap instead of serial round trips
-#pragma unroll 1
+#pragma unroll
             for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
                 f32x4 c4[BATCH];
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
-                    const int t = tid + (it0 + u) * NTHR;
-                    const int rl = t / CH, ch = t - rl * CH;
+                    const int rl = rl0 + (it0 + u) * RSTEP;
                     c4[u] = *reinterpret_cast<const f32x4*>(Cs + rl * BN + ((ch ^ (rl & 7)) << 2));
                 }
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
-                    const int t = tid + (it0 + u) * NTHR;
-                    const int rl = t / CH, ch = t - rl * CH;
-                    const int row = m0 + p * PROWS + rl;
+                    const int row = m0 + p * PROWS + rl0 + (it0 + u) * RSTEP;
                     if (row < Mv) {
                         const float v[4] = {c4[u][0], c4[u][1], c4[u][2], c4[u][3]};
-                        epi(row, n0 + ch * 4, v);
+                        epi.apply(row, col, v, cc, pr[it0 + u]);
                     }
                 }
             }
@@ -635,7 +742,9 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             return run<AT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
         case EPI_BIAS_RESID:
             return run<AT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
-        case EPI_FC1: return run<AT>(a, EpiFc1<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
+        case EPI_FC1:
+            if (a.out_at2) return run<AT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
+            return run<AT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
         case EPI_FC2: return run<AT>(a, EpiFc2<AT>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out}, s);
         case EPI_GELU_BWD: return run<AT>(a, EpiGeluBwd<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.N}, s);
         case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
@@ -651,18 +760,6 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
     return -1;
 }
 
-template <int NOUT>
-struct EpiProbe {  // measurement only
-    bf16* out; int ld; size_t plane;
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {
-        const size_t o = (size_t)row * ld + col;
-        const float g0 = gelu_fwd<bf16>(a[0]), g1 = gelu_fwd<bf16>(a[1]), g2 = gelu_fwd<bf16>(a[2]), g3 = gelu_fwd<bf16>(a[3]);
-        if (NOUT >= 1) store4(out + o, g0, g1, g2, g3);
-        if (NOUT >= 2) store4(out + plane + o, a[0], a[1], a[2], a[3]);
-        if (NOUT == 0) asm volatile("" ::"v"(g0), "v"(g1), "v"(g2), "v"(g3));
-    }
-};
-
 // measurement hook: plain bf16 GEMM into a bf16 C with a selectable kernel variant
 int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s) {
     if (K % 64 != 0 || N % 256 != 0 || M <= 0) { set_error("gemm_raw: bad shape"); return -1; }
@@ -677,17 +774,14 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 9: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, epi, s);
         case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
-        case 52: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, EpiProbe<2>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
         case 15: return launch_bf16_cfg<256, 256, 2, 4, 3>(a, epi, s);
         case 16: return launch_bf16_cfg<256, 256, 2, 4, 6>(a, epi, s);
         case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);
         case 12: return launch_bf16_cfg<128, 256, 2, 4, 0>(a, epi, s);
         case 13: return launch_bf16_cfg<256, 256, 2, 4, 1>(a, epi, s);
         case 14: return launch_bf16_cfg<256, 256, 2, 4, 2>(a, epi, s);
-        // epilogue-traffic probes (C must hold 2*M*N bf16): FC1-style epilogue with 2 / 1 / 0 output streams
-        case 20: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiProbe<2>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
-        case 21: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiProbe<1>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
-        case 22: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiProbe<0>{static_cast<bf16*>(C), N, (size_t)M * N}, s);
+        case 60: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
+        case 62: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiGeluBwd<bf16>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N}, s);
     }
     set_error("gemm_raw: unknown variant %d", variant);
     return -1;

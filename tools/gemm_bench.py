@@ -5,6 +5,8 @@ import sys
 
 import torch
 
+DBG = (9, 19, 60, 61, 62, 63, 64)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
 from _lib import check, lib, ptr, stream_ptr  # noqa: E402
@@ -19,7 +21,7 @@ def bench(M, N, K, variant, iters=20):
     for _ in range(3):
         check(lib().dyt_gemm_bf16_raw(ptr(a), ptr(w), ptr(c), M, N, K, variant, stream_ptr()))
     torch.cuda.synchronize()
-    if variant in (9, 19):
+    if variant in DBG:
         import ctypes
         check(lib().dyt_debug_counters((ctypes.c_uint64 * 4)(), 1))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,7 +31,7 @@ def bench(M, N, K, variant, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    if variant in (9, 19):
+    if variant in DBG:
         import ctypes
         buf = (ctypes.c_uint64 * 4)()
         check(lib().dyt_debug_counters(buf, 1))
