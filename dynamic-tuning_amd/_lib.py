@@ -17,13 +17,27 @@ OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0 = 1, 2, 3
 # enum dyt_param (include/dyt_hip.h)
 (P_CLS, P_POS, P_PE_W, P_PE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_PROJ_W, P_PROJ_B, P_LN2_W, P_LN2_B,
  P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_NORM_W, P_NORM_B, P_AD_DOWN_W, P_AD_DOWN_B, P_AD_UP_W, P_AD_UP_B,
- P_GATE_W, P_GATE_B, P_HEAD_W, P_HEAD_B, P_COUNT) = range(27)
+ P_GATE_W, P_GATE_B, P_HEAD_W, P_HEAD_B,
+ P_POOL_QUERY, P_POOL_NQ_W, P_POOL_NQ_B, P_POOL_NK_W, P_POOL_NK_B, P_POOL_NV_W, P_POOL_NV_B, P_POOL_Q_W, P_POOL_K_W,
+ P_POOL_V_W, P_POOL_Q_BIAS, P_POOL_V_BIAS, P_POOL_PROJ_W, P_POOL_PROJ_B, P_COUNT) = range(41)
 
 # reference state_dict key suffix -> param id  
 GLOBAL_KEYS = {
     "cls_token": P_CLS, "pos_embed": P_POS, "patch_embed.proj.weight": P_PE_W, "patch_embed.proj.bias": P_PE_B,
     "norm.weight": P_NORM_W, "norm.bias": P_NORM_B, "head.weight": P_HEAD_W, "head.bias": P_HEAD_B,
 }
+# video model only: the attentive pooling head (video_models/video_vision_transformer_IN21K.py:407-410)
+POOL_KEYS = {
+    "query_token": P_POOL_QUERY,
+    "attentive_blocks.norm_q.weight": P_POOL_NQ_W, "attentive_blocks.norm_q.bias": P_POOL_NQ_B,
+    "attentive_blocks.norm_k.weight": P_POOL_NK_W, "attentive_blocks.norm_k.bias": P_POOL_NK_B,
+    "attentive_blocks.norm_v.weight": P_POOL_NV_W, "attentive_blocks.norm_v.bias": P_POOL_NV_B,
+    "attentive_blocks.cross_attn.q.weight": P_POOL_Q_W, "attentive_blocks.cross_attn.k.weight": P_POOL_K_W,
+    "attentive_blocks.cross_attn.v.weight": P_POOL_V_W, "attentive_blocks.cross_attn.q_bias": P_POOL_Q_BIAS,
+    "attentive_blocks.cross_attn.v_bias": P_POOL_V_BIAS, "attentive_blocks.cross_attn.proj.weight": P_POOL_PROJ_W,
+    "attentive_blocks.cross_attn.proj.bias": P_POOL_PROJ_B,
+}
+GLOBAL_KEYS.update(POOL_KEYS)
 BLOCK_KEYS = {
     "norm1.weight": P_LN1_W, "norm1.bias": P_LN1_B, "attn.qkv.weight": P_QKV_W, "attn.qkv.bias": P_QKV_B,
     "attn.proj.weight": P_PROJ_W, "attn.proj.bias": P_PROJ_B, "norm2.weight": P_LN2_W, "norm2.bias": P_LN2_B,
@@ -53,7 +67,7 @@ class Config(ctypes.Structure):
     _fields_ = [("num_classes", ctypes.c_int32), ("ffn_num", ctypes.c_int32), ("depth", ctypes.c_int32),
                 ("precision", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("slots", ctypes.c_int32),
                 ("adapter_scale", ctypes.c_float), ("adapter_dropout", ctypes.c_float), ("tau", ctypes.c_float),
-                ("threshold", ctypes.c_float)]
+                ("threshold", ctypes.c_float), ("frames", ctypes.c_int32)]
 
 
 class DyTError(RuntimeError):

@@ -206,6 +206,18 @@ struct EpiStoreAT {
 };
 
 template <class AT>
+struct EpiBiasAT {
+    const float* bias; AT* out; int ld;
+    typedef Bias4 Col; typedef NoCtx Pre;
+    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre&) const {
+        store4(out + (size_t)row * ld + col, a[0] + c.b[0], a[1] + c.b[1], a[2] + c.b[2], a[3] + c.b[3]);
+    }
+    DYT_EPI_CHAIN
+};
+
+template <class AT>
 struct EpiAdDown {
     const float* bias;  // padded to RP
     AT* out;            // [M, RP]
@@ -755,6 +767,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_AD_DGRAD_UP:
             return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
         case EPI_EMBED: return run<AT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
+        case EPI_BIAS_AT: return run<AT>(a, EpiBiasAT<AT>{a.bias, (AT*)a.out_at, a.N}, s);
     }
     set_error("gemm: unknown epilogue %d", (int)kind);
     return -1;
@@ -781,6 +794,8 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 13: return launch_bf16_cfg<256, 256, 2, 4, 1>(a, epi, s);
         case 14: return launch_bf16_cfg<256, 256, 2, 4, 2>(a, epi, s);
         case 60: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
+        case 65: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
+        case 66: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiGeluBwd<bf16>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N}, s);
         case 62: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiGeluBwd<bf16>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N}, s);
     }
     set_error("gemm_raw: unknown variant %d", variant);

@@ -22,6 +22,7 @@ enum EpiKind {
     EPI_AD_UP,          // out_f32 = resid + scale*(acc + bias)                     (Adapter.up_proj * scale + residual)
     EPI_AD_DGRAD_UP,    // out_at = acc * scale * relu'/dropout mask                (dgrad through up_proj)
     EPI_EMBED,          // x0[b*197+1+p] = acc + bias + pos[1+p]                    (PatchEmbed + pos_embed)
+    EPI_BIAS_AT,        // out_at = acc + bias (bias may be null)                    (video pooling head k / v projections)
 };
 
 struct GemmArgs {
@@ -132,6 +133,7 @@ struct LossArgs {
     const float* logits_s; const float* logits_t; const int64_t* targets;
     const int* counts;      // [depth*B] kept tokens per (layer,image) incl. cls, student pass
     int batch, C, depth;
+    int count_batch = 0;    // images the kept-token counts span (video: frames = batch * t); 0 = batch
     float target_ratio, loss_ratio, token_minimal, token_minimal_weight;
     float* dlogits_s; float* dlogits_t; float* out_losses; float* dtok;
     float* scratch = nullptr;   // [4*B] per-image partial terms
@@ -202,6 +204,30 @@ int launch_colsum64(int precision, const void* Y, int M, int r, float* out, floa
 
 int launch_fill_f32(float* p, float v, int64_t n, hipStream_t s);
 int launch_iota(int* p, int n, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// video model: attentive pooling head (pool.hip)
+// ------------------------------------------------------------------------------------------
+int launch_pool_ln_fwd(int precision, const float* x, const float* nw, const float* nb, const float* kw, const float* kb,
+                       const float* vw, const float* vb, float* xf, float2* st_f, float2* st_kv, void* xk, void* xv,
+                       int rows, hipStream_t s);
+int launch_pool_q_fwd(const float* query, const float* nqw, const float* nqb, const float* Wq, const float* qbias, float* qn,
+                      float* qhat, float* st_q, float* qs, hipStream_t s);
+int launch_pool_attn_fwd(int precision, const float* qs, const void* K, const void* V, float* P, float* o, int clips,
+                         int NK, hipStream_t s);
+int launch_pool_attn_bwd(int precision, const float* qs, const void* K, const void* V, const float* P, const float* dO,
+                         void* dK, void* dV, float* dq_part, int clips, int NK, hipStream_t s);
+int launch_pool_q_bwd(const float* dq_part, int clips, const float* qn, const float* qhat, const float* st_q, const float* Wq,
+                      const float* nqw, float* gq, float* dWq, float* dqb, float* dnqw, float* dnqb, float* dquery,
+                      hipStream_t s);
+int launch_rows_linear(const float* x, const float* W, const float* bias, float* out, int R, int N, int K, hipStream_t s);
+int launch_rows_linear_bwd(const float* dout, const float* x, const float* W, float* dx, float* dW, float* db, int R, int N,
+                           int K, hipStream_t s);
+int launch_transpose_rows(int precision, const void* src, void* dst, int rows, int rows_pad, float* colsum_part,
+                          hipStream_t s);
+int launch_pool_ln_bwd(int precision, const void* dxk, const void* dxv, const float* xf, const float2* st_kv, const float* kw,
+                       const float* vw, const float* x, const float2* st_f, const float* nw, float* g, float* partial,
+                       int rows, int* nblocks_out, hipStream_t s);
 
 inline size_t at_size(int precision) { return precision == 0 ? 4 : 2; }
 

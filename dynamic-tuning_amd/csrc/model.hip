@@ -104,8 +104,15 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
     void *xn, *h1, *g_at, *dH, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn;
     float *g, *delta, *dmask, *tok_partial, *wg_partial;
 };
+struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
+    float *xf = nullptr, *P = nullptr, *o = nullptr, *y = nullptr, *qn = nullptr, *qhat = nullptr, *qs = nullptr, *st_q = nullptr;
+    float *dq_part = nullptr, *gq = nullptr, *dy = nullptr, *dO = nullptr;
+    float2 *st_f = nullptr, *st_kv = nullptr;
+    void *xk = nullptr, *xv = nullptr, *Kp = nullptr, *Vp = nullptr;
+};
 struct Slot {
     Transients T;
+    PoolS pool;
     hipStream_t branch = nullptr;        // side stream for the adapter branch of this pass
     float* u0_own = nullptr; void* u0_at_own = nullptr;  // block-0 buffers (slot 1 may alias slot 0's, see step)
     hipEvent_t ev_f = nullptr, ev_j = nullptr;
@@ -137,6 +144,11 @@ struct dyt_ctx {
     float* ad_down_b;
     // trainable flat layout
     int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
+    // video model (frames > 1): attentive pooling head, trainable
+    int frames = 1;
+    int64_t off_pquery = 0, off_pnq_w = 0, off_pnq_b = 0, off_pnk_w = 0, off_pnk_b = 0, off_pnv_w = 0, off_pnv_b = 0,
+            off_pq_w = 0, off_pk_w = 0, off_pv_w = 0, off_pq_bias = 0, off_pv_bias = 0, off_pproj_w = 0, off_pproj_b = 0;
+    void *pk_w = nullptr, *pk_wT = nullptr, *pv_w = nullptr, *pv_wT = nullptr;   // per-step AT copies of k / v weights
     std::vector<Slot> slots;
     float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses, *grad2, *loss_part;
     int* cls_rows = nullptr;   // [max_batch] token row of each image's cls token (b*197)
@@ -222,6 +234,24 @@ static void layout(dyt_ctx* c, bool dry) {
             L.total = carve<int>(c, 4, dry); L.row_src = carve<int>(c, M, dry); L.dst_of = carve<int>(c, M, dry);
         }
     }
+    if (c->frames > 1) {
+        c->pk_w = carve_at(c, (size_t)D * D, dry); c->pk_wT = carve_at(c, (size_t)D * D, dry);
+        c->pv_w = carve_at(c, (size_t)D * D, dry); c->pv_wT = carve_at(c, (size_t)D * D, dry);
+        const size_t clips = B / c->frames;
+        for (int sl = 0; sl < cf.slots; ++sl) {
+            PoolS& Q = c->slots[sl].pool;
+            Q.xf = carve<float>(c, M * D, dry);
+            Q.st_f = carve<float2>(c, M, dry); Q.st_kv = carve<float2>(c, M, dry);
+            Q.xk = carve_at(c, M * D, dry); Q.xv = carve_at(c, M * D, dry);
+            Q.Kp = carve_at(c, M * D, dry); Q.Vp = carve_at(c, M * D, dry);
+            Q.P = carve<float>(c, B * NH * NT, dry);
+            Q.o = carve<float>(c, clips * D, dry); Q.y = carve<float>(c, clips * D, dry);
+            Q.dy = carve<float>(c, clips * D, dry); Q.dO = carve<float>(c, clips * D, dry);
+            Q.dq_part = carve<float>(c, clips * D, dry);
+            Q.qn = carve<float>(c, D, dry); Q.qhat = carve<float>(c, D, dry); Q.qs = carve<float>(c, D, dry);
+            Q.gq = carve<float>(c, D, dry); Q.st_q = carve<float>(c, 4, dry);
+        }
+    }
     for (int sl = 0; sl < cf.slots; ++sl) {
         Transients& T = c->slots[sl].T;
         T.xn = carve_at(c, M * D, dry);
@@ -264,6 +294,18 @@ static void trainable_layout(dyt_ctx* c) {
     o = c->layer_stride * c->cfg.depth;
     c->off_hw = o; o = a4(o + C * D);
     c->off_hb = o; o = a4(o + C);
+    if (c->frames > 1) {
+        c->off_pquery = o; o += D;
+        c->off_pnq_w = o; o += D; c->off_pnq_b = o; o += D;
+        c->off_pnk_w = o; o += D; c->off_pnk_b = o; o += D;   // norm_k / norm_v {w,b} stay adjacent:
+        c->off_pnv_w = o; o += D; c->off_pnv_b = o; o += D;   // one 4x768 partial reduction covers them
+        c->off_pq_w = o; o += (int64_t)D * D;
+        c->off_pk_w = o; o += (int64_t)D * D;
+        c->off_pv_w = o; o += (int64_t)D * D;
+        c->off_pq_bias = o; o += D; c->off_pv_bias = o; o += D;
+        c->off_pproj_w = o; o += (int64_t)D * D;
+        c->off_pproj_b = o; o += D;
+    }
     c->n_train = o;
 }
 
@@ -282,9 +324,15 @@ extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
     int ndev = 0;
     DYT_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (ndev < 1) { set_error("no HIP device"); return DYT_ERR_HIP; }
+    if (cfg->frames > 1 && (cfg->max_batch % cfg->frames != 0 || cfg->frames * NT * 2 * sizeof(float) > 60 * 1024)) {
+        set_error("video model: max_batch %d must be a multiple of frames %d (and frames <= 38)", cfg->max_batch, cfg->frames);
+        return DYT_ERR_ARG;
+    }
     dyt_ctx* c = new dyt_ctx();
     c->cfg = *cfg;
     c->prec = cfg->precision;
+    c->frames = cfg->frames > 1 ? cfg->frames : 1;
+    if (c->frames > 1) c->cls_tail = false;   // every token of the last block reaches the pooling head
     c->at = at_size(c->prec);
     trainable_layout(c);
     layout(c, true);
@@ -353,6 +401,18 @@ extern "C" int dyt_trainable_offset(const dyt_ctx* c, int param, int layer, int6
         case DYT_P_GATE_B: *off = base + c->off_gb; *numel = 1; break;
         case DYT_P_HEAD_W: *off = c->off_hw; *numel = C * D; break;
         case DYT_P_HEAD_B: *off = c->off_hb; *numel = C; break;
+        case DYT_P_POOL_QUERY: case DYT_P_POOL_NQ_W: case DYT_P_POOL_NQ_B: case DYT_P_POOL_NK_W: case DYT_P_POOL_NK_B:
+        case DYT_P_POOL_NV_W: case DYT_P_POOL_NV_B: case DYT_P_POOL_Q_W: case DYT_P_POOL_K_W: case DYT_P_POOL_V_W:
+        case DYT_P_POOL_Q_BIAS: case DYT_P_POOL_V_BIAS: case DYT_P_POOL_PROJ_W: case DYT_P_POOL_PROJ_B: {
+            if (c->frames <= 1) { set_error("param %d exists in the video model only (cfg.frames > 1)", param); return DYT_ERR_ARG; }
+            const int64_t offs[] = {c->off_pquery, c->off_pnq_w, c->off_pnq_b, c->off_pnk_w, c->off_pnk_b, c->off_pnv_w,
+                                    c->off_pnv_b, c->off_pq_w, c->off_pk_w, c->off_pv_w, c->off_pq_bias, c->off_pv_bias,
+                                    c->off_pproj_w, c->off_pproj_b};
+            *off = offs[param - DYT_P_POOL_QUERY];
+            const bool mat = param == DYT_P_POOL_Q_W || param == DYT_P_POOL_K_W || param == DYT_P_POOL_V_W || param == DYT_P_POOL_PROJ_W;
+            *numel = mat ? (int64_t)D * D : D;
+            break;
+        }
         default: set_error("param %d is not trainable", param); return DYT_ERR_ARG;
     }
     return DYT_OK;
@@ -439,7 +499,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
     switch (option) {
         case DYT_OPT_STREAM_OVERLAP: c->overlap = value != 0; return DYT_OK;
-        case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0; for (auto& S : c->slots) S.valid = false; return DYT_OK;
+        case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0 && c->frames <= 1; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
     }
     set_error("unknown option %d", option);
@@ -518,6 +578,84 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
 
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 
+// ------------------------------------------------------------------------------------------
+// video model: attentive pooling head (video_models/video_vision_transformer_IN21K.py:463-483)
+// ------------------------------------------------------------------------------------------
+static int prep_pool(dyt_ctx* c, const float* tr, hipStream_t s) {
+    if (c->frames <= 1) return 0;
+    int rc = set_matrix(c, tr + c->off_pk_w, c->pk_w, c->pk_wT, D, D, s);
+    if (rc) return rc;
+    return set_matrix(c, tr + c->off_pv_w, c->pv_w, c->pv_wT, D, D, s);
+}
+
+static int pool_forward(dyt_ctx* c, Slot& S, const float* tr, float* logits, int B, hipStream_t s) {
+    const int P = c->prec, t = c->frames, clips = B / t, M = B * NT, NK = t * NT, C = c->cfg.num_classes;
+    PoolS& Q = S.pool;
+    RUN(2, 0, launch_pool_ln_fwd(P, S.xs[c->cfg.depth], c->norm_w, c->norm_b, tr + c->off_pnk_w, tr + c->off_pnk_b,
+                                 tr + c->off_pnv_w, tr + c->off_pnv_b, Q.xf, Q.st_f, Q.st_kv, Q.xk, Q.xv, M, s));
+    {
+        GemmArgs a; a.A = Q.xk; a.W = c->pk_w; a.M = M; a.N = D; a.K = D; a.out_at = Q.Kp;   // k has no bias
+        RUN_GEMM(EPI_BIAS_AT, a);
+    }
+    {
+        GemmArgs a; a.A = Q.xv; a.W = c->pv_w; a.M = M; a.N = D; a.K = D; a.bias = tr + c->off_pv_bias; a.out_at = Q.Vp;
+        RUN_GEMM(EPI_BIAS_AT, a);
+    }
+    RUN(2, 0, launch_pool_q_fwd(tr + c->off_pquery, tr + c->off_pnq_w, tr + c->off_pnq_b, tr + c->off_pq_w,
+                                tr + c->off_pq_bias, Q.qn, Q.qhat, Q.st_q, Q.qs, s));
+    RUN(1, 4.0 * clips * NH * (double)NK * HD, launch_pool_attn_fwd(P, Q.qs, Q.Kp, Q.Vp, Q.P, Q.o, clips, NK, s));
+    RUN(2, 0, launch_rows_linear(Q.o, tr + c->off_pproj_w, tr + c->off_pproj_b, Q.y, clips, D, D, s));
+    RUN(2, 0, launch_rows_linear(Q.y, tr + c->off_hw, tr + c->off_hb, logits, clips, C, D, s));
+    return 0;
+}
+
+// dlogits [clips, C] -> pooling-head weight gradients (accumulated into grad) and T.g = dL/d x_last [M,768]
+static int pool_backward(dyt_ctx* c, Slot& S, const float* tr, const float* dlogits, float* grad, hipStream_t s) {
+    const int P = c->prec, t = c->frames, B = S.batch, clips = B / t, M = B * NT, NK = t * NT, C = c->cfg.num_classes;
+    const int Mp = (M + 63) / 64 * 64;
+    PoolS& Q = S.pool;
+    Transients& T = S.T;
+    RUN(2, 0, launch_rows_linear_bwd(dlogits, Q.y, tr + c->off_hw, Q.dy, grad + c->off_hw, grad + c->off_hb, clips, C, D, s));
+    RUN(2, 0, launch_rows_linear_bwd(Q.dy, Q.o, tr + c->off_pproj_w, Q.dO, grad + c->off_pproj_w, grad + c->off_pproj_b,
+                                     clips, D, D, s));
+    void* dK = T.dO; void* dV = T.dxn;   // [M,768] AT transients, free until the trunk backward starts
+    RUN(1, 8.0 * clips * NH * (double)NK * HD,
+        launch_pool_attn_bwd(P, Q.qs, Q.Kp, Q.Vp, Q.P, Q.dO, dK, dV, Q.dq_part, clips, NK, s));
+    RUN(2, 0, launch_pool_q_bwd(Q.dq_part, clips, Q.qn, Q.qhat, Q.st_q, tr + c->off_pq_w, tr + c->off_pnq_w, Q.gq,
+                                grad + c->off_pq_w, grad + c->off_pq_bias, grad + c->off_pnq_w, grad + c->off_pnq_b,
+                                grad + c->off_pquery, s));
+    // weight gradients of k / v: dW = dK^T xk over the token rows -- operands transposed to K-contiguous, NT GEMM
+    void* dKt = T.h1; void* xkt = at_off(c, T.h1, (size_t)Mp * D);
+    void* dVt = T.dZ; void* xvt = at_off(c, T.dZ, (size_t)Mp * D);
+    RUN(2, 0, launch_transpose_rows(P, dK, dKt, M, Mp, nullptr, s));
+    RUN(2, 0, launch_transpose_rows(P, Q.xk, xkt, M, Mp, nullptr, s));
+    RUN(2, 0, launch_transpose_rows(P, dV, dVt, M, Mp, T.tok_partial, s));   // + column sums of dV -> v_bias
+    RUN(2, 0, launch_transpose_rows(P, Q.xv, xvt, M, Mp, nullptr, s));
+    {
+        GemmArgs a; a.A = dKt; a.W = xkt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pk_w; a.accumulate = 1;
+        RUN_GEMM(EPI_STORE_F32, a);
+    }
+    {
+        GemmArgs a; a.A = dVt; a.W = xvt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pv_w; a.accumulate = 1;
+        RUN_GEMM(EPI_STORE_F32, a);
+    }
+    RUN(2, 0, launch_reduce_partials(T.tok_partial, Mp / 64, D, grad + c->off_pv_bias, D, 1.0f, s));
+    // dgrads through k / v, then norm_k + norm_v + final norm backward in one row pass
+    {
+        GemmArgs a; a.A = dK; a.W = c->pk_wT; a.M = M; a.N = D; a.K = D; a.out_at = T.du_at;
+        RUN_GEMM(EPI_STORE_AT, a);
+    }
+    {
+        GemmArgs a; a.A = dV; a.W = c->pv_wT; a.M = M; a.N = D; a.K = D; a.out_at = T.dA2;
+        RUN_GEMM(EPI_STORE_AT, a);
+    }
+    int nblk = 0;
+    RUN(2, 0, launch_pool_ln_bwd(P, T.du_at, T.dA2, Q.xf, Q.st_kv, tr + c->off_pnk_w, tr + c->off_pnv_w, S.xs[c->cfg.depth],
+                                 Q.st_f, c->norm_w, T.g, T.wg_partial, M, &nblk, s));
+    RUN(2, 0, launch_reduce_partials(T.wg_partial, nblk, 4 * D, grad + c->off_pnk_w, 4 * D, 1.0f, s));
+    return 0;
+}
+
 static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int flags, const float* trainable,
                         const float* g1, const float* g2, const uint8_t* keep_mask, uint64_t seed, float* logits,
                         float* token_select, float* token_logits, bool do_prep, hipStream_t s,
@@ -537,7 +675,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     Slot& S = c->slots[slot];
     Transients& T = S.T;
     S.valid = false;
-    if (do_prep) { int rc = prep_adapters(c, trainable, s); if (rc) return rc; }
+    if (B % c->frames != 0) { set_error("video model: batch %d is not a multiple of frames %d", B, c->frames); return DYT_ERR_ARG; }
+    if (do_prep) { int rc = prep_adapters(c, trainable, s); if (rc) return rc; rc = prep_pool(c, trainable, s); if (rc) return rc; }
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
@@ -637,8 +776,13 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN_GEMM(EPI_FC2, a);
         }
     }
-    RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
-                              S.head_stats, logits, B, c->cfg.num_classes, s));
+    if (c->frames > 1) {
+        int rc = pool_forward(c, S, trainable, logits, B, s);
+        if (rc) return rc;
+    } else {
+        RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
+                                  S.head_stats, logits, B, c->cfg.num_classes, s));
+    }
     S.batch = B; S.flags = flags; S.valid = save; S.trainable = trainable;
     return DYT_OK;
 }
@@ -679,9 +823,14 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
     const bool cls_tail = c->cls_tail;
-    RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw,
-                              cls_tail ? S.gcls : g, grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes,
-                              cls_tail ? 1 : 0, s));
+    if (c->frames > 1) {
+        int rc = pool_backward(c, S, trainable, dlogits, grad, s);
+        if (rc) return rc;
+    } else {
+        RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw,
+                                  cls_tail ? S.gcls : g, grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes,
+                                  cls_tail ? 1 : 0, s));
+    }
 
     bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
     for (int l = depth - 1; l >= 0; --l) {
@@ -807,11 +956,12 @@ extern "C" int dyt_loss(dyt_ctx* c, int slot_student, const float* logits_s, con
     LossArgs a;
     a.logits_s = logits_s; a.logits_t = logits_t; a.targets = targets; a.counts = c->slots[slot_student].counts;
     a.batch = batch; a.C = c->cfg.num_classes; a.depth = c->cfg.depth;
+    a.count_batch = batch * c->frames;   // video: `batch` clips, the gates were evaluated on batch * t frames
     a.target_ratio = token_target_ratio; a.loss_ratio = token_loss_ratio; a.token_minimal = token_minimal;
     a.token_minimal_weight = token_minimal_weight;
     a.dlogits_s = dlogits_s; a.dlogits_t = dlogits_t; a.out_losses = out_losses; a.dtok = dtok;
     a.scratch = c->loss_part;
-    if (batch > c->cfg.max_batch) { set_error("batch %d exceeds max_batch", batch); return DYT_ERR_ARG; }
+    if (batch * c->frames > c->cfg.max_batch) { set_error("batch %d exceeds max_batch", batch); return DYT_ERR_ARG; }
     return launch_loss(a, s);
 }
 
@@ -847,7 +997,10 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
     hipStream_t s2 = par ? c->side : s;
+    if (batch % c->frames != 0) { set_error("video model: batch %d is not a multiple of frames %d", batch, c->frames); return DYT_ERR_ARG; }
     int rc = prep_adapters(c, trainable, s);
+    if (rc) return rc;
+    rc = prep_pool(c, trainable, s);
     if (rc) return rc;
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
     // The two passes see the same images and the same frozen weights, and nothing trainable or random sits
@@ -870,7 +1023,7 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
                       share ? &c->slots[0] : nullptr, nullptr, (share && par) ? c->ev_b0 : nullptr);
     if (rc) return rc;
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_join, s2)); DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0)); }
-    rc = dyt_loss(c, 0, ls, lt, targets, batch, token_target_ratio, token_loss_ratio, token_minimal, token_minimal_weight,
+    rc = dyt_loss(c, 0, ls, lt, targets, batch / c->frames, token_target_ratio, token_loss_ratio, token_minimal, token_minimal_weight,
                   c->dl_s, c->dl_t, out_losses, c->dtok, stream);
     if (rc) return rc;
     float* gt = par ? c->grad2 : grad_flat;  // teacher-pass gradients

@@ -11,59 +11,11 @@
 //   CE + KL + AdaLoss                           engine_finetune.py:52-63, models/losses.py:48-84
 //   torch.optim.AdamW                           main_image.py:285
 #include "kernels.h"
+#include "rowhelp.h"
 
 namespace dyt {
 
 #define LAUNCH_CHECK() DYT_HIP_CHECK(hipGetLastError())
-
-// a wave's view of one 768-float row: lane holds cols {lane*4 + 256*i + e}
-struct Row12 {
-    float v[12];
-    __device__ __forceinline__ void load(const float* p, int lane) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(p + i * 256 + lane * 4);
-            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-        }
-    }
-    template <class T>
-    __device__ __forceinline__ void load_at(const T* p, int lane) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float t[4];
-            load4(p + i * 256 + lane * 4, t);
-            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
-        }
-    }
-    template <class T>
-    __device__ __forceinline__ void store(T* p, int lane) const {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) store4(p + i * 256 + lane * 4, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-    }
-    __device__ __forceinline__ float sum() const {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s += v[i];
-        return wave_sum(s);
-    }
-};
-
-__device__ __forceinline__ float dot12(const Row12& a, const Row12& b) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) s = fmaf(a.v[i], b.v[i], s);
-    return wave_sum(s);
-}
-
-// normalise a row held in registers; returns (mean, rstd)
-__device__ __forceinline__ float2 ln_stats(const Row12& x) {
-    const float mean = x.sum() * (1.0f / D);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { const float d = x.v[i] - mean; s = fmaf(d, d, s); }
-    const float var = wave_sum(s) * (1.0f / D);
-    return make_float2(mean, 1.0f / sqrtf(var + LN_EPS));
-}
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm forward / backward
@@ -84,23 +36,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - st.x) * st.y * wr.v[i] + br.v[i];
     xr.store(out + (size_t)row * D, lane);
     if (stats && lane == 0) stats[row] = st;
-}
-
-__device__ __forceinline__ void ln_bwd_row(Row12& dy, const Row12& x, const Row12& w, float2 st) {
-    // in: dy = dL/d(LN out); out: dy = dL/dx
-    float s1 = 0.f, s2 = 0.f;
-    Row12 xh;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        xh.v[i] = (x.v[i] - st.x) * st.y;
-        dy.v[i] *= w.v[i];
-        s1 += dy.v[i];
-        s2 = fmaf(dy.v[i], xh.v[i], s2);
-    }
-    s1 = wave_sum(s1) * (1.0f / D);
-    s2 = wave_sum(s2) * (1.0f / D);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) dy.v[i] = st.y * (dy.v[i] - s1 - xh.v[i] * s2);
 }
 
 // dx = base + LNbwd(dy).  Optionally also does the NEXT (lower) block's backward prep on the row it just
@@ -422,14 +357,6 @@ int launch_pad_convert(int precision, const float* src, void* dst, int rows, int
 // ------------------------------------------------------------------------------------------
 // head: final LayerNorm on the cls rows + Linear(768, C)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum256(float v, float* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
-
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nw,
                                                        const float* __restrict__ nb, const float* __restrict__ hw,
                                                        const float* __restrict__ hb, float* __restrict__ cls_n,
@@ -568,8 +495,9 @@ __global__ __launch_bounds__(256) void loss_final_kernel(LossArgs a, const float
     const int B = a.batch;
     float ce_s = 0.f, ce_t = 0.f, kl = 0.f, kept = 0.f;
     for (int b = tid; b < B; b += 256) { ce_s += part[b * 4]; ce_t += part[b * 4 + 1]; kl += part[b * 4 + 2]; }
+    const int Bc = a.count_batch > 0 ? a.count_batch : B;   // images the gate statistics span
     if (a.counts)
-        for (int i = tid; i < a.depth * B; i += 256) kept += (float)(a.counts[i] - 1);
+        for (int i = tid; i < a.depth * Bc; i += 256) kept += (float)(a.counts[i] - 1);
     ce_s = wave_sum(ce_s); ce_t = wave_sum(ce_t); kl = wave_sum(kl); kept = wave_sum(kept);
     if (lane == 0) { red[wave][0] = ce_s; red[wave][1] = ce_t; red[wave][2] = kl; red[wave][3] = kept; }
     __syncthreads();
@@ -582,7 +510,7 @@ __global__ __launch_bounds__(256) void loss_final_kernel(LossArgs a, const float
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
         if (a.counts) {
             keptv = red[0][3] + red[1][3] + red[2][3] + red[3][3];
-            const float N = (float)a.depth * B * NP;
+            const float N = (float)a.depth * Bc * NP;
             mean = keptv / N;
             const float diff = mean - a.target_ratio;
             tok = diff * diff;

@@ -70,6 +70,7 @@ def train_step(model, samples, targets, optimizer, criterion=None, losses_out=No
     """One fused step (reference engine_finetune.py:47-79) on device tensors; returns the device
     tensor of loss components [loss, base, token, teacher, distillation, keep ratio, kept, 0]."""
     m = getattr(model, "module", model)
+    samples = m.fold_input(samples.float()).contiguous()   # video: [b,c,t,h,w] -> [(b t),c,h,w]
     eng = m.engine(samples.shape[0], samples.device)
     tr = criterion.token_target_ratio if target_ratio is None else target_ratio
     ratio = criterion.token_loss_ratio if criterion is not None else 2.0
@@ -135,6 +136,14 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         for i, k in enumerate(LOSS_KEYS):
             stats[k] = float(t[i]) / dist.get_world_size()
     return stats
+
+
+def train_video_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
+                          mixup_fn=None, log_writer=None, args=None, logger=None):
+    """Reference engine_finetune.py:109-203: the video loop is the image loop with clip tensors
+    [b,c,t,h,w]; the model folds the frames into the batch and pools them per clip."""
+    return train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler, max_norm, mixup_fn,
+                           log_writer, args, logger)
 
 
 def all_gather_concat(tensor):

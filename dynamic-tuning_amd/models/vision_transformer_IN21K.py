@@ -117,7 +117,7 @@ class _DyTFunction(torch.autograd.Function):
         eng = model._engine
         gbuf = torch.zeros_like(eng.flat)
         if dlogits is None:
-            dlogits = torch.zeros(ctx.batch, eng.num_classes, device=eng.device)
+            dlogits = torch.zeros(ctx.batch // eng.frames, eng.num_classes, device=eng.device)
         eng.backward(ctx.slot, dlogits.float().contiguous(), gbuf,
                      dtoken_select=None if dts is None else dts.float().contiguous(),
                      dtoken_logits=None if dtl is None else dtl.float().contiguous())
@@ -177,6 +177,11 @@ class VisionTransformer(nn.Module):
         self._engine = None
         self._sync_state = None
         self._seed_counter = 0
+        self._frames = 1   # > 1 in the video subclass (video_models/video_vision_transformer_IN21K.py)
+
+    def fold_input(self, x):
+        """Image model: the batch is the input itself (the video subclass folds clips into frames here)."""
+        return x
 
     def init_weights(self, m):  # reference :323-332
         if isinstance(m, _LinearParams):
@@ -201,15 +206,17 @@ class VisionTransformer(nn.Module):
     def engine(self, batch, device):
         """Create (or grow) the libdyt_hip context and (re)upload parameters that changed."""
         eng = self._engine
-        if eng is None or eng.device != device or batch > eng.cfg.max_batch:
+        if eng is None or eng.device != device or batch > eng.cfg.max_batch or eng.frames != (self._frames or 1):
             mb = max(batch, self.max_batch or 0)
+            if self._frames and self._frames > 1:
+                mb = -(-mb // self._frames) * self._frames   # whole clips
             old = self._engine
             self._engine = None
             del old
             eng = DyTEngine(self.num_classes, self.tuning_config.ffn_num, self.blocks[0].adaptmlp.scale, device,
                             precision=self.precision, max_batch=mb, depth=self.depth,
                             adapter_dropout=self.blocks[0].adaptmlp.dropout, tau=self.blocks[0].mlp_token_select.tau,
-                            threshold=self.blocks[0].mlp_token_select.threshold)
+                            threshold=self.blocks[0].mlp_token_select.threshold, frames=self._frames or 1)
             self._engine = eng
             self._sync_state = None
         self._sync(eng)
@@ -244,7 +251,7 @@ class VisionTransformer(nn.Module):
         stream seeded from torch's seed and a per-model call counter."""
         if not x.is_cuda:
             raise DyTError("DyT VisionTransformer runs on a HIP device only (input is on %s); there is no CPU path" % x.device)
-        x = x.float().contiguous()
+        x = self.fold_input(x.float()).contiguous()
         eng = self.engine(x.shape[0], x.device)
         g1 = g2 = None
         if gumbel is not None:

@@ -28,12 +28,14 @@ def parse_precision(p):
 
 class DyTEngine:
     def __init__(self, num_classes, ffn_num, adapter_scale, device, precision=PREC_BF16, max_batch=128, depth=12,
-                 slots=2, adapter_dropout=0.1, tau=5.0, threshold=0.5):
+                 slots=2, adapter_dropout=0.1, tau=5.0, threshold=0.5, frames=1):
         if torch.device(device).type != "cuda":
             raise DyTError("the DyT path runs on a HIP device only (got %s); there is no CPU path" % (device,))
         self.device = torch.device(device)
         self.cfg = Config(int(num_classes), int(ffn_num), int(depth), parse_precision(precision), int(max_batch),
-                          int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold))
+                          int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
+                          int(frames))
+        self.frames = max(1, int(frames))   # > 1: video model, every batch is clips * frames images
         self.L = lib()
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -98,7 +100,7 @@ class DyTEngine:
         B = images.shape[0]
         flags = ((F_TRAINING if training else 0) | (F_COMPLETE if complete_model else 0) | (F_SAVE if save else 0) |
                  (F_MASKED_DENSE if masked_dense else 0) | (F_GATE_ALWAYS if gate_always else 0))
-        logits = torch.empty(B, self.num_classes, device=self.device, dtype=torch.float32)
+        logits = torch.empty(B // self.frames, self.num_classes, device=self.device, dtype=torch.float32)
         has_tok = want_tokens and (not complete_model or gate_always)
         ts = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32) if has_tok else None
         tl = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32) if has_tok else None

@@ -24,8 +24,20 @@ NUM_PATCHES = 196
 NUM_TOKENS = 197
 
 
-def param_shapes(num_classes=100, ffn_num=64, depth=DEPTH):
-    """Ordered ``name -> shape`` for the reference model's ``state_dict()``."""
+POOL_SHAPES = {  # video model only (video_models/video_vision_transformer_IN21K.py:27-75,407-410)
+    "query_token": (1, 1, DIM),
+    "attentive_blocks.norm_q.weight": (DIM,), "attentive_blocks.norm_q.bias": (DIM,),
+    "attentive_blocks.norm_k.weight": (DIM,), "attentive_blocks.norm_k.bias": (DIM,),
+    "attentive_blocks.norm_v.weight": (DIM,), "attentive_blocks.norm_v.bias": (DIM,),
+    "attentive_blocks.cross_attn.q_bias": (DIM,), "attentive_blocks.cross_attn.v_bias": (DIM,),
+    "attentive_blocks.cross_attn.q.weight": (DIM, DIM), "attentive_blocks.cross_attn.k.weight": (DIM, DIM),
+    "attentive_blocks.cross_attn.v.weight": (DIM, DIM),
+    "attentive_blocks.cross_attn.proj.weight": (DIM, DIM), "attentive_blocks.cross_attn.proj.bias": (DIM,),
+}
+
+
+def param_shapes(num_classes=100, ffn_num=64, depth=DEPTH, video=False):
+    """Ordered ``name -> shape`` for the reference model's ``state_dict()`` (video=True: the video model's)."""
     shapes = {
         "cls_token": (1, 1, DIM),
         "pos_embed": (1, NUM_TOKENS, DIM),
@@ -56,12 +68,15 @@ def param_shapes(num_classes=100, ffn_num=64, depth=DEPTH):
     shapes["norm.bias"] = (DIM,)
     shapes["head.weight"] = (num_classes, DIM)
     shapes["head.bias"] = (num_classes,)
+    if video:
+        shapes.update(POOL_SHAPES)
     return shapes
 
 
 def is_trainable(name):
     """Freeze rule of ``main_image.py:250-256``: adapters, gates and the head train."""
-    return ("adaptmlp." in name) or ("mlp_token_select." in name) or name.startswith("head.")
+    return (("adaptmlp." in name) or ("mlp_token_select." in name) or name.startswith("head.") or
+            name == "query_token" or name.startswith("attentive_blocks."))   # video: missing from the ViT checkpoint
 
 
 def _rng(name, seed):
@@ -74,7 +89,7 @@ def _normal(name, shape, seed, std, mean=0.0):
 
 
 def make_state_dict(num_classes=100, ffn_num=64, seed=0, kind="test", depth=DEPTH,
-                    gate_bias=0.0):
+                    gate_bias=0.0, video=False):
     """Synthetic weights.
 
     kind="bench": what the reference's own init gives (trunc-normal(0.02) linears with
@@ -88,11 +103,13 @@ def make_state_dict(num_classes=100, ffn_num=64, seed=0, kind="test", depth=DEPT
     """
     sd = {}
     test = kind == "test"
-    for name, shape in param_shapes(num_classes, ffn_num, depth).items():
+    for name, shape in param_shapes(num_classes, ffn_num, depth, video).items():
         if name == "cls_token":
             t = _normal(name, shape, seed, 0.02 if test else 1e-6)
         elif name == "pos_embed":
             t = _normal(name, shape, seed, 0.02)
+        elif name == "query_token":   # reference init is zeros (:407): LN of a constant row would be degenerate
+            t = _normal(name, shape, seed, 0.02 if not test else 0.5)
         elif ".norm" in name or name.startswith("norm."):
             if name.endswith("weight"):
                 t = _normal(name, shape, seed, 0.1, 1.0) if test else torch.ones(shape)

@@ -63,6 +63,15 @@ enum dyt_param {
     DYT_P_AD_UP_W, DYT_P_AD_UP_B,     /* T blocks.i.adaptmlp.up_proj [768,r] */
     DYT_P_GATE_W, DYT_P_GATE_B,       /* T blocks.i.mlp_token_select.mlp_head [1,768] */
     DYT_P_HEAD_W, DYT_P_HEAD_B,       /* T head [C,768] */
+    /* video model only (cfg.frames > 1): the attentive pooling head, all trainable (missing from the
+     * ViT checkpoint) -- video_models/video_vision_transformer_IN21K.py:27-110,407-410 */
+    DYT_P_POOL_QUERY,                     /* T query_token [1,1,768] */
+    DYT_P_POOL_NQ_W, DYT_P_POOL_NQ_B,     /* T attentive_blocks.norm_q */
+    DYT_P_POOL_NK_W, DYT_P_POOL_NK_B,     /* T attentive_blocks.norm_k */
+    DYT_P_POOL_NV_W, DYT_P_POOL_NV_B,     /* T attentive_blocks.norm_v */
+    DYT_P_POOL_Q_W, DYT_P_POOL_K_W, DYT_P_POOL_V_W,   /* T attentive_blocks.cross_attn.{q,k,v}.weight [768,768] */
+    DYT_P_POOL_Q_BIAS, DYT_P_POOL_V_BIAS,             /* T attentive_blocks.cross_attn.{q_bias,v_bias} [768] */
+    DYT_P_POOL_PROJ_W, DYT_P_POOL_PROJ_B,             /* T attentive_blocks.cross_attn.proj [768,768] */
     DYT_P_COUNT
 };
 
@@ -80,6 +89,11 @@ typedef struct dyt_config {
     float adapter_dropout;   /* 0.1, vision_transformer_IN21K.py:133 */
     float tau;               /* 5, dynamic_adapter.py:59 */
     float threshold;         /* 0.5, dynamic_adapter.py:59 */
+    int32_t frames;          /* 0/1: image model.  t > 1: video model (video_models/video_vision_transformer_IN21K.py:
+                                435-483) -- `images`/`batch` of every call are the b*t frames of b clips, clip-major
+                                ("b c t h w -> (b t) c h w"), batch % t == 0; logits / targets have b = batch/t rows;
+                                the cls-pooling head is replaced by the attentive pooling head over the t*197
+                                final-norm tokens of a clip (one query, 12 heads) */
 } dyt_config;
 
 typedef struct dyt_ctx dyt_ctx;

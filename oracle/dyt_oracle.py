@@ -131,14 +131,42 @@ def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="ma
     return x + h + adapt, sel, logits  # :163
 
 
+def attentive_pool(sd, t, frames):
+    """Pooling tail of the video model: VisionTransformer.forward
+    (video_models/video_vision_transformer_IN21K.py:463-483) -> AttentiveBlock.forward (:44-51) ->
+    CrossAttention.forward (:79-110).  ``t``: final-norm tokens [b*frames, 197, 768] -> [b, 768]."""
+    bt, n, c = t.shape
+    b = bt // frames
+    x = t.reshape(b, frames * n, c)                                   # "(b t) tokens c -> b (t tokens) c"  :476
+    p = "attentive_blocks."
+    xq = layer_norm(sd["query_token"].expand(b, -1, -1), sd[p + "norm_q.weight"], sd[p + "norm_q.bias"])  # :45
+    xk = layer_norm(x, sd[p + "norm_k.weight"], sd[p + "norm_k.bias"])   # :46
+    xv = layer_norm(x, sd[p + "norm_v.weight"], sd[p + "norm_v.bias"])   # :47
+    ca = p + "cross_attn."
+    q = F.linear(xq, sd[ca + "q.weight"], sd[ca + "q_bias"])            # :92  (k_bias is zeros, :89)
+    k = F.linear(xk, sd[ca + "k.weight"])                               # :95
+    v = F.linear(xv, sd[ca + "v.weight"], sd[ca + "v_bias"])            # :98
+    q = q.reshape(b, 1, HEADS, HEAD_DIM).transpose(1, 2) * (HEAD_DIM ** -0.5)   # :93,:101
+    k = k.reshape(b, frames * n, HEADS, HEAD_DIM).transpose(1, 2)
+    v = v.reshape(b, frames * n, HEADS, HEAD_DIM).transpose(1, 2)
+    a = (q @ k.transpose(-2, -1)).softmax(dim=-1)                        # :102-104
+    o = (a @ v).transpose(1, 2).reshape(b, 1, c)                         # :107
+    o = F.linear(o, sd[ca + "proj.weight"], sd[ca + "proj.bias"])        # :108
+    return o[:, 0, :]                                                    # :479
+
+
 def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=False,
             training=True, mode="masked", tau=5.0, threshold=0.5, drop_p=0.1, depth=DEPTH,
-            return_blocks=False):
+            return_blocks=False, frames=1):
     """VisionTransformer.forward, models/vision_transformer_IN21K.py:343-385.
 
     g1, g2: [depth, B, 196] Gumbel draws (None in eval); keep_masks: [depth, B*197, r]
     uint8/bool adapter-dropout keep masks or None.
-    Returns logits [B,C] and {"token_select","token_logits"} each [B,depth,196,1]."""
+    Returns logits [B,C] and {"token_select","token_logits"} each [B,depth,196,1].
+
+    frames > 1: the video model (video_models/video_vision_transformer_IN21K.py:435-483): ``x`` is the
+    clip tensor already folded to [(b t),3,224,224] ("b c t h w -> (b t) c h w", :437); the trunk is
+    identical, the head is the attentive pooling over the t*197 final-norm tokens of each clip."""
     B = x.shape[0]
     t = embed(sd, x)
     sels, logs, xs = [], [], [t]
@@ -156,7 +184,10 @@ def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=
     ts = torch.stack(sels, dim=1)[:, :, 1:, :]  # :367 (drop the cls column)
     tl = torch.stack(logs, dim=1)  # :368
     t = layer_norm(t, sd["norm.weight"], sd["norm.bias"])  # :370
-    logits = F.linear(t[:, 0], sd["head.weight"], sd["head.bias"])  # :375-380 (cls pooling)
+    if frames > 1:
+        logits = F.linear(attentive_pool(sd, t, frames), sd["head.weight"], sd["head.bias"])  # video :480
+    else:
+        logits = F.linear(t[:, 0], sd["head.weight"], sd["head.bias"])  # :375-380 (cls pooling)
     out = dict(token_select=ts, token_logits=tl)
     if return_blocks:
         out["blocks"] = xs
@@ -175,15 +206,16 @@ def ada_loss(logits, token_sel, y, token_target_ratio=0.5, token_loss_ratio=2.0,
 
 def step_loss(sd, x, y, g1, g2, keep_masks, scale=0.1, mode="masked", token_target_ratio=0.5,
               token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0, depth=DEPTH,
-              drop_p=0.1):
+              drop_p=0.1, frames=1):
     """Loss of one fine-tune step, engine_finetune.py:47-65: student + teacher forward,
-    KL(student || teacher.detach()), teacher CE, AdaLoss(student).
+    KL(student || teacher.detach()), teacher CE, AdaLoss(student)  (video: the identical body of
+    train_video_one_epoch, engine_finetune.py:138-155, with frames > 1).
 
     g1/g2: [2, depth, B, 196] (pass 0 = student, 1 = teacher; the teacher pass also draws
     gate noise although its mask is discarded, :152,161); keep_masks [2, depth, B*197, r]."""
     km = (None, None) if keep_masks is None else (keep_masks[0], keep_masks[1])
-    out_s, tok = forward(sd, x, g1[0], g2[0], km[0], scale, False, True, mode, depth=depth, drop_p=drop_p)
-    out_t, _ = forward(sd, x, g1[1], g2[1], km[1], scale, True, True, mode, depth=depth, drop_p=drop_p)
+    out_s, tok = forward(sd, x, g1[0], g2[0], km[0], scale, False, True, mode, depth=depth, drop_p=drop_p, frames=frames)
+    out_t, _ = forward(sd, x, g1[1], g2[1], km[1], scale, True, True, mode, depth=depth, drop_p=drop_p, frames=frames)
     kl = F.kl_div(F.log_softmax(out_s, dim=-1), F.log_softmax(out_t.detach(), dim=-1),
                   reduction="batchmean", log_target=True)  # :52-57
     teacher = F.cross_entropy(out_t, y)  # :60
@@ -196,7 +228,8 @@ def step_loss(sd, x, y, g1, g2, keep_masks, scale=0.1, mode="masked", token_targ
 
 def trainable_names(sd):
     """Freeze rule, main_image.py:250-256."""
-    return [k for k in sd if ("adaptmlp." in k) or ("mlp_token_select." in k) or k.startswith("head.")]
+    return [k for k in sd if ("adaptmlp." in k) or ("mlp_token_select." in k) or k.startswith("head.") or
+            k == "query_token" or k.startswith("attentive_blocks.")]   # video: the pooling head is not in the checkpoint
 
 
 def step_grads(sd, x, y, g1, g2, keep_masks, **kw):

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/video_step.npz by running the REAL reference video model on CPU.
+
+Same rules as make_golden.py (build container only; data, not code, is committed):
+``video_models.video_vision_transformer_IN21K.vit_base_patch16_224_in21k`` is built with the
+synthetic weights of ``synth.make_state_dict(video=True)``, one optimisation step is driven through
+the reference's own ``engine_finetune.train_video_one_epoch`` (engine_finetune.py:109-203) with the
+freeze rule of main_video.py:279-285 (adapters, gates, head, ``query_token`` and ``attentive_blocks.*``
+train), and an eval-mode forward is recorded as well.  Usage:  python tests/golden/make_golden_video.py
+"""
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (installs the third-party stand-ins, puts the reference on sys.path)
+
+synth = mg.synth
+from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k as video_vit  # noqa: E402
+
+BIG = ("cross_attn.q.weight", "cross_attn.k.weight", "cross_attn.v.weight", "cross_attn.proj.weight")
+ROW_STRIDE = 96   # 8 of the 768 rows of each 768x768 pooling-head gradient are stored
+
+
+def build(num_classes, ffn_num, scalar, sd):
+    tuning = mg.EasyDict(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none",
+                         ffn_adapter_init_option="lora", ffn_adapter_scalar=scalar, ffn_num=ffn_num, d_model=768)
+    select = mg.EasyDict(open=True, keep_layers=0)
+    model = video_vit(num_classes=num_classes, drop_path_rate=0.0, tuning_config=tuning, select_config=select)
+    msg = model.load_state_dict(sd, strict=True)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    for n, p in model.named_parameters():  # main_video.py:279-285
+        p.requires_grad = synth.is_trainable(n)
+    return model
+
+
+def clips_from_frames(x, frames):
+    """[(b t),3,H,W] clip-major frames -> the [b,3,t,H,W] clip tensor the reference model folds back."""
+    bt, c, h, w = x.shape
+    return x.reshape(bt // frames, frames, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
+
+
+def main(fname="video_step.npz", clips=2, frames=2, num_classes=7, ffn_num=8, scalar="0.1", wd=0.01, lr=1e-3,
+         target_ratio=0.5, gate_bias=0.4, seed=11):
+    torch.manual_seed(4321 + seed)
+    B = clips * frames
+    sd = synth.make_state_dict(num_classes, ffn_num, seed=seed, kind="test", gate_bias=gate_bias, video=True)
+    model = build(num_classes, ffn_num, scalar, sd)
+    out = {"meta_clips": clips, "meta_frames": frames, "meta_num_classes": num_classes, "meta_ffn_num": ffn_num,
+           "meta_scale": float(scalar), "meta_wd": wd, "meta_lr": lr, "meta_target_ratio": target_ratio,
+           "meta_gate_bias": gate_bias, "meta_seed": seed, "meta_row_stride": ROW_STRIDE}
+    x, _ = synth.make_batch(B, num_classes, seed=seed)
+    y = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 5)).integers(0, num_classes, size=(clips,)))
+    out["targets"] = y.numpy()
+    xc = clips_from_frames(x, frames)
+
+    # ---- eval-mode forward (engine_finetune.py:281-356 evaluates with model.eval()) ----
+    model.eval()
+    with torch.no_grad():
+        le, de = model(xc)
+    out["eval_logits"] = le.numpy()
+    out["eval_token_select"] = de["token_select"].numpy().astype(np.uint8)
+    out["eval_token_logits"] = de["token_logits"].numpy()
+    out["eval_min_gate_margin"] = np.float64(de["token_logits"].abs().min())
+
+    # ---- one training step through the reference's own loop ----
+    params = [p for n, p in model.named_parameters() if p.requires_grad]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    optimizer = torch.optim.AdamW(params, lr=lr, weight_decay=wd)  # main_video.py:316
+    criterion = mg.AdaLoss(base_criterion=nn.CrossEntropyLoss(), token_target_ratio=target_ratio, token_loss_ratio=2.0,
+                           token_minimal=0.0, token_minimal_weight=0.0)
+    scaler = mg.misc.NativeScalerWithGradNormCount()
+    args = types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=0.0, warmup_epochs=0, epochs=10, metric="accuracy",
+                                 nb_classes=num_classes)
+    grads_rec = []
+    step_orig = optimizer.step
+
+    def step_hook(*a, **k):
+        grads_rec.append({n: p.grad.detach().clone() for n, p in zip(names, params)})
+        return step_orig(*a, **k)
+    optimizer.step = step_hook
+    logits_rec = []
+    h = model.register_forward_hook(lambda m, i, o: logits_rec.append(
+        (o[0].detach().clone(), o[1]["token_select"].detach().clone(), o[1]["token_logits"].detach().clone())))
+    keep = synth.make_dropout_masks(B, ffn_num, seed=seed + 3)
+    with mg.Recorder(keep) as rec:
+        stats = mg.engine_finetune.train_video_one_epoch(model, criterion, [(xc, y)], optimizer, torch.device("cpu"), 0,
+                                                         scaler, None, None, None, args=args,
+                                                         logger=logging.getLogger("golden"))
+    h.remove()
+    g1, g2 = rec.gumbels(2, 12, B)
+    out["g1"], out["g2"] = g1.numpy(), g2.numpy()
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        out["stat_" + k] = np.float64(stats[k])
+    (ls, ts, tl), (lt, _, _) = logits_rec[0], logits_rec[1]
+    out["logits_student"], out["logits_teacher"] = ls.numpy(), lt.numpy()
+    out["token_select"] = ts.numpy().astype(np.uint8)
+    out["token_logits"] = tl.numpy()
+    z = (tl[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0
+    out["min_gate_margin"] = np.float64(z.abs().min())
+    for n, g in grads_rec[0].items():
+        out["gradnorm/" + n] = np.float64(g.double().norm())
+        if n.endswith(BIG):
+            out["gradrows/" + n] = g[::ROW_STRIDE].numpy()
+        elif mg.keep_grad(n):
+            out["grad/" + n] = g.numpy()
+    for n, p in zip(names, params):
+        if n.endswith(BIG):
+            out["param_after_rows/" + n] = p.detach()[::ROW_STRIDE].numpy().copy()
+        elif mg.keep_grad(n):
+            out["param_after/" + n] = p.detach().numpy().copy()
+    print(fname, {k: round(float(v), 6) for k, v in stats.items()}, "keep", float(ts.float().mean()),
+          "margin", float(z.abs().min()), "eval margin", float(out["eval_min_gate_margin"]))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    logging.basicConfig(level=logging.WARNING)
+    main()

@@ -216,6 +216,94 @@ def t_step_golden():
             torch.cuda.empty_cache()
 
 
+def build_video_model(g, precision, train_mode="compact"):
+    from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k
+    C, r = int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = synth.make_state_dict(C, r, seed=int(g["meta_seed"]), kind="test", gate_bias=float(g["meta_gate_bias"]), video=True)
+    tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                 ffn_adapter_scalar=str(float(g["meta_scale"])), ffn_num=r, d_model=768)
+    model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0),
+                                       precision=precision, train_mode=train_mode)
+    model.load_state_dict(sd, strict=True)
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    return model.cuda(), sd
+
+
+def t_video_golden():
+    """Video model: eval forward and one fused step vs the reference's own
+    video_vision_transformer_IN21K + train_video_one_epoch run (tests/golden/video_step.npz)."""
+    g = dict(np.load(os.path.join(ROOT, "tests/golden/video_step.npz")))
+    clips, frames, C, r, seed = (int(g["meta_clips"]), int(g["meta_frames"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]),
+                                 int(g["meta_seed"]))
+    B = clips * frames
+    x, _ = synth.make_batch(B, C, seed=seed)
+    xc = x.reshape(clips, frames, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous()   # [b,c,t,h,w]
+    y = torch.from_numpy(g["targets"])
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    stride = int(g["meta_row_stride"])
+    for prec in ("fp32", "bf16"):
+        ltol = 1e-3 if prec == "fp32" else 0.25
+        model, sd = build_video_model(g, prec, "masked")
+        model.eval()
+        with torch.no_grad():
+            logits, aux = model(xc.cuda())
+        report("video eval logits %s" % prec, float(np.abs(logits.cpu().numpy() - g["eval_logits"]).max()), ltol)
+        flips = int((aux["token_select"].cpu().numpy().astype(np.uint8) != g["eval_token_select"]).sum())
+        report("video eval masks %s" % prec, flips, 0 if prec == "fp32" else 400)
+        for mode in ("masked", "compact"):
+            model, sd = build_video_model(g, prec, mode)
+            model.train()
+            model.fold_input(xc)
+            eng = model.engine(B, torch.device("cuda", 0))
+            ls = torch.empty(clips, C, device="cuda")
+            lt = torch.empty(clips, C, device="cuda")
+            ts = torch.zeros(B, 12, 196, device="cuda")
+            losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), float(g["meta_target_ratio"]), 2.0, 0.0, 0.0, masked_dense=(mode == "masked"),
+                                      g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(),
+                                      logits_s=ls, logits_t=lt, token_select=ts).cpu()
+            tag = "video %s/%s" % (prec, mode)
+            report("step logits student %s" % tag, float(np.abs(ls.cpu().numpy() - g["logits_student"]).max()), ltol)
+            report("step logits teacher %s" % tag, float(np.abs(lt.cpu().numpy() - g["logits_teacher"]).max()), ltol)
+            flips = int((ts.cpu().numpy().astype(np.uint8) != g["token_select"][..., 0]).sum())
+            report("step masks %s" % tag, flips, 0 if prec == "fp32" else 400, "of %d" % ts.numel())
+            for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
+                ref = float(g["stat_" + k])
+                report("step %s %s" % (k, tag), abs(float(losses[i]) - ref), (1e-4 if prec == "fp32" else 0.05) * max(1.0, abs(ref)))
+            if mode == "masked":
+                gref = {n[len("grad/"):]: (torch.from_numpy(v), None) for n, v in g.items() if n.startswith("grad/")}
+                gref.update({n[len("gradrows/"):]: (torch.from_numpy(v), stride) for n, v in g.items() if n.startswith("gradrows/")})
+            else:
+                _, gg, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="compact",
+                                        token_target_ratio=float(g["meta_target_ratio"]), frames=frames)
+                gref = {n: (v, None) for n, v in gg.items()}
+            worst, wname = 0.0, ""
+            for n, (gr, st) in gref.items():
+                shape = tuple(sd[n].shape)
+                got = eng.trainable_view(n, shape, eng.grad).cpu()
+                if st:
+                    got = got[::st]
+                # norm_k.bias has an exactly-zero true gradient (a constant added to every key of a clip shifts all
+                # scores equally; the reference's own value is 1e-9 round-off), hence the absolute floor
+                e = float((got - gr).norm() / max(float(gr.norm()), 1e-4 if prec == "fp32" else 1e-3))
+                if e > worst:
+                    worst, wname = e, n
+            report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.2, wname)
+            if prec == "fp32" and mode == "masked":
+                eng.adamw(float(g["meta_lr"]), float(g["meta_wd"]))
+                worst = 0.0
+                for key in g:
+                    if key.startswith("param_after/"):
+                        n = key.split("/", 1)[1]
+                        got = eng.trainable_view(n, g[key].shape).cpu().numpy()
+                        big = np.abs(g["grad/" + n]) > 1e-6
+                        worst = max(worst, float(np.abs(got - g[key])[big].max(initial=0.0)))
+                report("video adamw params after step", worst, 2e-5)
+            del model, eng
+            torch.cuda.empty_cache()
+
+
 def t_autograd_api():
     """module API + autograd bridge vs the fused step (same numbers expected)."""
     from models.losses import AdaLoss

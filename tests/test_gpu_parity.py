@@ -47,6 +47,12 @@ def test_finetune_step_vs_reference_golden():
     _run(D.t_step_golden)
 
 
+def test_video_model_vs_reference_golden():
+    """video model (frames folded into the batch + attentive pooling head, 88 trainable tensors): eval forward
+    and fused step vs the reference's video_vision_transformer_IN21K / train_video_one_epoch; both modes."""
+    _run(D.t_video_golden)
+
+
 def test_module_api_autograd_bridge():
     _run(D.t_autograd_api)
 

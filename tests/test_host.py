@@ -88,10 +88,32 @@ def test_key_mapping_covers_state_dict():
     seen = set()
     for k in synth.param_shapes(10, 8):
         pid, layer = _lib.key_to_param(k)
-        assert 0 <= pid < _lib.P_COUNT and 0 <= layer < 12
+        assert 0 <= pid < _lib.P_POOL_QUERY and 0 <= layer < 12
+        assert _lib.is_trainable_param(pid) == synth.is_trainable(k)
+        seen.add(pid)
+    assert seen == set(range(_lib.P_POOL_QUERY))
+    for k in synth.param_shapes(10, 8, video=True):      # video model: + the 14 pooling-head tensors, all trainable
+        pid, layer = _lib.key_to_param(k)
         assert _lib.is_trainable_param(pid) == synth.is_trainable(k)
         seen.add(pid)
     assert seen == set(range(_lib.P_COUNT))
+
+
+def test_video_module_parameter_surface():
+    """video_models.video_vision_transformer_IN21K mirror: the reference's state_dict keys/shapes
+    (video_models/video_vision_transformer_IN21K.py:27-75,407-410) and its freeze rule (main_video.py:279-285)."""
+    from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k
+    tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                 ffn_adapter_scalar="0.1", ffn_num=8, d_model=768)
+    m = vit_base_patch16_224_in21k(num_classes=7, drop_path_rate=0.0, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
+    shapes = synth.param_shapes(7, 8, video=True)
+    sd = m.state_dict()
+    assert set(sd) == set(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert float(m.query_token.abs().max()) == 0.0     # reference init :407
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 3, 2, 224, 224))              # no CPU path
 
 
 def test_adaloss_mirror_equals_oracle():

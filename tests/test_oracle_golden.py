@@ -142,3 +142,52 @@ def test_compact_mode_semantics(step64):
     assert (grads[n] - grads2[n]).norm() > 1e-3 * grads[n].norm()  # the gate gradient differs...
     n = "head.weight"
     assert (grads[n] - grads2[n]).norm() < 1e-5 * grads[n].norm()  # ...the head gradient does not
+
+
+# ---- video model: attentive pooling head over t*197 tokens per clip ----
+@pytest.fixture(scope="module")
+def video(golden_dir):
+    g = load(golden_dir, "video_step.npz")
+    clips, frames, C, r = int(g["meta_clips"]), int(g["meta_frames"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    seed = int(g["meta_seed"])
+    sd = synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=float(g["meta_gate_bias"]), video=True)
+    x, _ = synth.make_batch(clips * frames, C, seed=seed)
+    y = torch.from_numpy(g["targets"])
+    keep = synth.make_dropout_masks(clips * frames, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    d, grads, outs = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="masked",
+                                  token_target_ratio=float(g["meta_target_ratio"]), frames=frames)
+    return g, sd, d, grads, outs, (x, y, g1, g2, keep, frames)
+
+
+def test_video_eval_forward(video):
+    g, sd, _, _, _, (x, y, g1, g2, keep, frames) = video
+    with torch.no_grad():
+        logits, tok = O.forward(sd, x, scale=float(g["meta_scale"]), training=False, frames=frames)
+    assert logits.shape == g["eval_logits"].shape
+    assert np.abs(logits.numpy() - g["eval_logits"]).max() < 2e-5
+    assert float(g["eval_min_gate_margin"]) > 1e-5
+    assert np.array_equal(tok["token_select"].numpy().astype(np.uint8), g["eval_token_select"])
+
+
+def test_video_step_losses_and_logits(video):
+    g, _, d, _, (ls, lt, tok), _ = video
+    assert np.abs(ls.detach().numpy() - g["logits_student"]).max() < 2e-5
+    assert np.abs(lt.detach().numpy() - g["logits_teacher"]).max() < 2e-5
+    assert np.array_equal(tok["token_select"].detach().numpy().astype(np.uint8), g["token_select"])
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(float(d[k]) - float(g["stat_" + k])) < 1e-5 * max(1.0, abs(float(g["stat_" + k]))), k
+
+
+def test_video_trainable_grads(video):
+    g, sd, _, grads, _, _ = video
+    assert len(grads) == 74 + 14   # adapters/gates/head + query_token + 13 attentive_blocks tensors
+    stride = int(g["meta_row_stride"])
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-9, n
+        if "grad/" + n in g:
+            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-9, n
+        if "gradrows/" + n in g:
+            ref = g["gradrows/" + n]
+            assert np.abs(gr[::stride].numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, n

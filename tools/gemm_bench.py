@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
 from _lib import check, lib, ptr, stream_ptr  # noqa: E402
 
-SHAPES = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072), (17690, 3072, 768)]
+SHAPES = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072), (17690, 3072, 768),
+          (17690, 768, 3072), (25216, 768, 2304), (21760, 768, 3072)]
 
 
 def bench(M, N, K, variant, iters=20):
