@@ -43,8 +43,12 @@ class Cfg(dict):
 
 
 def build_model(args, device):
-    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
-    sd = synth.make_state_dict(args.classes, args.ffn_num, seed=0, kind="bench", gate_bias=math.log(0.7 / 0.3))
+    video = args.video_frames > 1
+    if video:
+        from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k
+    else:
+        from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    sd = synth.make_state_dict(args.classes, args.ffn_num, seed=0, kind="bench", gate_bias=math.log(0.7 / 0.3), video=video)
     tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none",
                  ffn_adapter_init_option="lora", ffn_adapter_scalar="0.1", ffn_num=args.ffn_num, d_model=768)
     model = vit_base_patch16_224_in21k(num_classes=args.classes, drop_path_rate=0.0, tuning_config=tuning,
@@ -121,7 +125,12 @@ def main():
     ap.add_argument("--ffn_num", type=int, default=64)
     ap.add_argument("--keep", type=float, default=0.7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--video-frames", type=int, default=0,
+                    help="T > 1: BASELINE.json configs[4] shape instead of the headline one -- the video model, "
+                         "--batch frames per GPU = batch/T clips of T frames (train_video.sh: 16 clips x 8 frames, 400 classes)")
     args = ap.parse_args()
+    if args.video_frames > 1:
+        assert args.batch % args.video_frames == 0, "--batch must be a multiple of --video-frames"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +148,10 @@ def main():
     torch.manual_seed(1234 + rank)
     model = build_model(args, device)
     x, y = synth.make_batch(args.batch, args.classes, seed=100 + rank)  # each rank its own shard of the global batch
+    if args.video_frames > 1:   # [b,c,t,h,w] clips, one target per clip
+        T = args.video_frames
+        x = x.reshape(args.batch // T, T, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous()
+        y = y[: args.batch // T].contiguous()
     x, y = x.to(device), y.to(device)
     log("model built, ctx %.1f GB" % (0 if model._engine is None else model._engine.bytes / 1e9))
     keep_cal = calibrate_gates(model, x, args.keep)
@@ -213,13 +226,18 @@ def main():
     if rank == 0:
         ips = args.batch * world * args.steps / dt
         gflop = STEP_GFLOP_AT_07 + STEP_GFLOP_SLOPE * (keep_meas - 0.7) if args.mode == "compact" else 139.614
+        if args.video_frames > 1:   # + k/v projections of the pooling head per frame: fwd + dgrad + wgrad, two passes
+            gflop += 2 * 3 * 2 * (2 * 197 * 768 * 768) / 1e9
         out = {
             "metric": "images/sec DyT ViT-B/16 fine-tune step (student+teacher fwd, bwd, AdamW) @ keep~0.7",
             "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "ViT-B/16 DyT on CIFAR-100 shape, batch=128/GPU, 1xMI355X per rank, keep-ratio target 0.7 "
-                                   "(BASELINE.json configs[1]; N>1 = configs[3] shape: global batch 128*N, DP over RCCL)",
+            "config": {"workload": ("ViT-B/16 DyT on CIFAR-100 shape, batch=128/GPU, 1xMI355X per rank, keep-ratio target 0.7 "
+                                    "(BASELINE.json configs[1]; N>1 = configs[3] shape: global batch 128*N, DP over RCCL)")
+                       if args.video_frames <= 1 else
+                       ("NOT the headline config: video DyT ViT-B/16 (BASELINE.json configs[4] shape), %d clips x %d frames per GPU, "
+                        "%d classes; `value` counts frames/s" % (args.batch // args.video_frames, args.video_frames, args.classes)),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "ffn_num": args.ffn_num,
                        "num_classes": args.classes, "train_mode": args.mode, "parallelism": "dp%d" % world,
                        "keep_ratio_measured": round(keep_meas, 4), "keep_ratio_calibrated": round(keep_cal, 4)},
