@@ -182,6 +182,7 @@ def main():
     for i in range(args.steps):
         one_step(args.warmup + i)
         acc += losses
+    t_host = time.perf_counter() - t0   # host time to ENQUEUE the timed steps (no sync inside the loop)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -191,7 +192,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     host = (acc / args.steps).tolist()
-    log("timed %d steps: %.2f ms/step" % (args.steps, dt / args.steps * 1e3))
+    log("timed %d steps: %.2f ms/step (host enqueue %.2f ms/step)" % (args.steps, dt / args.steps * 1e3, t_host / args.steps * 1e3))
     keep_meas = host[5]
 
     # dominant-kernel roofline: HIP events around every GEMM launch of ONE step (same stream)
@@ -245,6 +246,7 @@ def main():
             "step_gflop_per_image": round(gflop, 3),
             "step_mfma_frac": round(ips / world * gflop * 1e9 / (PEAK[args.precision] * 1e12), 4),
             "loss": round(host[0], 4),
+            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
             "roofline": roof,
         }
         log("roofline", roof)
