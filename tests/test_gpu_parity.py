@@ -53,6 +53,27 @@ def test_video_model_vs_reference_golden():
     _run(D.t_video_golden)
 
 
+def test_video_full_clip_length_vs_oracle():
+    """train_video.sh geometry (8 frames -> 1576 keys per clip, 400 classes), 2 clips: eval logits of the HIP path
+    (fp32 mode) vs the oracle; clip order is a pure permutation of the logits rows (clips never mix)."""
+    from oracle import dyt_oracle as O
+    clips, frames, C, r = 2, 8, 400, 64
+    g = {"meta_num_classes": C, "meta_ffn_num": r, "meta_seed": 21, "meta_gate_bias": 0.6, "meta_scale": 0.1}
+    model, sd = D.build_video_model(g, "fp32")
+    model.eval()
+    x, _ = synth.make_batch(clips * frames, C, seed=21)
+    xc = x.reshape(clips, frames, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous()
+    with torch.no_grad():
+        got, aux = model(xc.cuda())
+        swapped, _ = model(xc.flip(0).contiguous().cuda())
+        ref, tok = O.forward(sd, x, scale=0.1, training=False, frames=frames)
+    assert got.shape == (clips, C)
+    assert float((got.cpu() - ref).abs().max()) < 1e-3
+    flips = int((aux["token_select"].cpu() != tok["token_select"]).sum())
+    assert flips <= 2, flips          # decisions within fp32 round-off of the threshold may differ
+    assert torch.equal(swapped.flip(0), got)
+
+
 def test_module_api_autograd_bridge():
     _run(D.t_autograd_api)
 
