@@ -218,9 +218,10 @@ int launch_pool_attn_fwd(int precision, const float* qs, const void* K, const vo
 int launch_pool_attn_bwd(int precision, const float* qs, const void* K, const void* V, const float* P, const float* dO,
                          void* dK, void* dV, float* dq_part, int clips, int NK, hipStream_t s);
 int launch_pool_q_bwd(const float* dq_part, int clips, const float* qn, const float* qhat, const float* st_q, const float* Wq,
-                      const float* nqw, float* gq, float* dWq, float* dqb, float* dnqw, float* dnqb, float* dquery,
-                      hipStream_t s);
-int launch_rows_linear(const float* x, const float* W, const float* bias, float* out, int R, int N, int K, hipStream_t s);
+                      const float* nqw, float* gq, float* dqn, float* dWq, float* dqb, float* dnqw, float* dnqb,
+                      float* dquery, hipStream_t s);
+int launch_rows_linear(const float* x, const float* W, const float* bias, float* out, int R, int N, int K, float scale,
+                       hipStream_t s);
 int launch_rows_linear_bwd(const float* dout, const float* x, const float* W, float* dx, float* dW, float* db, int R, int N,
                            int K, hipStream_t s);
 int launch_transpose_rows(int precision, const void* src, void* dst, int rows, int rows_pad, float* colsum_part,

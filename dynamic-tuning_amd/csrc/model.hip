@@ -106,9 +106,11 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
     float *xf = nullptr, *P = nullptr, *o = nullptr, *y = nullptr, *qn = nullptr, *qhat = nullptr, *qs = nullptr, *st_q = nullptr;
-    float *dq_part = nullptr, *gq = nullptr, *dy = nullptr, *dO = nullptr;
+    float *dq_part = nullptr, *gq = nullptr, *dqn = nullptr, *dy = nullptr, *dO = nullptr;
     float2 *st_f = nullptr, *st_kv = nullptr;
     void *xk = nullptr, *xv = nullptr, *Kp = nullptr, *Vp = nullptr;
+    void *dKt = nullptr, *xkt = nullptr, *dVt = nullptr, *xvt = nullptr;   // [768, Mpad] token-transposed operands of the k / v weight gradients
+    hipStream_t wstream = nullptr; hipEvent_t ev_wf = nullptr, ev_wj = nullptr; bool wpending = false;   // weight-gradient side stream
 };
 struct Slot {
     Transients T;
@@ -244,12 +246,15 @@ static void layout(dyt_ctx* c, bool dry) {
             Q.st_f = carve<float2>(c, M, dry); Q.st_kv = carve<float2>(c, M, dry);
             Q.xk = carve_at(c, M * D, dry); Q.xv = carve_at(c, M * D, dry);
             Q.Kp = carve_at(c, M * D, dry); Q.Vp = carve_at(c, M * D, dry);
+            const size_t Mp = (M + 63) / 64 * 64;
+            Q.dKt = carve_at(c, Mp * D, dry); Q.xkt = carve_at(c, Mp * D, dry);
+            Q.dVt = carve_at(c, Mp * D, dry); Q.xvt = carve_at(c, Mp * D, dry);
             Q.P = carve<float>(c, B * NH * NT, dry);
             Q.o = carve<float>(c, clips * D, dry); Q.y = carve<float>(c, clips * D, dry);
             Q.dy = carve<float>(c, clips * D, dry); Q.dO = carve<float>(c, clips * D, dry);
             Q.dq_part = carve<float>(c, clips * D, dry);
             Q.qn = carve<float>(c, D, dry); Q.qhat = carve<float>(c, D, dry); Q.qs = carve<float>(c, D, dry);
-            Q.gq = carve<float>(c, D, dry); Q.st_q = carve<float>(c, 4, dry);
+            Q.gq = carve<float>(c, D, dry); Q.dqn = carve<float>(c, D, dry); Q.st_q = carve<float>(c, 4, dry);
         }
     }
     for (int sl = 0; sl < cf.slots; ++sl) {
@@ -362,6 +367,9 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
         if (S.ev_f) hipEventDestroy(S.ev_f);
         if (S.ev_j) hipEventDestroy(S.ev_j);
         if (S.branch) hipStreamDestroy(S.branch);
+        if (S.pool.ev_wf) hipEventDestroy(S.pool.ev_wf);
+        if (S.pool.ev_wj) hipEventDestroy(S.pool.ev_wj);
+        if (S.pool.wstream) hipStreamDestroy(S.pool.wstream);
     }
     if (c->ev_b0) hipEventDestroy(c->ev_b0);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -604,8 +612,8 @@ static int pool_forward(dyt_ctx* c, Slot& S, const float* tr, float* logits, int
     RUN(2, 0, launch_pool_q_fwd(tr + c->off_pquery, tr + c->off_pnq_w, tr + c->off_pnq_b, tr + c->off_pq_w,
                                 tr + c->off_pq_bias, Q.qn, Q.qhat, Q.st_q, Q.qs, s));
     RUN(1, 4.0 * clips * NH * (double)NK * HD, launch_pool_attn_fwd(P, Q.qs, Q.Kp, Q.Vp, Q.P, Q.o, clips, NK, s));
-    RUN(2, 0, launch_rows_linear(Q.o, tr + c->off_pproj_w, tr + c->off_pproj_b, Q.y, clips, D, D, s));
-    RUN(2, 0, launch_rows_linear(Q.y, tr + c->off_hw, tr + c->off_hb, logits, clips, C, D, s));
+    RUN(2, 0, launch_rows_linear(Q.o, tr + c->off_pproj_w, tr + c->off_pproj_b, Q.y, clips, D, D, 1.0f, s));
+    RUN(2, 0, launch_rows_linear(Q.y, tr + c->off_hw, tr + c->off_hb, logits, clips, C, D, 1.0f, s));
     return 0;
 }
 
@@ -621,25 +629,37 @@ static int pool_backward(dyt_ctx* c, Slot& S, const float* tr, const float* dlog
     void* dK = T.dO; void* dV = T.dxn;   // [M,768] AT transients, free until the trunk backward starts
     RUN(1, 8.0 * clips * NH * (double)NK * HD,
         launch_pool_attn_bwd(P, Q.qs, Q.Kp, Q.Vp, Q.P, Q.dO, dK, dV, Q.dq_part, clips, NK, s));
-    RUN(2, 0, launch_pool_q_bwd(Q.dq_part, clips, Q.qn, Q.qhat, Q.st_q, tr + c->off_pq_w, tr + c->off_pnq_w, Q.gq,
+    RUN(2, 0, launch_pool_q_bwd(Q.dq_part, clips, Q.qn, Q.qhat, Q.st_q, tr + c->off_pq_w, tr + c->off_pnq_w, Q.gq, Q.dqn,
                                 grad + c->off_pq_w, grad + c->off_pq_bias, grad + c->off_pnq_w, grad + c->off_pnq_b,
                                 grad + c->off_pquery, s));
-    // weight gradients of k / v: dW = dK^T xk over the token rows -- operands transposed to K-contiguous, NT GEMM
-    void* dKt = T.h1; void* xkt = at_off(c, T.h1, (size_t)Mp * D);
-    void* dVt = T.dZ; void* xvt = at_off(c, T.dZ, (size_t)Mp * D);
-    RUN(2, 0, launch_transpose_rows(P, dK, dKt, M, Mp, nullptr, s));
-    RUN(2, 0, launch_transpose_rows(P, Q.xk, xkt, M, Mp, nullptr, s));
-    RUN(2, 0, launch_transpose_rows(P, dV, dVt, M, Mp, T.tok_partial, s));   // + column sums of dV -> v_bias
-    RUN(2, 0, launch_transpose_rows(P, Q.xv, xvt, M, Mp, nullptr, s));
-    {
-        GemmArgs a; a.A = dKt; a.W = xkt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pk_w; a.accumulate = 1;
-        RUN_GEMM(EPI_STORE_F32, a);
-    }
-    {
-        GemmArgs a; a.A = dVt; a.W = xvt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pv_w; a.accumulate = 1;
-        RUN_GEMM(EPI_STORE_F32, a);
-    }
+    // weight gradients of k / v: dW = dK^T xk over the token rows -- operands transposed to K-contiguous, NT GEMM.
+    // A 768x768 output is only 36 workgroups, so the two GEMMs go to a side stream and run under the trunk's
+    // backward (they touch nothing else: their operands are private copies, their outputs own regions of grad).
+    RUN(2, 0, launch_transpose_rows(P, dK, Q.dKt, M, Mp, nullptr, s));
+    RUN(2, 0, launch_transpose_rows(P, Q.xk, Q.xkt, M, Mp, nullptr, s));
+    RUN(2, 0, launch_transpose_rows(P, dV, Q.dVt, M, Mp, T.tok_partial, s));   // + column sums of dV -> v_bias
+    RUN(2, 0, launch_transpose_rows(P, Q.xv, Q.xvt, M, Mp, nullptr, s));
     RUN(2, 0, launch_reduce_partials(T.tok_partial, Mp / 64, D, grad + c->off_pv_bias, D, 1.0f, s));
+    hipStream_t ws = nullptr;
+    if (c->overlap && !c->prof) {
+        if (!Q.wstream) {
+            DYT_HIP_CHECK(hipStreamCreateWithFlags(&Q.wstream, hipStreamNonBlocking));
+            DYT_HIP_CHECK(hipEventCreateWithFlags(&Q.ev_wf, hipEventDisableTiming));
+            DYT_HIP_CHECK(hipEventCreateWithFlags(&Q.ev_wj, hipEventDisableTiming));
+        }
+        ws = Q.wstream;
+        DYT_HIP_CHECK(hipEventRecord(Q.ev_wf, s));
+        DYT_HIP_CHECK(hipStreamWaitEvent(ws, Q.ev_wf, 0));
+    }
+    {
+        GemmArgs a; a.A = Q.dKt; a.W = Q.xkt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pk_w; a.accumulate = 1;
+        RUN_ON(ws, 0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+    }
+    {
+        GemmArgs a; a.A = Q.dVt; a.W = Q.xvt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pv_w; a.accumulate = 1;
+        RUN_ON(ws, 0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
+    }
+    if (ws) { DYT_HIP_CHECK(hipEventRecord(Q.ev_wj, ws)); Q.wpending = true; }   // joined at the end of backward_impl
     // dgrads through k / v, then norm_k + norm_v + final norm backward in one row pass
     {
         GemmArgs a; a.A = dK; a.W = c->pk_wT; a.M = M; a.N = D; a.K = D; a.out_at = T.du_at;
@@ -932,6 +952,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             prepped = fuse;
         }
     }
+    if (S.pool.wpending) { DYT_HIP_CHECK(hipStreamWaitEvent(s, S.pool.ev_wj, 0)); S.pool.wpending = false; }
     return DYT_OK;
 }
 

@@ -69,14 +69,11 @@ int launch_pool_ln_fwd(int precision, const float* x, const float* nw, const flo
 // ------------------------------------------------------------------------------------------
 // query path (batch independent): qn = LN_q(query_token) ; q = (Wq qn + q_bias) * head_dim^-0.5
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_q_fwd_kernel(const float* __restrict__ query, const float* __restrict__ nqw,
-                                                         const float* __restrict__ nqb, const float* __restrict__ Wq,
-                                                         const float* __restrict__ qbias, float* __restrict__ qn,
-                                                         float* __restrict__ qhat, float* __restrict__ st_q,
-                                                         float* __restrict__ qs) {
-    __shared__ float row[D];
+__global__ __launch_bounds__(256) void pool_q_ln_kernel(const float* __restrict__ query, const float* __restrict__ nqw,
+                                                        const float* __restrict__ nqb, float* __restrict__ qn,
+                                                        float* __restrict__ qhat, float* __restrict__ st_q) {
     __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     float v[3], s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { v[i] = query[tid + 256 * i]; s += v[i]; }
@@ -89,25 +86,18 @@ __global__ __launch_bounds__(256) void pool_q_fwd_kernel(const float* __restrict
     for (int i = 0; i < 3; ++i) {
         const int c = tid + 256 * i;
         const float xh = (v[i] - mean) * rstd;
-        const float y = xh * nqw[c] + nqb[c];
-        row[c] = y; qn[c] = y; qhat[c] = xh;
+        qn[c] = xh * nqw[c] + nqb[c];
+        qhat[c] = xh;
     }
     if (tid == 0) { st_q[0] = mean; st_q[1] = rstd; }
-    __syncthreads();
-    for (int n = wave; n < D; n += 4) {
-        float acc = 0.f;
-        const float* wp = Wq + (size_t)n * D;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) acc = fmaf(row[lane + 64 * i], wp[lane + 64 * i], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) qs[n] = (acc + qbias[n]) * 0.125f;
-    }
 }
+int launch_rows_linear(const float* x, const float* W, const float* bias, float* out, int R, int N, int K, float scale,
+                       hipStream_t s);
 int launch_pool_q_fwd(const float* query, const float* nqw, const float* nqb, const float* Wq, const float* qbias, float* qn,
                       float* qhat, float* st_q, float* qs, hipStream_t s) {
-    hipLaunchKernelGGL(pool_q_fwd_kernel, dim3(1), dim3(256), 0, s, query, nqw, nqb, Wq, qbias, qn, qhat, st_q, qs);
+    hipLaunchKernelGGL(pool_q_ln_kernel, dim3(1), dim3(256), 0, s, query, nqw, nqb, qn, qhat, st_q);
     LAUNCH_CHECK();
-    return 0;
+    return launch_rows_linear(qn, Wq, qbias, qs, 1, D, D, 0.125f, s);   // head_dim ** -0.5
 }
 
 // ------------------------------------------------------------------------------------------
@@ -220,7 +210,7 @@ int launch_pool_attn_bwd(int precision, const float* qs, const void* K, const vo
 // ------------------------------------------------------------------------------------------
 // query path backward.  dq (w.r.t. the scaled q) = sum over clips of dq_part.
 //   kernel W (grid 768): dWq[n,:] += g_n qn ; dq_bias[n] += g_n       with g_n = dq[n] / 8
-//   kernel X (grid 1)  : dqn = Wq^T g ; d norm_q.{w,b} ; d query_token
+//   then dqn = Wq^T g (rows_linear_bwd_x) and one workgroup for d norm_q.{w,b} ; d query_token
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_q_bwd_w_kernel(const float* __restrict__ dq_part, int clips,
                                                            const float* __restrict__ qn, float* __restrict__ dWq,
@@ -233,21 +223,19 @@ __global__ __launch_bounds__(256) void pool_q_bwd_w_kernel(const float* __restri
     for (int i = 0; i < 3; ++i) dWq[(size_t)n * D + tid + 256 * i] += g * qn[tid + 256 * i];
     if (tid == 0) { dqb[n] += g; gq[n] = g; }
 }
-__global__ __launch_bounds__(256) void pool_q_bwd_x_kernel(const float* __restrict__ gq, const float* __restrict__ Wq,
-                                                           const float* __restrict__ nqw, const float* __restrict__ qhat,
-                                                           const float* __restrict__ st_q, float* __restrict__ dnqw,
-                                                           float* __restrict__ dnqb, float* __restrict__ dquery) {
-    __shared__ float g[D];
+__global__ void rows_linear_bwd_x_kernel(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ dx,
+                                         int R, int N, int K);   // defined with the tiny dense layers below
+__global__ __launch_bounds__(256) void pool_q_bwd_ln_kernel(const float* __restrict__ dqn, const float* __restrict__ nqw,
+                                                            const float* __restrict__ qhat, const float* __restrict__ st_q,
+                                                            float* __restrict__ dnqw, float* __restrict__ dnqb,
+                                                            float* __restrict__ dquery) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
-    for (int n = tid; n < D; n += 256) g[n] = gq[n];
-    __syncthreads();
     float dy[3], xh[3], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int k = tid + 256 * i;
-        float acc = 0.f;
-        for (int n = 0; n < D; ++n) acc = fmaf(g[n], Wq[(size_t)n * D + k], acc);
+        const float acc = dqn[k];
         xh[i] = qhat[k];
         dnqw[k] += acc * xh[i];
         dnqb[k] += acc;
@@ -262,10 +250,11 @@ __global__ __launch_bounds__(256) void pool_q_bwd_x_kernel(const float* __restri
     for (int i = 0; i < 3; ++i) dquery[tid + 256 * i] += rstd * (dy[i] - s1 - xh[i] * s2);
 }
 int launch_pool_q_bwd(const float* dq_part, int clips, const float* qn, const float* qhat, const float* st_q, const float* Wq,
-                      const float* nqw, float* gq, float* dWq, float* dqb, float* dnqw, float* dnqb, float* dquery,
-                      hipStream_t s) {
+                      const float* nqw, float* gq, float* dqn, float* dWq, float* dqb, float* dnqw, float* dnqb,
+                      float* dquery, hipStream_t s) {
     hipLaunchKernelGGL(pool_q_bwd_w_kernel, dim3(D), dim3(256), 0, s, dq_part, clips, qn, dWq, dqb, gq);
-    hipLaunchKernelGGL(pool_q_bwd_x_kernel, dim3(1), dim3(256), 0, s, gq, Wq, nqw, qhat, st_q, dnqw, dnqb, dquery);
+    hipLaunchKernelGGL(rows_linear_bwd_x_kernel, dim3(D / 64, 1), dim3(256), 0, s, gq, Wq, dqn, 1, D, D);   // dqn = Wq^T g
+    hipLaunchKernelGGL(pool_q_bwd_ln_kernel, dim3(1), dim3(256), 0, s, dqn, nqw, qhat, st_q, dnqw, dnqb, dquery);
     LAUNCH_CHECK();
     return 0;
 }
@@ -276,28 +265,44 @@ int launch_pool_q_bwd(const float* dq_part, int clips, const float* qn, const fl
 // out[r,n] = x[r,:] . W[n,:] + bias[n]        grid (ceil(N/4), R), one wave per output
 __global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                           const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                          int K) {
+                                                          int K, float scale) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), r = blockIdx.y;
     if (n >= N) return;
     float acc = 0.f;
     for (int k = lane; k < K; k += 64) acc = fmaf(x[(size_t)r * K + k], W[(size_t)n * K + k], acc);
     acc = wave_sum(acc);
-    if (lane == 0) out[(size_t)r * N + n] = acc + (bias ? bias[n] : 0.f);
+    if (lane == 0) out[(size_t)r * N + n] = (acc + (bias ? bias[n] : 0.f)) * scale;
 }
-int launch_rows_linear(const float* x, const float* W, const float* bias, float* out, int R, int N, int K, hipStream_t s) {
-    hipLaunchKernelGGL(rows_linear_kernel, dim3((N + 3) / 4, R), dim3(256), 0, s, x, W, bias, out, N, K);
+int launch_rows_linear(const float* x, const float* W, const float* bias, float* out, int R, int N, int K, float scale,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(rows_linear_kernel, dim3((N + 3) / 4, R), dim3(256), 0, s, x, W, bias, out, N, K, scale);
     LAUNCH_CHECK();
     return 0;
 }
-// dx[r,k] = sum_n dout[r,n] W[n,k]             grid (ceil(K/256), R)
+// dx[r,k] = sum_n dout[r,n] W[n,k].  Workgroup = 64 columns k (lane) x up to 16 rows r; the N loop is split over the
+// 4 waves (fixed order), W is read once per workgroup, fully coalesced.   grid (K/64, ceil(R/16))
 __global__ __launch_bounds__(256) void rows_linear_bwd_x_kernel(const float* __restrict__ dout, const float* __restrict__ W,
-                                                                float* __restrict__ dx, int N, int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (k >= K) return;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc = fmaf(dout[(size_t)r * N + n], W[(size_t)n * K + k], acc);
-    dx[(size_t)r * K + k] = acc;
+                                                                float* __restrict__ dx, int R, int N, int K) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, r0 = blockIdx.y * 16;
+    const int nr = min(16, R - r0);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int n = wave; n < N; n += 4) {
+        const float w = W[(size_t)n * K + k];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nr) acc[i] = fmaf(dout[(size_t)(r0 + i) * N + n], w, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (wave == 0)
+        for (int i = 0; i < nr; ++i)
+            dx[(size_t)(r0 + i) * K + k] = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
 }
 // dW[n,k] += sum_r dout[r,n] x[r,k] ; db[n] += sum_r dout[r,n]     grid N
 __global__ __launch_bounds__(256) void rows_linear_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ x,
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(256) void rows_linear_bwd_w_kernel(const float* __r
 }
 int launch_rows_linear_bwd(const float* dout, const float* x, const float* W, float* dx, float* dW, float* db, int R, int N,
                            int K, hipStream_t s) {
-    if (dx) hipLaunchKernelGGL(rows_linear_bwd_x_kernel, dim3((K + 255) / 256, R), dim3(256), 0, s, dout, W, dx, N, K);
+    if (K % 64 != 0) { set_error("rows_linear_bwd: K=%d must be a multiple of 64", K); return -1; }
+    if (dx) hipLaunchKernelGGL(rows_linear_bwd_x_kernel, dim3(K / 64, (R + 15) / 16), dim3(256), 0, s, dout, W, dx, R, N, K);
     hipLaunchKernelGGL(rows_linear_bwd_w_kernel, dim3(N), dim3(256), 0, s, dout, x, dW, db, R, N, K);
     LAUNCH_CHECK();
     return 0;
