@@ -47,7 +47,7 @@ def bench(M, N, K, variant, iters=20):
 
 if __name__ == "__main__":
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2]
-    CHECKED = {v for v in variants if v in (0, 4, 5, 10, 11, 12)}
+    CHECKED = {v for v in variants if v in (0, 4, 5, 10, 11, 12, 30)}
     print("%-22s" % "M,N,K" + "".join("  v%-2d us / TF/s (err)     " % v for v in variants))
     for (M, N, K) in SHAPES:
         line = "%-22s" % ("%d,%d,%d" % (M, N, K))
