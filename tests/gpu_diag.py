@@ -70,6 +70,26 @@ def t_linear():
             report("linear prec=%d M=%d N=%d K=%d" % (prec, M, N, K), relerr(c.cpu(), ref), tol)
 
 
+def t_linear_row_ranges():
+    """bf16 nn.Linear through the C ABI at row counts around every tile-dispatch boundary of the narrow-N (768) GEMM:
+    128x128 only, one partial round of 256x256, whole rounds + 128x128 tail rows, ragged last tiles.  Every output
+    row is checked (a wrong row range or a stale tile shows up as an O(1) error in a block of rows)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, K = 768, 768
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.05
+    bias = torch.randn(N, generator=g, device="cuda")
+    wb = w.bfloat16().float()
+    for M in (2047, 2049, 12608, 16385, 18912, 21760, 21761, 25216, 25216 + 37, 50432 + 5):
+        a = torch.randn(M, K, generator=g, device="cuda")
+        c = torch.full((M, N), float("nan"), device="cuda")
+        check(lib().dyt_linear(ptr(a), ptr(w), ptr(bias), ptr(c), M, N, K, 1, stream_ptr()))
+        ref = a.bfloat16().float() @ wb.t() + bias          # same operand rounding; fp32 accumulate on both sides
+        err = (c - ref).abs().amax(dim=1)                       # per row
+        report("linear bf16 rows M=%d (worst row %d)" % (M, int(err.argmax())), float(err.max()), 2e-3)
+        del a, c, ref
+    torch.cuda.empty_cache()
+
+
 def attn_ref(qkv, B, dout=None):
     q3 = qkv.double().reshape(B, 197, 3, 12, 64).permute(2, 0, 3, 1, 4)
     q3 = q3.detach().clone().requires_grad_(dout is not None)

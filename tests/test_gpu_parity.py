@@ -28,6 +28,10 @@ def test_linear_kernels_fp32_and_bf16():
     _run(D.t_linear)
 
 
+def test_linear_row_ranges_across_tile_dispatch():
+    _run(D.t_linear_row_ranges)
+
+
 def test_attention_fwd_bwd_kernels():
     _run(D.t_attention)
 
