@@ -209,13 +209,14 @@ def main():
         ms, n, fl = eng.profile_read(0)
         ms_a, n_a, fl_a = eng.profile_read(1)
         ms_o, n_o, _ = eng.profile_read(2)
+        _, n_kern, _ = eng.profile_read(3)   # kernel launches behind the n GEMMs (PMC traffic is per kernel launch)
         eng.profile(False)
         ach = fl / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_%s_nt_kernel (all epilogues)" % ("bf16" if args.precision == "bf16" else "f32"),
                 "achieved": round(ach, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK[args.precision], 4),
-                "traffic": round(traffic["hbm_bytes_per_launch"]) if traffic and args.precision == "bf16" else None,
+                "traffic": round(traffic["hbm_bytes_per_launch"] * max(n_kern, 1) / max(n, 1)) if traffic and args.precision == "bf16" else None,
                 "traffic_source": "profiles/round1/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 "
-                                  "gfx950 correction), bytes per launch" if traffic else None,
+                                  "gfx950 correction): bytes per kernel launch x kernel launches per GEMM (%d / %d this step)" % (n_kern, n) if traffic else None,
                 "timing_note": "per-kernel durations are taken with the multi-stream overlap switched off (serial launches), "
                                "so they are clean but pessimistic w.r.t. the overlapped schedule that `value` is measured on", "launches_per_step": n, "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                 "avg_launch_ms": round(ms / max(n, 1), 4), "gemm_ms_per_step": round(ms, 3),

@@ -708,6 +708,15 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
+// kernel launches of the bf16 family since the last reset (a logical GEMM may be two launches: bench.py converts
+// the per-kernel-launch PMC traffic to its per-GEMM unit with this)
+static long long g_bf16_kernel_launches = 0;
+long long gemm_kernel_launch_count(int reset) {
+    const long long n = g_bf16_kernel_launches;
+    if (reset) g_bf16_kernel_launches = 0;
+    return n;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi>
 static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int m_begin = 0, int m_end = -1) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
@@ -724,6 +733,7 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi);
+    ++g_bf16_kernel_launches;
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -54,6 +54,7 @@ struct GemmArgs {
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
 int gemm_debug_counters(unsigned long long* out4, int reset);
+long long gemm_kernel_launch_count(int reset);
 int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------

@@ -517,10 +517,15 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
 extern "C" int dyt_profile_enable(dyt_ctx* c, int on) {
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
     c->prof = on != 0;
+    if (on) gemm_kernel_launch_count(1);
     return DYT_OK;
 }
 extern "C" int dyt_profile_read(dyt_ctx* c, int category, double* ms, int64_t* launches, double* flops) {
     if (!c || !ms || !launches || !flops) { set_error("null argument"); return DYT_ERR_ARG; }
+    if (category == 3) {   // bf16 GEMM KERNEL launches since dyt_profile_enable(ctx, 1) (a GEMM may take two)
+        *ms = 0; *flops = 0; *launches = gemm_kernel_launch_count(0);
+        return DYT_OK;
+    }
     DYT_HIP_CHECK(hipDeviceSynchronize());
     double t = 0, f = 0;
     int64_t n = 0;

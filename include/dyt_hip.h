@@ -216,7 +216,9 @@ int dyt_debug_counters(uint64_t* out4, int reset);
 /* bracket every kernel launch with hipEvents on `stream` and accumulate per category */
 int dyt_profile_enable(dyt_ctx* ctx, int on);
 /* categories: 0 gemm (big MFMA GEMMs), 1 attention, 2 everything else.  Returns accumulated
- * milliseconds, launches and algorithmic FLOPs since the last call, then resets.  Synchronises. */
+ * milliseconds, launches and algorithmic FLOPs since the last call, then resets.  Synchronises.
+ * category 3: `launches` = bf16 GEMM KERNEL launches since dyt_profile_enable(ctx, 1) (one GEMM of category 0 may be
+ * two kernel launches with different tiles); ms / flops are 0; no reset, no synchronisation. */
 int dyt_profile_read(dyt_ctx* ctx, int category, double* ms, int64_t* launches, double* flops);
 
 #ifdef __cplusplus
