@@ -240,3 +240,28 @@ def test_scheduling_options_do_not_change_results(precision):
         assert float((r[1] - base[1]).abs().max()) < tol                    # logits
         assert float((r[0][:5] - base[0][:5]).abs().max()) < tol * 10       # losses
         assert float((r[3] - base[3]).norm() / base[3].norm()) < tol * 10   # flat gradient
+
+
+def test_c_abi_error_paths():
+    """Misuse is reported through the status code + dyt_last_error (DyTError in the mirror), never a crash."""
+    from _lib import DyTError
+    from runtime import DyTEngine
+    dev = torch.device("cuda", 0)
+    eng = DyTEngine(10, 8, 0.1, dev, precision="fp32", max_batch=2)
+    x = torch.zeros(3, 3, 224, 224, device=dev)
+    with pytest.raises(DyTError, match="max_batch"):
+        eng.forward(x)                                            # batch 3 > max_batch 2
+    g = torch.zeros(eng.n_train, device=dev)
+    with pytest.raises(DyTError, match="saved forward"):
+        eng.backward(0, torch.zeros(2, 10, device=dev), g)        # no forward with DYT_F_SAVE before
+    with pytest.raises(DyTError, match="g1 and g2"):
+        eng.forward(x[:2], training=True, g1=torch.zeros(12, 2, 196, device=dev))
+    with pytest.raises(DyTError):
+        DyTEngine(10, 65, 0.1, dev)                               # adapter rank > 64
+    with pytest.raises(DyTError, match="multiple of frames"):
+        DyTEngine(10, 8, 0.1, dev, max_batch=6, frames=4)         # video: max_batch must hold whole clips
+    veng = DyTEngine(10, 8, 0.1, dev, precision="fp32", max_batch=4, frames=2)
+    with pytest.raises(DyTError, match="multiple of frames"):
+        veng.forward(x)                                           # 3 frames with 2 frames per clip
+    with pytest.raises(DyTError, match="video model only"):
+        eng.trainable_slice("query_token")
