@@ -110,6 +110,26 @@ template <> __device__ __forceinline__ void gelu_both<__bf16>(float x, float& h,
     h = x * phi;
     gp = fmaf(x, pdf, phi);
 }
+// the same for two elements at once, written on 2-vectors so that the polynomial, the products and the final
+// h / gelu' run as packed-fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32: two elements per issue slot); only the two
+// v_rcp / v_exp and the sign select stay scalar.  Bit-identical to gelu_both<__bf16> per element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_both_x2(f32x2 x, f32x2& h, f32x2& gp) {
+    const f32x2 a = __builtin_elementwise_abs(x);
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.2316419f, 0.2316419f}, a, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 e = __builtin_elementwise_fma(x * x, f32x2{-0.72134752f, -0.72134752f}, f32x2{-1.3257480647f, -1.3257480647f});
+    const f32x2 pdf = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    f32x2 p = __builtin_elementwise_fma(f32x2{1.330274429f, 1.330274429f}, t, f32x2{-1.821255978f, -1.821255978f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.781477937f, 1.781477937f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.356563782f, -0.356563782f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.319381530f, 0.319381530f});
+    const f32x2 tail = pdf * (t * p);
+    const f32x2 om = f32x2{1.0f, 1.0f} - tail;
+    const f32x2 phi = {x[0] >= 0.f ? om[0] : tail[0], x[1] >= 0.f ? om[1] : tail[1]};
+    h = x * phi;
+    gp = __builtin_elementwise_fma(x, pdf, phi);
+}
 // sigmoid exactly as 1/(1+exp(-x)) in fp32 (the form the reference's y_soft > 0.5 test sees)
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 

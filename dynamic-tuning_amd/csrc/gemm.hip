@@ -128,8 +128,17 @@ struct EpiFc1 {
         const size_t o = (size_t)row * ld + col;
         float hv[4], gv[4];
         if (HAS_GP) {
+            if constexpr (sizeof(AT) == 2) {   // two elements per packed-fp32 issue slot
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gelu_both<AT>(a[i] + c.b[i], hv[i], gv[i]);
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 h2, g2;
+                    gelu_both_x2(f32x2{a[i], a[i + 1]} + f32x2{c.b[i], c.b[i + 1]}, h2, g2);
+                    hv[i] = h2[0]; hv[i + 1] = h2[1]; gv[i] = g2[0]; gv[i + 1] = g2[1];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gelu_both<AT>(a[i] + c.b[i], hv[i], gv[i]);
+            }
             store4_nt(gp + o, gv[0], gv[1], gv[2], gv[3]);
         } else {
 #pragma unroll
