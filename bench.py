@@ -82,8 +82,11 @@ def cpu_baseline(args):
     B = 16
     ncores = synth.available_cores()
     torch.set_num_threads(ncores)
-    sd = synth.make_state_dict(args.classes, args.ffn_num, seed=0, kind="bench", gate_bias=math.log(0.7 / 0.3))
+    video = args.video_frames > 1
+    sd = synth.make_state_dict(args.classes, args.ffn_num, seed=0, kind="bench", gate_bias=math.log(0.7 / 0.3), video=video)
     x, y = synth.make_batch(B, args.classes, seed=0)
+    if video:
+        y = y[: B // args.video_frames].contiguous()
     g1, g2 = synth.make_noise(B, seed=2)
     keep = synth.make_dropout_masks(B, args.ffn_num, seed=3)
     opt = {}
@@ -91,7 +94,8 @@ def cpu_baseline(args):
     t_all = time.time()
     for i in range(4):
         t0 = time.time()
-        O.train_step(sd, opt, x, y, g1, g2, keep, lr=1e-3, wd=0.01, scale=0.1, mode="masked", token_target_ratio=0.5)
+        O.train_step(sd, opt, x, y, g1, g2, keep, lr=1e-3, wd=0.01, scale=0.1, mode="masked", token_target_ratio=0.5,
+                     frames=args.video_frames if video else 1)
         times.append(time.time() - t0)
         log("cpu baseline step %d: %.2f s" % (i, times[-1]))
         if time.time() - t_all > 60 and len(times) >= 2:
@@ -104,8 +108,9 @@ def cpu_baseline(args):
     except Exception:
         pass
     return {"value": round(B / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/dyt_oracle.py train_step (reference-as-written masked step, fp32), B=16, %d timed steps "
-                      "after 1 warm-up, %.2f s/step, %s" % (len(times) - 1, dt, model)}
+            "sample": "oracle/dyt_oracle.py train_step (reference-as-written masked step, fp32%s), B=16, %d timed steps "
+                      "after 1 warm-up, %.2f s/step, %s" % (", video model: %d clips x %d frames" % (B // args.video_frames, args.video_frames)
+                                                            if video else "", len(times) - 1, dt, model)}
 
 
 def log(*a):
