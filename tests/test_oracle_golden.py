@@ -185,9 +185,11 @@ def test_video_trainable_grads(video):
     stride = int(g["meta_row_stride"])
     for n, gr in grads.items():
         ref_norm = float(g["gradnorm/" + n])
-        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-9, n
+        # absolute floor 1e-7: attentive_blocks.norm_k.bias has an exactly-zero true gradient (a constant added to every
+        # key shifts all scores of a clip equally); what is stored is round-off (2.7e-9) that depends on the BLAS threading
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-7, n
         if "grad/" + n in g:
-            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-9, n
+            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-7, n
         if "gradrows/" + n in g:
             ref = g["gradrows/" + n]
             assert np.abs(gr[::stride].numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, n
