@@ -355,6 +355,46 @@ def t_autograd_api():
     report("autograd-API grads vs golden (worst rel L2)", worst, 2e-3, wname)
 
 
+def t_video_autograd_api():
+    """video module API + autograd bridge (model(clips) twice, loss.backward()) vs the reference's gradients."""
+    from models.losses import AdaLoss
+    import torch.nn.functional as F
+    g = dict(np.load(os.path.join(ROOT, "tests/golden/video_step.npz")))
+    clips, frames, C, r, seed = (int(g["meta_clips"]), int(g["meta_frames"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]),
+                                 int(g["meta_seed"]))
+    B = clips * frames
+    x, _ = synth.make_batch(B, C, seed=seed)
+    xc = x.reshape(clips, frames, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous().cuda()
+    ys = torch.from_numpy(g["targets"]).cuda()
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    model, sd = build_video_model(g, "fp32", "masked")
+    model.train()
+    crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=float(g["meta_target_ratio"]), token_loss_ratio=2.0,
+                   token_minimal=0.0, token_minimal_weight=0.0)
+    out, tok = model(xc, gumbel=(g1[0], g2[0]), keep_mask=keep[0])
+    tout, _ = model(xc, complete_model=True, gumbel=(g1[1], g2[1]), keep_mask=keep[1])
+    kl = F.kl_div(F.log_softmax(out, -1), F.log_softmax(tout.detach(), -1), reduction="batchmean", log_target=True)
+    loss, d = crit(dict(prediction=out, **tok), ys)
+    loss = loss + crit.base_criterion(tout, ys) + kl
+    loss.backward()
+    report("video autograd-API loss vs golden", abs(float(loss) - float(g["stat_loss"])), 1e-4 * float(g["stat_loss"]))
+    stride = int(g["meta_row_stride"])
+    worst, wname = 0.0, ""
+    params = dict(model.named_parameters())
+    for key, ref in g.items():
+        if key.startswith("grad/") or key.startswith("gradrows/"):
+            n = key.split("/", 1)[1]
+            got = params[n].grad.detach().cpu()
+            if key.startswith("gradrows/"):
+                got = got[::stride]
+            ref = torch.from_numpy(ref)
+            e = float((got - ref).norm() / max(float(ref.norm()), 1e-4))
+            if e > worst:
+                worst, wname = e, n
+    report("video autograd-API grads (rel L2, worst tensor)", worst, 2e-3, wname)
+
+
 def t_perf_smoke():
     """Tiny timing probe at B=32 (not the bench): ms/step for both precisions."""
     from engine_finetune import FusedAdamW, train_step

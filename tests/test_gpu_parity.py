@@ -78,6 +78,10 @@ def test_video_full_clip_length_vs_oracle():
     assert torch.equal(swapped.flip(0), got)
 
 
+def test_video_module_api_autograd_bridge():
+    _run(D.t_video_autograd_api)
+
+
 def test_module_api_autograd_bridge():
     _run(D.t_autograd_api)
 
