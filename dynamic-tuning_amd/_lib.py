@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
-F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS = 1, 2, 4, 8, 16
+F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD = 1, 2, 4, 8, 16, 32
 OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0 = 1, 2, 3
 
 # enum dyt_param (include/dyt_hip.h)

@@ -1054,7 +1054,7 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     if (rc) return rc;
     float* gt = par ? c->grad2 : grad_flat;  // teacher-pass gradients
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
-    DYT_HIP_CHECK(hipMemsetAsync(grad_flat, 0, (size_t)c->n_train * sizeof(float), s));
+    if (!(flags & DYT_F_ACCUM_GRAD)) DYT_HIP_CHECK(hipMemsetAsync(grad_flat, 0, (size_t)c->n_train * sizeof(float), s));
     if (par) DYT_HIP_CHECK(hipMemsetAsync(c->grad2, 0, (size_t)c->n_train * sizeof(float), s2));
     rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s);
     if (rc) return rc;

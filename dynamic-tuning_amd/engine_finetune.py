@@ -66,7 +66,8 @@ def allreduce_grads(engine, group=None):
 
 
 def train_step(model, samples, targets, optimizer, criterion=None, losses_out=None, gumbel=None, keep_mask=None,
-               seed=0, target_ratio=None, token_minimal=None, token_minimal_weight=None):
+               seed=0, target_ratio=None, token_minimal=None, token_minimal_weight=None, accumulate=False, update=True,
+               accum_iter=1):
     """One fused step (reference engine_finetune.py:47-79) on device tensors; returns the device
     tensor of loss components [loss, base, token, teacher, distillation, keep ratio, kept, 0]."""
     m = getattr(model, "module", model)
@@ -80,9 +81,10 @@ def train_step(model, samples, targets, optimizer, criterion=None, losses_out=No
     if gumbel is not None:
         g1, g2 = gumbel
     out = eng.step_fwd_bwd(samples, targets, tr, ratio, tmin, tw, masked_dense=(m.train_mode == "masked"), g1=g1, g2=g2,
-                           keep_mask=keep_mask, seed=seed, losses=losses_out)
-    scale = allreduce_grads(eng)
-    optimizer.step(grad_scale=scale)
+                           keep_mask=keep_mask, seed=seed, losses=losses_out, accumulate=accumulate)
+    if update:   # reference :66-76: `loss /= accum_iter`, optimizer step on every accum_iter-th micro-batch
+        scale = allreduce_grads(eng)
+        optimizer.step(grad_scale=scale / accum_iter)
     return out
 
 
@@ -93,8 +95,9 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     misc.py:252-272, only exists for its fp16 autocast)."""
     if not isinstance(optimizer, FusedAdamW):
         raise DyTError("train_one_epoch drives the fused HIP step; pass engine_finetune.FusedAdamW(model, ...)")
-    if mixup_fn is not None or (args is not None and getattr(args, "accum_iter", 1) != 1):
-        raise NotImplementedError("mixup / gradient accumulation are not used by train_IN21K.sh / train_vtab.sh")
+    if mixup_fn is not None:
+        raise NotImplementedError("mixup is not used by train_IN21K.sh / train_vtab.sh / train_video.sh")
+    accum_iter = max(1, int(getattr(args, "accum_iter", 1) or 1)) if args is not None else 1
     model.train(True)
     m = getattr(model, "module", model)
     print_freq = 20
@@ -108,10 +111,12 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     lr = optimizer.param_groups[0]["lr"]
     for it, batch in enumerate(data_loader):
         samples, targets = batch[0], batch[1]
-        lr = lr_sched.adjust_learning_rate(optimizer, it / nsteps + epoch, args)
+        if it % accum_iter == 0:   # per-iteration schedule, reference :43-46
+            lr = lr_sched.adjust_learning_rate(optimizer, it / nsteps + epoch, args)
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
-        train_step(model, samples, targets, optimizer, criterion, losses_out=step_losses, seed=seed0 + it)
+        train_step(model, samples, targets, optimizer, criterion, losses_out=step_losses, seed=seed0 + it,
+                   accumulate=(it % accum_iter != 0), update=((it + 1) % accum_iter == 0), accum_iter=accum_iter)
         acc += step_losses
         pending += 1
         if (it + 1) % print_freq == 0 or it + 1 == nsteps:

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from _lib import (Config, DyTError, F_COMPLETE, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TRAINING, PREC_BF16, PREC_FP32,
+from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TRAINING, PREC_BF16, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
@@ -129,10 +129,11 @@ class DyTEngine:
 
     def step_fwd_bwd(self, images, targets, target_ratio=0.5, loss_ratio=2.0, token_minimal=0.0,
                      token_minimal_weight=0.0, masked_dense=False, g1=None, g2=None, keep_mask=None, seed=0,
-                     logits_s=None, logits_t=None, token_select=None, losses=None):
-        """engine_finetune.py:47-76 up to (not including) the optimizer step; gradients land in self.grad."""
+                     logits_s=None, logits_t=None, token_select=None, losses=None, accumulate=False):
+        """engine_finetune.py:47-76 up to (not including) the optimizer step; gradients land in self.grad
+        (accumulate=True: are added to it -- gradient accumulation over micro-batches)."""
         B = images.shape[0]
-        flags = F_MASKED_DENSE if masked_dense else 0
+        flags = (F_MASKED_DENSE if masked_dense else 0) | (F_ACCUM_GRAD if accumulate else 0)
         out = self.losses if losses is None else losses
         with torch.cuda.device(self.device):
             check(self.L.dyt_step_fwd_bwd(self.h, ptr(images), ptr(targets), B, flags, ptr(self.flat), ptr(g1), ptr(g2),

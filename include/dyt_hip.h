@@ -43,6 +43,8 @@ extern "C" {
 #define DYT_F_MASKED_DENSE 8   /* student pass computes the MLP for every token and multiplies by the
                                   mask, exactly as the reference trains (vision_transformer_IN21K.py:159-162);
                                   default is the compacted MLP of models/model_speed_test.py:274-310 */
+#define DYT_F_ACCUM_GRAD 32    /* dyt_step_fwd_bwd: add to grad_flat instead of overwriting it -- gradient accumulation over
+                                  accum_iter micro-batches (engine_finetune.py:43-46,66-76; fold 1/accum_iter into dyt_adamw's grad_scale) */
 #define DYT_F_GATE_ALWAYS 16   /* also evaluate the token dispatcher in a COMPLETE pass (the reference does,
                                   and discards it, :150-152) so token_select/token_logits are returned */
 

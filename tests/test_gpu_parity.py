@@ -298,3 +298,22 @@ def test_full_size_backward_is_linear_and_batch_equivariant():
         lb, ab = m(x.flip(0).contiguous())
     assert torch.equal(lb.flip(0), la)
     assert torch.equal(ab["token_select"].flip(0), aa["token_select"])
+
+
+def test_gradient_accumulation_flag():
+    """DYT_F_ACCUM_GRAD (engine_finetune.py:43-46,66-76 accum_iter): two micro-batches accumulated == sum of their gradients."""
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "step_r8.npz")))
+    model, sd = D.build_model(g, "fp32", "masked")
+    model.train()
+    B, C = 3, int(g["meta_num_classes"])
+    eng = model.engine(B, torch.device("cuda", 0))
+    grads = []
+    batches = [synth.make_batch(B, C, seed=40 + i) for i in range(2)]
+    for i, (x, y) in enumerate(batches):
+        eng.step_fwd_bwd(x.cuda(), y.cuda(), seed=100 + i)
+        grads.append(eng.grad.clone())
+    for i, (x, y) in enumerate(batches):
+        eng.step_fwd_bwd(x.cuda(), y.cuda(), seed=100 + i, accumulate=(i > 0))
+    ref = grads[0] + grads[1]
+    assert float(ref.abs().max()) > 0
+    assert float((eng.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
