@@ -722,7 +722,7 @@ int launch_reduce_partials(const float* partial, int nparts, int stride, float* 
 // adapter weight gradients:  C[c][j] = sum_m X[m][c] Y[m][j]   (+ column sums of X in j = 64)
 // ------------------------------------------------------------------------------------------
 constexpr int WG_J = 80;        // 64 adapter columns + the ones column (+ pad)
-constexpr int WG_CHUNK = 512;   // tokens per workgroup
+constexpr int WG_CHUNK = 512;   // minimum tokens per workgroup (the partial buffers are sized for M / 512 chunks)
 
 // bf16: MFMA 16x16x32 with the token dimension as K; tiles are transposed while staged to LDS.
 // 64 tokens per step; the next step's rows are prefetched into registers while the current step's
@@ -731,7 +731,7 @@ constexpr int WG_CHUNK = 512;   // tokens per workgroup
 // ones ROW of the A operand, computed by wave 0 of the first channel block (-> partial[..][768][j]).
 constexpr int WG_ROWS = D + 8;  // partial rows per chunk: 768 channels + 1 row of Y column sums (+pad)
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Y, int M,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, int chunk) {
     constexpr int TS = 64;        // tokens per step
     constexpr int LDT = TS + 8;   // bf16 per LDS row (144 B: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) bf16 Xt[128 * LDT];
@@ -739,8 +739,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict_
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * 128;
-    const int m0 = blockIdx.y * WG_CHUNK;
-    const int mend = min(m0 + WG_CHUNK, M);
+    const int m0 = blockIdx.y * chunk;
+    const int mend = min(m0 + chunk, M);
     f32x4 acc[2][5], accy[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -831,18 +831,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict_
 
 // fp32 exact variant: 64 channels x 64 columns per workgroup, 4x4 outputs per thread
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, int chunk) {
     __shared__ float Xs[16][64 + 4];
     __shared__ float Ys[16][64 + 4];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * 64;
-    const int m0 = blockIdx.y * WG_CHUNK;
+    const int m0 = blockIdx.y * chunk;
     const int ty = tid >> 4, tx = tid & 15;
     const int lr = tid >> 4, lc = (tid & 15) * 4;
     float acc[4][4] = {};
     float xs[4] = {0.f, 0.f, 0.f, 0.f};
     float ys[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int tb = m0; tb < min(m0 + WG_CHUNK, M); tb += 16) {
+    for (int tb = m0; tb < min(m0 + chunk, M); tb += 16) {
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yv = xv;
         if (tb + lr < M) {
             xv = *reinterpret_cast<const float4*>(X + (size_t)(tb + lr) * D + c0 + lc);
@@ -898,13 +898,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchun
 }
 
 int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
-    const int nchunks = (a.M + WG_CHUNK - 1) / WG_CHUNK;
+    // tokens per workgroup: at least WG_CHUNK, and large enough that the (channel blocks x chunks) grid is ONE round
+    // of the 256 CUs (B=128: 6 x 50 = 300 workgroups would leave a 44-workgroup second round; 6 x 40 does not)
+    const int cblocks = precision == 0 ? D / 64 : D / 128;
+    const int want = (a.M + 256 / cblocks - 1) / (256 / cblocks);
+    const int chunk = max(WG_CHUNK, (want + 63) / 64 * 64);
+    const int nchunks = (a.M + chunk - 1) / chunk;
     if (precision == 0)
         hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 64, nchunks), dim3(256), 0, s, (const float*)a.X, (const float*)a.Y,
-                           a.M, a.partial);
+                           a.M, a.partial, chunk);
     else
         hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks), dim3(256), 0, s, (const bf16*)a.X, (const bf16*)a.Y,
-                           a.M, a.partial);
+                           a.M, a.partial, chunk);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (a.r + 1) + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.r,
                        a.out_w, a.sc, a.sj, a.alpha, a.out_xsum, a.alpha_x, a.out_ysum, a.alpha_y);
     LAUNCH_CHECK();
