@@ -177,7 +177,15 @@ struct EpiGeluBwd {
     const AT* gp; AT* out; int ld;   // gp = gelu'(z) saved by the fc1 epilogue
     typedef NoCtx Col; typedef Raw4<AT> Pre;
     __device__ __forceinline__ Col col_init(int) const { return {}; }
-    __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(gp + (size_t)row * ld + col); }
+    __device__ __forceinline__ Pre pre(int row, int col) const {   // gelu'(z) is read exactly once: streaming load
+        if constexpr (sizeof(AT) == 2) {
+            Pre p;
+            p.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(gp + (size_t)row * ld + col));
+            return p;
+        } else {
+            return load_raw4(gp + (size_t)row * ld + col);
+        }
+    }
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre& p) const {
         float g[4];
         p.get(g);
