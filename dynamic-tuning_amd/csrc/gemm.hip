@@ -164,7 +164,7 @@ struct EpiFc2 {
     }
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         const float h0 = a[0] + c.b[0], h1 = a[1] + c.b[1], h2 = a[2] + c.b[2], h3 = a[3] + c.b[3];
-        if (h_out) store4(h_out + (size_t)row * D + col, h0, h1, h2, h3);
+        if (h_out) store4_nt(h_out + (size_t)row * D + col, h0, h1, h2, h3);   // read again only by the backward pass
         float r[4];
         p.r.get(r);
         store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);

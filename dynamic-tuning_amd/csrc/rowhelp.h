@@ -15,6 +15,15 @@ struct Row12 {
             v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
         }
     }
+    // streaming variant: saved activations that the backward pass reads exactly once (keeps them out of the L2 lines
+    // the concurrently running GEMMs are re-using)
+    __device__ __forceinline__ void load_nt(const float* p, int lane) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i * 256 + lane * 4));
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+        }
+    }
     template <class T>
     __device__ __forceinline__ void load_at(const T* p, int lane) {
 #pragma unroll

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     if (row >= rows) return;
     Row12 g, xr, wr;
     g.load_at(dy + (size_t)row * D, lane);
-    xr.load(x + (size_t)row * D, lane);
+    xr.load_nt(x + (size_t)row * D, lane);   // residual snapshot of the forward pass: last use
     wr.load(w, lane);
     ln_bwd_row(g, xr, wr, stats[row]);
     if (base) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         const int b = t / NT, n = t - b * NT;
         Row12 du, ur;
         const bool need_u = a.dA2 || a.gate_w;
-        if (need_u) ur.load(a.u + (size_t)t * D, lane);
+        if (need_u) ur.load_nt(a.u + (size_t)t * D, lane);   // saved u of the forward pass: last use
         if (a.write_du && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
         else if (a.write_du && n == 0) du.load(a.g_cls + (size_t)b * D, lane);
         else {
