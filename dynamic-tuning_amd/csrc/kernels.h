@@ -200,12 +200,6 @@ struct WgradArgs {
     float* out_ysum = nullptr; float alpha_y = 0.f;   // out_ysum[j] += alpha_y * sum_m Y[m][j], j < r
 };
 int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s);
-// out[j] += alpha * sum_m Y[m][j], j < r  (Y [M,64] AT)
-int launch_colsum64(int precision, const void* Y, int M, int r, float* out, float alpha, hipStream_t s);
-
-int launch_fill_f32(float* p, float v, int64_t n, hipStream_t s);
-int launch_iota(int* p, int n, hipStream_t s);
-
 // ------------------------------------------------------------------------------------------
 // video model: attentive pooling head (pool.hip)
 // ------------------------------------------------------------------------------------------

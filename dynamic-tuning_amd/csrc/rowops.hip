@@ -916,42 +916,4 @@ int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
     return 0;
 }
 
-template <class AT>
-__global__ __launch_bounds__(256) void colsum64_kernel(const AT* __restrict__ Y, int M, int r, float* __restrict__ out,
-                                                       float alpha) {
-    __shared__ float red[4][64];
-    const int j = threadIdx.x & 63, rr = threadIdx.x >> 6;
-    float acc = 0.f;
-    for (int m = blockIdx.x * 4 + rr; m < M; m += gridDim.x * 4) acc += to_f32(Y[(size_t)m * RP + j]);
-    red[rr][j] = acc;
-    __syncthreads();
-    if (rr == 0 && j < r) atomicAdd(out + j, alpha * (red[0][j] + red[1][j] + red[2][j] + red[3][j]));
-}
-int launch_colsum64(int precision, const void* Y, int M, int r, float* out, float alpha, hipStream_t s) {
-    const int grid = min(64, (M + 3) / 4);
-    if (precision == 0) hipLaunchKernelGGL(colsum64_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)Y, M, r, out, alpha);
-    else hipLaunchKernelGGL(colsum64_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)Y, M, r, out, alpha);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-__global__ void fill_f32_kernel(float* p, float v, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-int launch_fill_f32(float* p, float v, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
-    LAUNCH_CHECK();
-    return 0;
-}
-__global__ void iota_kernel(int* p, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = i;
-}
-int launch_iota(int* p, int n, hipStream_t s) {
-    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
-    LAUNCH_CHECK();
-    return 0;
-}
-
 }  // namespace dyt
