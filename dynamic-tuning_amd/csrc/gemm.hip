@@ -673,6 +673,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
     }
 }
 
+}  // namespace dyt
+#include "gemm_bpre.h"
+namespace dyt {
+
 // ------------------------------------------------------------------------------------------
 // fp32 exact kernel (vector ALU): 64x64x16 tile, 256 threads, 4x4 outputs per thread
 // ------------------------------------------------------------------------------------------
@@ -755,12 +759,42 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
     return 0;
 }
 
+template <int ABL, class Epi>
+static int launch_bf16_bpre(const GemmArgs& a, const Epi& epi, hipStream_t s, int m_begin = 0, int m_end = -1) {
+    if (m_end < 0) m_end = a.M;
+    if (m_end <= m_begin) return 0;
+    if (a.K % 256 != 0 || a.N % 256 != 0) { set_error("gemm_bpre: K=%d and N=%d must be multiples of 256", a.K, a.N); return -1; }
+    const int grid = ((m_end - m_begin + 127) / 128) * (a.N / 256);
+    hipLaunchKernelGGL((gemm_bf16_bpre_kernel<Epi, ABL>), dim3(grid), dim3(256), 0, s, static_cast<const bf16*>(a.A),
+                       static_cast<const bf16*>(a.W), m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi);
+    ++g_bf16_kernel_launches;
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s) {
+    if (N % 16 != 0 || K % 32 != 0) { set_error("preshuffle: N=%d %% 16, K=%d %% 32 required", N, K); return -1; }
+    const size_t chunks = (size_t)N * K / 8;
+    hipLaunchKernelGGL(preshuffle_w_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const bf16*>(W), static_cast<bf16*>(Wp), N, K);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int g_big_tile_min_n = 2304;
+static int g_use_bpre = 1;        // wide-N GEMMs with a pre-shuffled frozen weight: 128x256 tiles, 2 workgroups / CU (gemm_bpre.h)
 static int g_split_rows = 1;      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
 
 template <class Epi>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
+    // Wide-N GEMMs against a frozen weight: the pre-shuffled-weight kernel (128x256 tiles, two workgroups per CU, the
+    // weight never touches LDS).  In the step: 28.10 vs 28.40 ms with the 256x256 kernel; routing the N = 768 GEMMs
+    // through it as well gains another 0.5 % wall time but costs 8 % serial GEMM time, so they keep the split-row scheme.
+    if (a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) {
+        GemmArgs b = a; b.W = a.Wp;
+        return launch_bf16_bpre<0>(b, epi, s);
+    }
     if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
     if (a.N % 256 == 0 && a.K >= 256 && g_split_rows) {
         // Narrow-N GEMMs (N = 768): per row, 256x256 tiles are ~1.6x cheaper than 128x128 tiles (half the L2->LDS bytes
@@ -845,7 +879,17 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 9: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, epi, s);
         case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
-        case 30: return run_bf16(a, epi, s);   // the product dispatch (incl. the split-row scheme for narrow N)
+        case 30: return run_bf16(a, epi, s);
+        case 70: case 79: case 71: {   // pre-shuffled-weight kernel (test-only: shuffles W into a cached scratch buffer first)
+            static bf16* wp = nullptr; static size_t wp_elems = 0;
+            const size_t need = (size_t)N * K;
+            if (need > wp_elems) { if (wp) hipFree(wp); DYT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), need * 2)); wp_elems = need; }
+            if (launch_preshuffle_w(W, wp, N, K, s)) return -2;
+            GemmArgs b = a; b.W = wp;
+            if (variant == 70) return launch_bf16_bpre<0>(b, epi, s);
+            if (variant == 79) return launch_bf16_bpre<9>(b, epi, s);
+            return launch_bf16_bpre<0>(b, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
+        }   // the product dispatch (incl. the split-row scheme for narrow N)
         case 15: return launch_bf16_cfg<256, 256, 2, 4, 3>(a, epi, s);
         case 16: return launch_bf16_cfg<256, 256, 2, 4, 6>(a, epi, s);
         case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);

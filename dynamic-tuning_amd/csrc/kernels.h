@@ -28,6 +28,7 @@ enum EpiKind {
 struct GemmArgs {
     const void* A = nullptr;      // [M,K]  AT
     const void* W = nullptr;      // [N,K]  AT
+    const void* Wp = nullptr;     // optional: the same (frozen) weight pre-shuffled into MFMA fragment order (gemm_bpre.h)
     int M = 0, N = 0, K = 0;
     const int* m_dev = nullptr;   // device-side count of valid rows (<= M), or null
     const int* a_map = nullptr;   // gather: logical A row r is read from A[a_map[r]] (null = identity)
@@ -53,6 +54,8 @@ struct GemmArgs {
 };
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
+// bf16 W [N,K] row-major -> fragment order for the pre-shuffled-weight kernel (N % 16 == 0, K % 32 == 0)
+int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s);
 int gemm_debug_counters(unsigned long long* out4, int reset);
 long long gemm_kernel_launch_count(int reset);
 int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s);

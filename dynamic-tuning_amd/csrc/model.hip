@@ -92,6 +92,7 @@ using namespace dyt;
 struct LayerW {  // frozen, library-owned
     float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;
     void *qkv_w, *qkv_wT, *proj_w, *proj_wT, *fc1_w, *fc1_wT, *fc2_w, *fc2_wT;
+    void *qkv_wp = nullptr, *fc1_wp = nullptr, *fc2_wTp = nullptr;   // bf16 mode: MFMA-fragment-order twins (gemm_bpre.h)
 };
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
@@ -203,6 +204,10 @@ static void layout(dyt_ctx* c, bool dry) {
         w.proj_w = carve_at(c, (size_t)D * D, dry); w.proj_wT = carve_at(c, (size_t)D * D, dry);
         w.fc1_w = carve_at(c, (size_t)DM * D, dry); w.fc1_wT = carve_at(c, (size_t)DM * D, dry);
         w.fc2_w = carve_at(c, (size_t)DM * D, dry); w.fc2_wT = carve_at(c, (size_t)DM * D, dry);
+        if (c->prec != 0) {
+            w.qkv_wp = carve_at(c, (size_t)3 * D * D, dry); w.fc1_wp = carve_at(c, (size_t)DM * D, dry);
+            w.fc2_wTp = carve_at(c, (size_t)DM * D, dry);
+        }
     }
     c->ad_down_w = carve_at(c, depth * RP * D, dry);
     c->ad_down_wT = carve_at(c, depth * RP * D, dry);
@@ -451,15 +456,27 @@ extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src
         case DYT_P_PE_B: return copy_f32(c->pe_b, src, D, s);
         case DYT_P_LN1_W: return copy_f32(w->ln1_w, src, D, s);
         case DYT_P_LN1_B: return copy_f32(w->ln1_b, src, D, s);
-        case DYT_P_QKV_W: return set_matrix(c, src, w->qkv_w, w->qkv_wT, 3 * D, D, s);
+        case DYT_P_QKV_W: {
+            int rc = set_matrix(c, src, w->qkv_w, w->qkv_wT, 3 * D, D, s);
+            if (!rc && w->qkv_wp) rc = launch_preshuffle_w(w->qkv_w, w->qkv_wp, 3 * D, D, s);
+            return rc;
+        }
         case DYT_P_QKV_B: return copy_f32(w->qkv_b, src, 3 * D, s);
         case DYT_P_PROJ_W: return set_matrix(c, src, w->proj_w, w->proj_wT, D, D, s);
         case DYT_P_PROJ_B: return copy_f32(w->proj_b, src, D, s);
         case DYT_P_LN2_W: return copy_f32(w->ln2_w, src, D, s);
         case DYT_P_LN2_B: return copy_f32(w->ln2_b, src, D, s);
-        case DYT_P_FC1_W: return set_matrix(c, src, w->fc1_w, w->fc1_wT, DM, D, s);
+        case DYT_P_FC1_W: {
+            int rc = set_matrix(c, src, w->fc1_w, w->fc1_wT, DM, D, s);
+            if (!rc && w->fc1_wp) rc = launch_preshuffle_w(w->fc1_w, w->fc1_wp, DM, D, s);
+            return rc;
+        }
         case DYT_P_FC1_B: return copy_f32(w->fc1_b, src, DM, s);
-        case DYT_P_FC2_W: return set_matrix(c, src, w->fc2_w, w->fc2_wT, D, DM, s);
+        case DYT_P_FC2_W: {
+            int rc = set_matrix(c, src, w->fc2_w, w->fc2_wT, D, DM, s);
+            if (!rc && w->fc2_wTp) rc = launch_preshuffle_w(w->fc2_wT, w->fc2_wTp, DM, D, s);   // fc2^T: [3072, 768]
+            return rc;
+        }
         case DYT_P_FC2_B: return copy_f32(w->fc2_b, src, D, s);
         case DYT_P_NORM_W: return copy_f32(c->norm_w, src, D, s);
         case DYT_P_NORM_B: return copy_f32(c->norm_b, src, D, s);
@@ -727,7 +744,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         if (!(share0 && l == 0)) {
             RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s));
             {
-                GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
+                GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
                 a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
                 RUN_GEMM(EPI_QKV, a);
             }
@@ -787,7 +804,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // MLP on the kept (or all / cls) tokens, scatter-add into the residual stream
         const int* kdev = (dense || tail) ? nullptr : L.total;
         {
-            GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
+            GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr;
             RUN_GEMM(EPI_FC1, a);
         }
@@ -905,7 +922,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         if (!first) {
             const void* A_dh = need_dH ? (const void*)T.dH : A_g;
             {
-                GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
+                GemmArgs a; a.A = A_dh; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;
                 RUN_GEMM(EPI_GELU_BWD, a);
             }

@@ -193,16 +193,17 @@ def test_token_select_module_standalone():
 
 
 def test_gemm_variants_full_occupancy_bitwise():
-    """Regression for an LDS-DMA race that only shows when every CU is busy: the 256x256 pipelined GEMM
+    """Regression for an LDS-DMA race that only shows when every CU is busy: the 256x256 pipelined GEMM, the
+    pre-shuffled-weight GEMM (variant 70: weight fragments straight from global memory, hand-counted vmcnt waits)
     and the 128x128 GEMM accumulate in the same k order, so their bf16 outputs must be BITWISE equal
-    on every row at the bench's full size, run after run; both must match an fp32 reference."""
+    on every row at the bench's full size, run after run; all must match an fp32 reference."""
     from _lib import check, lib, ptr, stream_ptr
     for (M, N, K) in [(25216, 2304, 768), (17690, 3072, 768), (25216, 768, 3072)]:
         g = torch.Generator(device="cuda").manual_seed(M + N)
         a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
         outs = []
-        for variant in (0, 10, 10, 10):
+        for variant in (0, 10, 10, 10, 70, 70, 70, 30):
             c = torch.zeros(2 * M, N, device="cuda", dtype=torch.bfloat16)
             check(lib().dyt_gemm_bf16_raw(ptr(a), ptr(w), ptr(c), M, N, K, variant, stream_ptr()))
             torch.cuda.synchronize()
