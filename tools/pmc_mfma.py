@@ -15,7 +15,7 @@ import sys
 acc = {}
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    fam = "gemm_bf16_nt_kernel" if "gemm_bf16_nt_kernel" in k else ("attn_" + re.search(r"attn_(\w+?)_bf16", k).group(1) if "attn_" in k and "bf16" in k else None)
+    fam = "gemm_bf16 (nt + bpre kernels)" if "gemm_bf16_" in k else ("attn_" + re.search(r"attn_(\w+?)_bf16", k).group(1) if "attn_" in k and "bf16" in k else None)
     if fam is None:
         continue
     d = acc.setdefault(fam, {})
