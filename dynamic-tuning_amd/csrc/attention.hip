@@ -16,7 +16,7 @@
 //     permutation, so P never moves between lanes;
 //   * the same holds for every product of the backward pass (two kernels: dQ per query tile,
 //     dK/dV per key tile -- no atomics, deterministic).
-// exact path (fp32 vector ALU): one thread per query / key row -- the parity mode.
+// exact path (fp32 operands on the matrix cores, v_mfma_f32_32x32x2_f32): the parity mode, same tiling.
 #include "kernels.h"
 
 namespace dyt {
@@ -343,103 +343,186 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// exact fp32 kernels (vector ALU)
+// exact fp32 kernels on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulate, one
+// rounding per product = an fmaf chain) -- the parity mode.
+//
+// Same decomposition as the bf16 kernels (one 32-row query / key tile per wave, 7 waves, the full 32 x 224 score
+// block of a tile in registers, scores transposed so the softmax is lane-local, C/D layout of one product = B
+// operand of the next).  The operand of a 32x32x2 MFMA is ONE fp32 per lane (lane l: row l & 31, k = l >> 5), so:
+//   * a row fragment (k = head channel d) is a ds_read_b128 of 4 consecutive d -- lanes 0..31 take d < 32, lanes
+//     32..63 d >= 32, register t of the chunk feeds MFMA t; both operands use the same assignment, only the order in
+//     which the 64 channels are accumulated is permuted.  Row stride 68 floats: conflict-free for that read;
+//   * a TRANSPOSED fragment (k = key / query index, rows = d) is a ds_read_b32 down a column of the same row-major
+//     image with the lanes along d -- no transposed LDS copies at all (the bf16 kernels need two).
+// Pad rows (197..223) are zero-filled so that 0 * pad stays 0.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+constexpr int FLD = 68;                      // fp32 per LDS row (272 B)
+constexpr int F_IMG = NPAD * FLD * 4;        // 60928 B
+#define MFMA32F(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// stage a [197][64] fp32 matrix (row stride `ld` in global) into a row-major LDS image with row stride LD; rows >= 197 zero
+template <int NTHREADS, int LD>
+__device__ __forceinline__ void stage_rows_f32(const float* __restrict__ src, int ld, float* img, int tid) {
+    for (int t = tid; t < NPAD * 16; t += NTHREADS) {
+        const int r = t >> 4, c = t & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < NT) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c * 4);
+        *reinterpret_cast<float4*>(img + r * LD + c * 4) = v;
+    }
+}
+// the 32 channels [hi*32, hi*32+32) of one global row: the B operand of a row-fragment product, register s <-> d = hi*32 + s
+__device__ __forceinline__ void load_half_row(const float* __restrict__ p, float (&o)[32]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c * 4);
+        o[4 * c] = v.x; o[4 * c + 1] = v.y; o[4 * c + 2] = v.z; o[4 * c + 3] = v.w;
+    }
+}
+// acc[rows of img tile][cols of breg] += sum_d img[row0 + (lane&31)][d] * breg[d]   (d permuted as described above)
+__device__ __forceinline__ void mma_rowfrag(f32x16& acc, const float* img, int row0, int l31, int hi, const float (&breg)[32]) {
+    const float* rp = img + (row0 + l31) * FLD + hi * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(rp + c * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = MFMA32F(a[t], breg[4 * c + t], acc);
+    }
+}
+__device__ __forceinline__ void zero16(f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+}
+
+__global__ __launch_bounds__(448) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, float* __restrict__ out,
                                                            float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
-    float* Vs = Ks + NT * HD;
+    float* Vs = reinterpret_cast<float*>(smem + F_IMG);   // row stride 64: only read down columns
     const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
-    const int tid = threadIdx.x;
-    const float4* k4 = reinterpret_cast<const float4*>(k + (size_t)bh * NT * HD);
-    const float4* v4 = reinterpret_cast<const float4*>(v + (size_t)bh * NT * HD);
-    for (int t = tid; t < NT * HD / 4; t += 256) {
-        reinterpret_cast<float4*>(Ks)[t] = k4[t];
-        reinterpret_cast<float4*>(Vs)[t] = v4[t];
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_rows_f32<448, FLD>(k + (size_t)bh * NT * HD, HD, Ks, tid);
+    stage_rows_f32<448, HD>(v + (size_t)bh * NT * HD, HD, Vs, tid);
     __syncthreads();
-    if (tid >= NT) return;
-    float qv[HD];
-    const float* qp = q + ((size_t)bh * NT + tid) * HD;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);
+    float qf[32];
+    load_half_row(q + ((size_t)bh * NT + qr) * HD + hi * 32, qf);
+    f32x16 st[7];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) qv[d] = qp[d];
+    for (int kt = 0; kt < 7; ++kt) {
+        zero16(st[kt]);
+        mma_rowfrag(st[kt], Ks, kt * 32, l31, hi, qf);   // S^T[key][q]
+    }
+    // st[kt][r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*hi][q = l31]; mask the pad keys
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = 192 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= NT) st[6][r] = -INFINITY;
+    }
     float m = -INFINITY;
-    for (int j = 0; j < NT; ++j) {
-        float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) s = fmaf(qv[d], Ks[j * HD + d], s);
-        m = fmaxf(m, s);
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, st[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(st[kt][r] - m);
+            st[kt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = m + logf(sum);
+
+    f32x16 o[2];
+    zero16(o[0]); zero16(o[1]);
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {   // O^T[d][q] += V^T[d][key] P^T[key][q]
+            const float* vp = Vs + (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * HD + l31;
+            o[0] = MFMA32F(vp[0], st[kt][r], o[0]);
+            o[1] = MFMA32F(vp[32], st[kt][r], o[1]);
+        }
+    if (qrow < NT) {
+        const float inv = 1.0f / sum;
+        float* op = out + ((size_t)b * NT + qrow) * D + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4(op + dt * 32 + 8 * g + 4 * hi, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                       o[dt][4 * g + 3] * inv);
     }
-    float l = 0.f, ov[HD];
-#pragma unroll
-    for (int d = 0; d < HD; ++d) ov[d] = 0.f;
-    for (int j = 0; j < NT; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) s = fmaf(qv[d], Ks[j * HD + d], s);
-        const float p = expf(s - m);
-        l += p;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) ov[d] = fmaf(p, Vs[j * HD + d], ov[d]);
-    }
-    const float inv = 1.0f / l;
-    float* op = out + ((size_t)b * NT + tid) * D + h * HD;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) op[d] = ov[d] * inv;
-    lse[(size_t)bh * NT + tid] = m + logf(l);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(448) void attn_bwd_dq_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, const float* __restrict__ o,
                                                               const float* __restrict__ dout,
                                                               const float* __restrict__ lse, float* __restrict__ delta,
                                                               float* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
-    float* Vs = Ks + NT * HD;
+    float* Vs = reinterpret_cast<float*>(smem + F_IMG);
     const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
-    const int tid = threadIdx.x;
-    const float4* k4 = reinterpret_cast<const float4*>(k + (size_t)bh * NT * HD);
-    const float4* v4 = reinterpret_cast<const float4*>(v + (size_t)bh * NT * HD);
-    for (int t = tid; t < NT * HD / 4; t += 256) {
-        reinterpret_cast<float4*>(Ks)[t] = k4[t];
-        reinterpret_cast<float4*>(Vs)[t] = v4[t];
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_rows_f32<448, FLD>(k + (size_t)bh * NT * HD, HD, Ks, tid);
+    stage_rows_f32<448, FLD>(v + (size_t)bh * NT * HD, HD, Vs, tid);
     __syncthreads();
-    if (tid >= NT) return;
-    float qv[HD], dov[HD], dq[HD];
-    const float* qp = q + ((size_t)bh * NT + tid) * HD;
-    const size_t trow = ((size_t)b * NT + tid) * D + h * HD;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);
+    const size_t trow = ((size_t)b * NT + qr) * D + h * HD + hi * 32;
+    float qf[32], dof[32];
+    load_half_row(q + ((size_t)bh * NT + qr) * HD + hi * 32, qf);
+    load_half_row(dout + trow, dof);
     float dl = 0.f;
+    {
+        float of[32];
+        load_half_row(o + trow, of);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        qv[d] = qp[d];
-        dov[d] = dout[trow + d];
-        dl = fmaf(dov[d], o[trow + d], dl);
-        dq[d] = 0.f;
+        for (int d = 0; d < 32; ++d) dl = fmaf(dof[d], of[d], dl);
     }
-    const float L = lse[(size_t)bh * NT + tid];
-    delta[(size_t)bh * NT + tid] = dl;
-    for (int j = 0; j < NT; ++j) {
-        float s = 0.f, dp = 0.f;
+    dl += __shfl_xor(dl, 32, 64);
+    const float L = lse[(size_t)bh * NT + qr];
+    if (hi == 0 && qrow < NT) delta[(size_t)bh * NT + qrow] = dl;
+
+    f32x16 dq[2];
+    zero16(dq[0]); zero16(dq[1]);
+#pragma unroll 1
+    for (int kt = 0; kt < 7; ++kt) {
+        f32x16 s, dp;
+        zero16(s); zero16(dp);
+        mma_rowfrag(s, Ks, kt * 32, l31, hi, qf);     // S^T[key][q]
+        mma_rowfrag(dp, Vs, kt * 32, l31, hi, dof);   // dP^T[key][q]
 #pragma unroll
-        for (int d = 0; d < HD; ++d) {
-            s = fmaf(qv[d], Ks[j * HD + d], s);
-            dp = fmaf(dov[d], Vs[j * HD + d], dp);
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            s[r] = key < NT ? expf(s[r] - L) * (dp[r] - dl) : 0.f;   // dS^T
         }
-        const float ds = expf(s - L) * (dp - dl);
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[j * HD + d], dq[d]);
+        for (int r = 0; r < 16; ++r) {   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            const float* kp = Ks + (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * FLD + l31;
+            dq[0] = MFMA32F(kp[0], s[r], dq[0]);
+            dq[1] = MFMA32F(kp[32], s[r], dq[1]);
+        }
     }
-    float* op = dqkv + ((size_t)b * NT + tid) * (3 * D) + h * HD;
+    if (qrow < NT) {
+        float* op = dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) op[d] = dq[d] * 0.125f;
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4(op + dt * 32 + 8 * g + 4 * hi, dq[dt][4 * g] * 0.125f, dq[dt][4 * g + 1] * 0.125f,
+                       dq[dt][4 * g + 2] * 0.125f, dq[dt][4 * g + 3] * 0.125f);
+    }
 }
 
-// two threads per key (each owns 32 of the 64 channels)
-__global__ __launch_bounds__(512) void attn_bwd_dkv_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+// dK, dV per key tile (7 waves, one 32-key tile each)
+__global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v,
                                                                const float* __restrict__ dout,
                                                                const float* __restrict__ lse,
@@ -447,52 +530,69 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_f32_kernel(const float* __re
                                                                float* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Qs = reinterpret_cast<float*>(smem);
-    float* dOs = Qs + NT * HD;
-    float* lse_s = dOs + NT * HD;
-    float* del_s = lse_s + NT;
+    float* dOs = reinterpret_cast<float*>(smem + F_IMG);
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * F_IMG);
+    float* del_s = lse_s + NPAD;
     const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
-    const int tid = threadIdx.x;
-    for (int t = tid; t < NT * HD / 4; t += 512) {
-        const int row = t >> 4, c4 = t & 15;
-        reinterpret_cast<float4*>(Qs)[t] = reinterpret_cast<const float4*>(q + (size_t)bh * NT * HD)[t];
-        reinterpret_cast<float4*>(dOs)[t] =
-            *reinterpret_cast<const float4*>(dout + ((size_t)b * NT + row) * D + h * HD + c4 * 4);
-    }
-    if (tid < NT) {
-        lse_s[tid] = lse[(size_t)bh * NT + tid];
-        del_s[tid] = delta[(size_t)bh * NT + tid];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_rows_f32<448, FLD>(q + (size_t)bh * NT * HD, HD, Qs, tid);
+    stage_rows_f32<448, FLD>(dout + (size_t)b * NT * D + h * HD, D, dOs, tid);
+    if (tid < NPAD) {
+        lse_s[tid] = tid < NT ? lse[(size_t)bh * NT + tid] : 0.f;
+        del_s[tid] = tid < NT ? delta[(size_t)bh * NT + tid] : 0.f;
     }
     __syncthreads();
-    const int j = tid >> 1, hf = tid & 1;
-    const int jj = min(j, NT - 1);
-    float kv[32], vv[32], dk[32], dv[32];
-    const float* kp = k + ((size_t)bh * NT + jj) * HD + hf * 32;
-    const float* vp = v + ((size_t)bh * NT + jj) * HD + hf * 32;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int key = wave * 32 + l31, kr = min(key, NT - 1);
+    float kf[32], vf[32];
+    load_half_row(k + ((size_t)bh * NT + kr) * HD + hi * 32, kf);
+    load_half_row(v + ((size_t)bh * NT + kr) * HD + hi * 32, vf);
+    f32x16 aK[2], aV[2];
+    zero16(aK[0]); zero16(aK[1]); zero16(aV[0]); zero16(aV[1]);
+#pragma unroll 1
+    for (int qt = 0; qt < 7; ++qt) {
+        f32x16 s, dp;
+        zero16(s); zero16(dp);
+        mma_rowfrag(s, Qs, qt * 32, l31, hi, kf);     // S[q][key]  (rows q in registers, column key = lane)
+        mma_rowfrag(dp, dOs, qt * 32, l31, hi, vf);   // dP[q][key]
+        f32x16 p;
 #pragma unroll
-    for (int d = 0; d < 32; ++d) { kv[d] = kp[d]; vv[d] = vp[d]; dk[d] = 0.f; dv[d] = 0.f; }
-    for (int i = 0; i < NT; ++i) {
-        const float* qi = Qs + i * HD + hf * 32;
-        const float* di = dOs + i * HD + hf * 32;
-        float s = 0.f, dp = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const int q0 = qt * 32 + 8 * g + 4 * hi;
+            const float4 L4 = *reinterpret_cast<const float4*>(lse_s + q0);
+            const float4 D4 = *reinterpret_cast<const float4*>(del_s + q0);
+            const float Ls[4] = {L4.x, L4.y, L4.z, L4.w};
+            const float Ds[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            s = fmaf(qi[d], kv[d], s);
-            dp = fmaf(di[d], vv[d], dp);
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const bool ok = (q0 + e < NT) && (key < NT);
+                const float pv = ok ? expf(s[r] - Ls[e]) : 0.f;
+                p[r] = pv;
+                s[r] = ok ? pv * (dp[r] - Ds[e]) : 0.f;  // dS
+            }
         }
-        s += __shfl_xor(s, 1, 64);
-        dp += __shfl_xor(dp, 1, 64);
-        const float p = expf(s - lse_s[i]);
-        const float ds = p * (dp - del_s[i]);
 #pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            dv[d] = fmaf(p, di[d], dv[d]);
-            dk[d] = fmaf(ds, qi[d], dk[d]);
+        for (int r = 0; r < 16; ++r) {
+            const int qi = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float* dop = dOs + qi * FLD + l31;
+            const float* qp = Qs + qi * FLD + l31;
+            aV[0] = MFMA32F(dop[0], p[r], aV[0]);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+            aV[1] = MFMA32F(dop[32], p[r], aV[1]);
+            aK[0] = MFMA32F(qp[0], s[r], aK[0]);     // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            aK[1] = MFMA32F(qp[32], s[r], aK[1]);
         }
     }
-    if (j < NT) {
-        float* op = dqkv + ((size_t)b * NT + j) * (3 * D) + h * HD + hf * 32;
+    if (key < NT) {
+        float* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) { op[D + d] = dk[d]; op[2 * D + d] = dv[d]; }
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hi;
+                store4(op + D + d, aK[dt][4 * g], aK[dt][4 * g + 1], aK[dt][4 * g + 2], aK[dt][4 * g + 3]);
+                store4(op + 2 * D + d, aV[dt][4 * g], aV[dt][4 * g + 1], aV[dt][4 * g + 2], aV[dt][4 * g + 3]);
+            }
     }
 }
 
@@ -506,10 +606,10 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
                     hipStream_t s) {
     const int grid = batch * NH;
     if (precision == 0) {
-        const size_t lds = 2 * NT * HD * sizeof(float);
+        const size_t lds = F_IMG + NPAD * HD * sizeof(float);
         static bool once = false;
         if (!once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; once = true; }
-        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid), dim3(256), lds, s, (const float*)q, (const float*)k,
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid), dim3(448), lds, s, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, lse);
     } else {
         const size_t lds = ROW_IMG + TR_IMG;
@@ -524,17 +624,17 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
                     const float* lse, float* delta, void* dqkv, int batch, hipStream_t s) {
     const int grid = batch * NH;
     if (precision == 0) {
-        const size_t lds1 = 2 * NT * HD * sizeof(float);
-        const size_t lds2 = (2 * NT * HD + 2 * NT) * sizeof(float);
+        const size_t lds1 = 2 * F_IMG;
+        const size_t lds2 = 2 * F_IMG + 2 * NPAD * sizeof(float);
         static bool once = false;
         if (!once) {
             if (set_lds((const void*)attn_bwd_dq_f32_kernel, lds1)) return -2;
             if (set_lds((const void*)attn_bwd_dkv_f32_kernel, lds2)) return -2;
             once = true;
         }
-        hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3(grid), dim3(256), lds1, s, (const float*)q, (const float*)k,
+        hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3(grid), dim3(448), lds1, s, (const float*)q, (const float*)k,
                            (const float*)v, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv);
-        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3(grid), dim3(512), lds2, s, (const float*)q, (const float*)k,
+        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3(grid), dim3(448), lds2, s, (const float*)q, (const float*)k,
                            (const float*)v, (const float*)dout, lse, delta, (float*)dqkv);
     } else {
         const size_t lds1 = 2 * ROW_IMG + TR_IMG;

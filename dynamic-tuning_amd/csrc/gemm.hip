@@ -10,7 +10,7 @@
 //              same XOR on the ds_read_b128 -- conflict-free for the 16x16x32 fragment read.
 //              The MFMA is issued with the W fragment as the A operand so that every lane ends
 //              up with 4 CONSECUTIVE output columns of one row (8/16-byte epilogue stores).
-// exact path : fp32 operands on the vector ALU (64x64x16 tile) -- the parity mode.
+// exact path : fp32 operands on the matrix cores (v_mfma_f32_32x32x2_f32, gemm_f32_mfma.h) -- the parity mode.
 //
 // Reference ops replaced: nn.Linear of Attention.qkv / .proj (models/vision_transformer_IN21K.py:56,73),
 // timm Mlp fc1/fc2 (:124-129,159), Adapter.down_proj/up_proj (models/dynamic_adapter.py:124-128),
@@ -27,7 +27,6 @@ namespace dyt {
 //   pre(row, col)            the functor's own global loads (residual, gelu', row maps), returned RAW so
 //                            that a whole pass worth of them is in flight before the first use
 //   apply(row, col, v, c, p) the arithmetic and the stores
-// operator()(row, col, v) chains the three (the fp32 exact kernel's per-thread 4x4 tile uses that).
 // ------------------------------------------------------------------------------------------
 struct NoCtx {};
 struct Bias4 { float b[4]; };
@@ -60,11 +59,6 @@ __device__ __forceinline__ void store4_nt(bf16* p, float a, float b, float c, fl
     bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
     __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
 }
-#define DYT_EPI_CHAIN                                                                            \
-    __device__ __forceinline__ void operator()(int row, int col, const float (&a)[4]) const {     \
-        apply(row, col, a, col_init(col), pre(row, col));                                        \
-    }
-
 struct EpiBiasF32 {
     const float* bias; float* out; int ld;
     typedef Bias4 Col; typedef NoCtx Pre;
@@ -73,7 +67,6 @@ struct EpiBiasF32 {
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre&) const {
         store4(out + (size_t)row * ld + col, a[0] + c.b[0], a[1] + c.b[1], a[2] + c.b[2], a[3] + c.b[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -97,7 +90,6 @@ struct EpiQKV {
         AT* dst = c.base + (((size_t)b * NH * NT + n) << 6);
         store4(dst, (a[0] + c.b.b[0]) * c.s, (a[1] + c.b.b[1]) * c.s, (a[2] + c.b.b[2]) * c.s, (a[3] + c.b.b[3]) * c.s);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -115,7 +107,6 @@ struct EpiBiasResid {
         store4(out + o, v0, v1, v2, v3);
         if (out_at) store4(out_at + o, v0, v1, v2, v3);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT, bool HAS_GP>
@@ -146,7 +137,6 @@ struct EpiFc1 {
         }
         store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -169,7 +159,6 @@ struct EpiFc2 {
         p.r.get(r);
         store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -191,7 +180,6 @@ struct EpiGeluBwd {
         p.get(g);
         store4(out + (size_t)row * ld + col, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 struct EpiStoreF32 {
@@ -207,7 +195,6 @@ struct EpiStoreF32 {
         p.get(r);
         store4(out + (size_t)row * ld + col, r[0] + a[0], r[1] + a[1], r[2] + a[2], r[3] + a[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -219,7 +206,6 @@ struct EpiStoreAT {
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre&) const {
         store4(out + (size_t)row * ld + col, a[0], a[1], a[2], a[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -231,7 +217,6 @@ struct EpiBiasAT {
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre&) const {
         store4(out + (size_t)row * ld + col, a[0] + c.b[0], a[1] + c.b[1], a[2] + c.b[2], a[3] + c.b[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -262,7 +247,6 @@ struct EpiAdDown {
         }
         store4(out + (size_t)row * RP + col, v[0], v[1], v[2], v[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 struct EpiAdUp {
@@ -282,7 +266,6 @@ struct EpiAdUp {
         store4(out + (size_t)p.dst * D + col, r[0] + scale * (a[0] + c.b[0]), r[1] + scale * (a[1] + c.b[1]),
                r[2] + scale * (a[2] + c.b[2]), r[3] + scale * (a[3] + c.b[3]));
     }
-    DYT_EPI_CHAIN
 };
 
 template <class AT>
@@ -298,7 +281,6 @@ struct EpiAdDgradUp {
         store4(out + (size_t)row * RP + col, d[0] != 0.f ? a[0] * s : 0.f, d[1] != 0.f ? a[1] * s : 0.f,
                d[2] != 0.f ? a[2] * s : 0.f, d[3] != 0.f ? a[3] * s : 0.f);
     }
-    DYT_EPI_CHAIN
 };
 
 struct EpiEmbed {
@@ -316,7 +298,6 @@ struct EpiEmbed {
         pr.get(ps);
         store4(x0 + o, a[0] + c.b[0] + ps[0], a[1] + c.b[1] + ps[1], a[2] + c.b[2] + ps[2], a[3] + c.b[3] + ps[3]);
     }
-    DYT_EPI_CHAIN
 };
 
 // ------------------------------------------------------------------------------------------
@@ -675,56 +656,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
 
 }  // namespace dyt
 #include "gemm_bpre.h"
+#include "gemm_f32_mfma.h"
 namespace dyt {
-
-// ------------------------------------------------------------------------------------------
-// fp32 exact kernel (vector ALU): 64x64x16 tile, 256 threads, 4x4 outputs per thread
-// ------------------------------------------------------------------------------------------
-template <class Epi>
-__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                          int M, int N, int K, const int* __restrict__ m_dev,
-                                                          const int* __restrict__ a_map, Epi epi) {
-    constexpr int BM = 64, BN = 64, BK = 16;
-    __shared__ float As[BK][BM + 4];
-    __shared__ float Ws[BK][BN + 4];
-    const int Mv = m_dev ? min(*m_dev, M) : M;
-    const int tiles_n = N / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    if (m0 >= Mv) return;
-    const int tid = threadIdx.x;
-    const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row, k offset
-    const int ty = tid >> 4, tx = tid & 15;
-    int arow = min(m0 + lr, Mv - 1);
-    if (a_map) arow = a_map[arow];
-    const float* ap = A + (size_t)arow * K + lk;
-    const float* wp = W + (size_t)(n0 + lr) * K + lk;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const float4 av = *reinterpret_cast<const float4*>(ap + k0);
-        const float4 wv = *reinterpret_cast<const float4*>(wp + k0);
-        __syncthreads();
-        As[lk + 0][lr] = av.x; As[lk + 1][lr] = av.y; As[lk + 2][lr] = av.z; As[lk + 3][lr] = av.w;
-        Ws[lk + 0][lr] = wv.x; Ws[lk + 1][lr] = wv.y; Ws[lk + 2][lr] = wv.z; Ws[lk + 3][lr] = wv.w;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < BK; ++k) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
-            const float4 w4 = *reinterpret_cast<const float4*>(&Ws[k][tx * 4]);
-            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + ty * 4 + i;
-        if (row < Mv) epi(row, n0 + tx * 4, acc[i]);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // launch
@@ -819,17 +752,31 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     return -1;
 }
 
-template <class Epi>
-static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
-    if (a.K % 16 != 0 || a.N % 64 != 0 || a.M <= 0) {
-        set_error("gemm_f32: N=%d %% 64, K=%d %% 16 required, M=%d", a.N, a.K, a.M);
-        return -1;
+template <int BM, int BN, class Epi>
+static int launch_f32_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const size_t lds = 2 * (BM + BN) * 128;
+    auto kern = gemm_f32_mfma_nt_kernel<BM, BN, 2, 2, Epi>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        attr_set = true;
     }
-    const int grid = ((a.M + 63) / 64) * (a.N / 64);
-    hipLaunchKernelGGL((gemm_f32_nt_kernel<Epi>), dim3(grid), dim3(256), 0, s, static_cast<const float*>(a.A),
-                       static_cast<const float*>(a.W), a.M, a.N, a.K, a.m_dev, a.a_map, epi);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, static_cast<const float*>(a.A), static_cast<const float*>(a.W),
+                       a.M, a.N, a.K, a.m_dev, a.a_map, 0, epi);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <class Epi>
+static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    if (a.K % 64 != 0 || a.N % 64 != 0 || a.M <= 0) {
+        set_error("gemm_f32: N=%d %% 64, K=%d %% 64 required, M=%d", a.N, a.K, a.M);
+        return -1;
+    }
+    if (a.N % 128 == 0) return launch_f32_cfg<128, 128>(a, epi, s);
+    return launch_f32_cfg<128, 64>(a, epi, s);
 }
 
 template <class AT, class Epi>
@@ -903,6 +850,12 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
     }
     set_error("gemm_raw: unknown variant %d", variant);
     return -1;
+}
+
+// measurement hook: plain fp32 GEMM (exact-fp32 MFMA kernel, product dispatch) into an fp32 C
+int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s) {
+    GemmArgs a; a.A = A; a.W = W; a.M = M; a.N = N; a.K = K;
+    return run_f32(a, EpiStoreAT<float>{static_cast<float*>(C), N}, s);
 }
 
 int gemm_debug_counters(unsigned long long* out4, int reset) {

@@ -9,7 +9,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:n]:
     name = r["Name"]
-    m = re.search(r"gemm_(bf16|f32)_nt_kernel.*?(Epi[A-Za-z0-9]+)", name)
+    m = re.search(r"gemm_(bf16|f32_mfma|bf16_bpre)(?:_nt)?_kernel.*?(Epi[A-Za-z0-9]+)", name)
     if m:
         tile = re.search(r"ILi(\d+)ELi(\d+)E|<(\d+), (\d+)", name)
         t = "x".join(x for x in (tile.groups() if tile else ()) if x)
