@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the DyT ViT-B/16 fine-tune step on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N>1: starts N ranks itself, or runs as one rank
+                                                         when launched by torch.distributed.run)
 
 One "step" = engine_finetune.py:47-79 of the reference: student forward (compacted MLP, Gumbel
 gate, adapter dropout), teacher forward (complete model), CE + 2*token-ratio + teacher CE + KL,
@@ -36,6 +37,7 @@ import synth  # noqa: E402
 STEP_GFLOP_AT_07 = 126.851   # SURVEY.md section 8d / BASELINE.md section 3, compact mode, r=64, C=100
 STEP_GFLOP_SLOPE = 42.542    # d(GFLOP)/d(keep ratio)
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # TFLOP/s dense MFMA, MI355X_MICROARCH.md
+TRAFFIC_JSON = os.path.join("round1", "gemm_traffic.json")
 
 
 class Cfg(dict):
@@ -130,6 +132,8 @@ def main():
     ap.add_argument("--ffn_num", type=int, default=64)
     ap.add_argument("--keep", type=float, default=0.7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the second (fp32 parity mode) measurement at N=1")
+    ap.add_argument("--hip-graph", type=int, default=1, help="replay the step's forward+backward from a captured hipGraph (0: eager launches)")
     ap.add_argument("--video-frames", type=int, default=0,
                     help="T > 1: BASELINE.json configs[4] shape instead of the headline one -- the video model, "
                          "--batch frames per GPU = batch/T clips of T frames (train_video.sh: 16 clips x 8 frames, 400 classes)")
@@ -137,6 +141,17 @@ def main():
     if args.video_frames > 1:
         assert args.batch % args.video_frames == 0, "--batch must be a multiple of --video-frames"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start N ranks ourselves (one process per GPU over RCCL), exactly the command the
+        # reference's train_IN21K.sh:10-16 launch line maps to; rank 0 of the children prints the one JSON line.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,43 +164,92 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
+    head = measure(args, args.precision, args.mode, args.steps, args.warmup, device, world, rank)
+    parity = None
+    if world == 1 and args.video_frames <= 1 and args.precision != "fp32" and not args.no_parity_mode:
+        # the same step in the PARITY arithmetic mode (exact fp32 on the matrix cores: logits <= 1e-3, gate masks bit-exact
+        # against the reference goldens, tests/test_gpu_parity.py), same workload and training mode as the headline
+        torch.cuda.empty_cache()
+        pm = measure(args, "fp32", args.mode, max(2, min(args.steps, 4)), 1, device, world, rank)
+        parity = {"dtype": "fp32", "train_mode": args.mode, "value": pm["value"], "unit": "images/s", "ms_per_step": pm["ms_per_step"],
+                  "steps": pm["steps"], "step_gflop_per_image": pm["step_gflop_per_image"], "step_mfma_frac": pm["step_mfma_frac"],
+                  "keep_ratio_measured": pm["keep_ratio_measured"], "roofline": pm["roofline"],
+                  "parity": "fp32 mode vs reference goldens on MI355X: logits max abs err < 1e-3, token-keep masks bit-exact, "
+                            "74 gradients rel-L2 < 2e-3 (tests/test_gpu_parity.py, tests/gpu_diag.py)"}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec DyT ViT-B/16 fine-tune step (student+teacher fwd, bwd, AdamW) @ keep~0.7",
+            "value": head["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": ("ViT-B/16 DyT on CIFAR-100 shape, batch=128/GPU, 1xMI355X per rank, keep-ratio target 0.7 "
+                                    "(BASELINE.json configs[1]; N>1 = configs[3] shape: global batch 128*N, DP over RCCL)")
+                       if args.video_frames <= 1 else
+                       ("NOT the headline config: video DyT ViT-B/16 (BASELINE.json configs[4] shape), %d clips x %d frames per GPU, "
+                        "%d classes; `value` counts frames/s" % (args.batch // args.video_frames, args.video_frames, args.classes)),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "ffn_num": args.ffn_num,
+                       "num_classes": args.classes, "train_mode": args.mode, "parallelism": "dp%d" % world,
+                       "keep_ratio_measured": head["keep_ratio_measured"], "keep_ratio_calibrated": head["keep_ratio_calibrated"],
+                       "hip_graph": head["hip_graph"]},
+            "images_per_s_per_gpu": round(head["value"] / world, 2),
+            "step_gflop_per_image": head["step_gflop_per_image"],
+            "step_mfma_frac": head["step_mfma_frac"],
+            "loss": head["loss"],
+            "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+            "roofline": head["roofline"],
+        }
+        if parity is not None:
+            out["parity_mode"] = parity
+        log("roofline", head["roofline"])
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure(args, precision, mode, steps, warmup, device, world, rank):
+    """Build the model in one arithmetic / training mode, calibrate the keep ratio, time `steps` fused steps (barrier +
+    synchronize on both sides, max over ranks) and take the dominant-kernel roofline of one extra event-profiled step."""
     from engine_finetune import FusedAdamW, train_step
+    margs = argparse.Namespace(**vars(args))
+    margs.precision, margs.mode = precision, mode
     torch.manual_seed(1234 + rank)
-    model = build_model(args, device)
+    model = build_model(margs, device)
     x, y = synth.make_batch(args.batch, args.classes, seed=100 + rank)  # each rank its own shard of the global batch
     if args.video_frames > 1:   # [b,c,t,h,w] clips, one target per clip
         T = args.video_frames
         x = x.reshape(args.batch // T, T, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous()
         y = y[: args.batch // T].contiguous()
     x, y = x.to(device), y.to(device)
-    log("model built, ctx %.1f GB" % (0 if model._engine is None else model._engine.bytes / 1e9))
     keep_cal = calibrate_gates(model, x, args.keep)
-    log("calibrated keep ratio %.4f, ctx %.1f GB" % (keep_cal, model._engine.bytes / 1e9))
-    if world > 1:  # DDP broadcasts rank 0's weights at construction (main_image.py:281)
-        dist.broadcast(model._engine.flat, src=0)
+    log("[%s/%s] calibrated keep ratio %.4f, ctx %.1f GB" % (precision, mode, keep_cal, model._engine.bytes / 1e9))
     model.train()
-    opt = FusedAdamW(model, lr=1e-3 * args.batch * world / 256, weight_decay=0.01)
+    opt = FusedAdamW(model, lr=1e-3 * args.batch * world / 256, weight_decay=0.01)   # broadcasts rank 0's trainables (DDP ctor)
     eng = model._engine
     if os.environ.get("DYT_NO_OVERLAP"):   # profiling aid: serial launches give clean per-kernel durations
         import _lib
         eng.set_option(_lib.OPT_STREAM_OVERLAP, 0)
+    use_graph = bool(args.hip_graph) and not os.environ.get("DYT_NO_OVERLAP")
     losses = torch.zeros(8, device=device)
     acc = torch.zeros(8, device=device)
 
     def one_step(i):
         train_step(model, x, y, opt, losses_out=losses, seed=1000 + i, target_ratio=args.keep, token_minimal=0.0,
-                   token_minimal_weight=0.0)
+                   token_minimal_weight=0.0, graph=use_graph)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         one_step(i)
     torch.cuda.synchronize()
-    log("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
+    for i in range(steps):
+        one_step(warmup + i)
         acc += losses
     t_host = time.perf_counter() - t0   # host time to ENQUEUE the timed steps (no sync inside the loop)
     if world > 1:
@@ -196,19 +260,21 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    host = (acc / args.steps).tolist()
-    log("timed %d steps: %.2f ms/step (host enqueue %.2f ms/step)" % (args.steps, dt / args.steps * 1e3, t_host / args.steps * 1e3))
+    host = (acc / steps).tolist()
+    log("[%s/%s] timed %d steps: %.2f ms/step (host enqueue %.2f ms/step)" % (precision, mode, steps, dt / steps * 1e3, t_host / steps * 1e3))
     keep_meas = host[5]
 
     # dominant-kernel roofline: HIP events around every GEMM launch of ONE step (same stream)
     roof = None
     traffic = None
-    try:  # HBM bytes per GEMM launch from the committed PMC passes of this same command (tools/pmc_traffic.py)
-        with open(os.path.join(ROOT, "profiles", "round1", "gemm_traffic.json")) as f:
-            traffic = json.load(f)
-    except Exception:
-        pass
+    if precision == "bf16":
+        try:  # HBM bytes per GEMM launch from the committed PMC passes of this same command (tools/pmc_traffic.py)
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)) as f:
+                traffic = json.load(f)
+        except Exception:
+            pass
     if rank == 0:
+        use_graph = False   # the event-profiled step runs eagerly, one stream
         eng.profile(True)
         one_step(10 ** 6)
         ms, n, fl = eng.profile_read(0)
@@ -217,50 +283,30 @@ def main():
         _, n_kern, _ = eng.profile_read(3)   # kernel launches behind the n GEMMs (PMC traffic is per kernel launch)
         eng.profile(False)
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_%s_nt_kernel (all epilogues)" % ("bf16" if args.precision == "bf16" else "f32"),
-                "achieved": round(ach, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK[args.precision], 4),
-                "traffic": round(traffic["hbm_bytes_per_launch"] * max(n_kern, 1) / max(n, 1)) if traffic and args.precision == "bf16" else None,
-                "traffic_source": "profiles/round1/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 "
-                                  "gfx950 correction): bytes per kernel launch x kernel launches per GEMM (%d / %d this step)" % (n_kern, n) if traffic else None,
+        kern = ("gemm_bf16_nt_kernel + gemm_bf16_bpre_kernel (bf16 MFMA 16x16x32, all epilogues)" if precision == "bf16"
+                else "gemm_f32_mfma_nt_kernel (exact-fp32 MFMA 32x32x2, all epilogues)")
+        roof = {"bound": "mfma", "kernel": kern,
+                "achieved": round(ach, 2), "peak": PEAK[precision], "unit": "TFLOP/s", "frac": round(ach / PEAK[precision], 4),
+                "traffic": round(traffic["hbm_bytes_per_launch"] * max(n_kern, 1) / max(n, 1)) if traffic else None,
+                "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 "
+                                   "gfx950 correction): bytes per kernel launch x kernel launches per GEMM (%d / %d this step)" % (TRAFFIC_JSON, n_kern, n)) if traffic else None,
                 "timing_note": "per-kernel durations are taken with the multi-stream overlap switched off (serial launches), "
                                "so they are clean but pessimistic w.r.t. the overlapped schedule that `value` is measured on", "launches_per_step": n, "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                 "avg_launch_ms": round(ms / max(n, 1), 4), "gemm_ms_per_step": round(ms, 3),
                 "attention_ms_per_step": round(ms_a, 3), "attention_tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2) if ms_a else None,
                 "other_kernels_ms_per_step": round(ms_o, 3), "other_launches": n_o}
-    if world > 1:
-        dist.barrier()
-
-    if rank == 0:
-        ips = args.batch * world * args.steps / dt
-        gflop = STEP_GFLOP_AT_07 + STEP_GFLOP_SLOPE * (keep_meas - 0.7) if args.mode == "compact" else 139.614
-        if args.video_frames > 1:   # + k/v projections of the pooling head per frame: fwd + dgrad + wgrad, two passes
-            gflop += 2 * 3 * 2 * (2 * 197 * 768 * 768) / 1e9
-        out = {
-            "metric": "images/sec DyT ViT-B/16 fine-tune step (student+teacher fwd, bwd, AdamW) @ keep~0.7",
-            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("ViT-B/16 DyT on CIFAR-100 shape, batch=128/GPU, 1xMI355X per rank, keep-ratio target 0.7 "
-                                    "(BASELINE.json configs[1]; N>1 = configs[3] shape: global batch 128*N, DP over RCCL)")
-                       if args.video_frames <= 1 else
-                       ("NOT the headline config: video DyT ViT-B/16 (BASELINE.json configs[4] shape), %d clips x %d frames per GPU, "
-                        "%d classes; `value` counts frames/s" % (args.batch // args.video_frames, args.video_frames, args.classes)),
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "ffn_num": args.ffn_num,
-                       "num_classes": args.classes, "train_mode": args.mode, "parallelism": "dp%d" % world,
-                       "keep_ratio_measured": round(keep_meas, 4), "keep_ratio_calibrated": round(keep_cal, 4)},
-            "images_per_s_per_gpu": round(ips / world, 2),
-            "step_gflop_per_image": round(gflop, 3),
-            "step_mfma_frac": round(ips / world * gflop * 1e9 / (PEAK[args.precision] * 1e12), 4),
-            "loss": round(host[0], 4),
-            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
-            "roofline": roof,
-        }
-        log("roofline", roof)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ips = args.batch * world * steps / dt
+    gflop = STEP_GFLOP_AT_07 + STEP_GFLOP_SLOPE * (keep_meas - 0.7) if mode == "compact" else 139.614
+    if args.video_frames > 1:   # + k/v projections of the pooling head per frame: fwd + dgrad + wgrad, two passes
+        gflop += 2 * 3 * 2 * (2 * 197 * 768 * 768) / 1e9
+    res = {"value": round(ips, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 3), "keep_ratio_measured": round(keep_meas, 4),
+           "keep_ratio_calibrated": round(keep_cal, 4), "loss": round(host[0], 4), "step_gflop_per_image": round(gflop, 3),
+           "step_mfma_frac": round(ips / world * gflop * 1e9 / (PEAK[precision] * 1e12), 4), "roofline": roof,
+           "hip_graph": bool(args.hip_graph) and not os.environ.get("DYT_NO_OVERLAP")}
+    del opt, model, eng
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

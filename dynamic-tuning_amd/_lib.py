@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
-F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD = 1, 2, 4, 8, 16, 32
+F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED = 1, 2, 4, 8, 16, 32, 64
 OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0 = 1, 2, 3
 
 # enum dyt_param (include/dyt_hip.h)
@@ -95,6 +95,11 @@ SYMBOLS = {
     "dyt_adamw": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "dyt_step_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _u64, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
                               _vp, _vp]),
+    "dyt_seed": (_i, [_vp, _u64, _vp]),
+    "dyt_grad_part": (_i, [_vp, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dyt_stream_wait_grads": (_i, [_vp, _i, _vp]),
+    "dyt_clip_grad_norm": (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp]),
+    "dyt_debug_dispatch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dyt_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dyt_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

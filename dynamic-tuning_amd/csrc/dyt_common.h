@@ -43,15 +43,28 @@ __device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
     o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
 }
 
+// Wave-wide reductions on the VALU only: DPP lane permutes inside a 16-lane row, v_readlane across the four rows
+// (__shfl_xor lowers to ds_bpermute_b32, five dependent trips through the LDS queue per reduction; the row kernels do two
+// to four reductions per 768-channel row).  Every lane receives the total.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_f32<0x141>(v);   // row_half_mirror: quad <-> neighbouring quad
+    v += dpp_f32<0x140>(v);   // row_mirror: half row <-> half row  => every lane holds its row's sum
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -225,6 +225,7 @@ struct EpiAdDown {
     AT* out;            // [M, RP]
     const uint8_t* keep; int r; float inv_keep; float drop_p; uint64_t seed, subseq;
     const int* row_map;  // token row of compact row `row` (mask / RNG are indexed by token), or null
+    const uint64_t* seed_dev;   // overrides `seed` when set (captured graphs draw fresh noise per replay)
     typedef Bias4 Col;
     struct Pre { int trow; };
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
@@ -240,7 +241,7 @@ struct EpiAdDown {
                 for (int i = 0; i < 4; ++i)
                     v[i] = (col + i < r && keep[(size_t)trow * r + col + i]) ? v[i] * inv_keep : 0.0f;
             } else {
-                Philox ph(seed, subseq, (uint64_t)trow * (RP / 4) + (col >> 2));
+                Philox ph(seed_dev ? *seed_dev : seed, subseq, (uint64_t)trow * (RP / 4) + (col >> 2));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ph.u01(i) >= drop_p ? v[i] * inv_keep : 0.0f;
             }
@@ -801,7 +802,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
         case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
-            return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map}, s);
+            return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
         case EPI_AD_UP: return run<AT>(a, EpiAdUp{a.bias, a.resid, a.out_f32, a.scale, a.row_map}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);

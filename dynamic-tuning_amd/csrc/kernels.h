@@ -49,6 +49,7 @@ struct GemmArgs {
     float inv_keep = 1.f;             // 1/(1-p) when training, else 1
     float drop_p = 0.f;               // >0 : apply dropout (Philox when keep == null)
     uint64_t seed = 0, subseq = 0;
+    const uint64_t* seed_dev = nullptr;   // when set, the Philox seed is read from this device word (graph replay)
     int accumulate = 0;
     double flops() const { return 2.0 * M * (double)N * K; }
 };
@@ -93,6 +94,7 @@ struct GateArgs {
     int training;
     float tau, threshold;
     uint64_t seed, subseq;   // Philox stream when training && !g1
+    const uint64_t* seed_dev = nullptr;   // when set, overrides `seed` with the device-side word (graph replay)
     float* soft;             // [B*197] y_soft per token (cls slot unused) -- saved for backward
     float* maskf;            // [B*197] hard mask per token as float (cls = 1)
     float* out_select;       // user tensor [B,depth,196] (pointer already offset to this layer) or null
@@ -102,8 +104,6 @@ struct GateArgs {
     int* counts;             // [B]
 };
 int launch_gate(const GateArgs& a, hipStream_t s);
-// offsets[b] = exclusive prefix of counts, total[0] = sum
-int launch_scan(const int* counts, int* offsets, int* total, int batch, hipStream_t s);
 // LN2 of the kept rows into the compact A operand; row_src[dst]=src token row, dst_of[src]=dst or -1;
 // also computes the row offsets (prefix of counts) itself and publishes total[0] = sum(counts)
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
@@ -145,6 +145,12 @@ struct LossArgs {
 };
 int launch_loss(const LossArgs& a, hipStream_t s);
 
+// seed word on the device: set / advance by one (one thread)
+int launch_seed_set(uint64_t* seed_dev, uint64_t value, hipStream_t s);
+int launch_seed_advance(uint64_t* seed_dev, hipStream_t s);
+// global-norm gradient clipping (torch.nn.utils.clip_grad_norm_ on the flat buffer): norm_out[0] = ||pre_scale * g||_2,
+// then g *= min(1, max_norm / (norm + 1e-6)); scratch: 256 floats
+int launch_clip_grad_norm(float* g, int64_t n, float max_norm, float pre_scale, float* scratch, float* norm_out, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2, float gscale, hipStream_t s);
 

@@ -119,6 +119,7 @@ struct Slot {
     hipStream_t branch = nullptr;        // side stream for the adapter branch of this pass
     float* u0_own = nullptr; void* u0_at_own = nullptr;  // block-0 buffers (slot 1 may alias slot 0's, see step)
     hipEvent_t ev_f = nullptr, ev_j = nullptr;
+    bool no_branch = false;              // this pass runs without its adapter side stream (see dyt_step_fwd_bwd)
     std::vector<LayerS> L;
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
     int* counts = nullptr;   // [depth*B]
@@ -155,6 +156,12 @@ struct dyt_ctx {
     std::vector<Slot> slots;
     float *dl_s, *dl_t, *dtok, *logits_s, *logits_t, *losses, *grad2, *loss_part;
     int* cls_rows = nullptr;   // [max_batch] token row of each image's cls token (b*197)
+    uint64_t* seed_dev = nullptr;   // device-side Philox seed word (DYT_F_DEVICE_SEED: captured graphs draw fresh noise per replay)
+    float* clip_scratch = nullptr;  // [256] partial sums of dyt_clip_grad_norm
+    // gradient availability for a chunked all-reduce (dyt_stream_wait_grads): layers >= grad_split and the head are final
+    hipEvent_t ev_half_s = nullptr, ev_half_t = nullptr, ev_upper = nullptr;
+    hipStream_t aux = nullptr;       // sums the upper part of the two passes' gradient buffers while the backward goes on
+    bool upper_recorded = false;
     bool cls_tail = true;      // last block: MLP/adapter on the cls rows only (only they reach the head)
     // second stream: the student and the teacher pass of a step are independent and run concurrently
     hipStream_t side = nullptr;
@@ -283,6 +290,8 @@ static void layout(dyt_ctx* c, bool dry) {
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
     c->cls_rows = carve<int>(c, B, dry);
+    c->seed_dev = carve<uint64_t>(c, 2, dry);
+    c->clip_scratch = carve<float>(c, 256, dry);
     c->dl_s = carve<float>(c, B * C, dry); c->dl_t = carve<float>(c, B * C, dry);
     c->logits_s = carve<float>(c, B * C, dry); c->logits_t = carve<float>(c, B * C, dry);
     c->dtok = carve<float>(c, 4, dry);
@@ -377,6 +386,10 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
         if (S.pool.wstream) hipStreamDestroy(S.pool.wstream);
     }
     if (c->ev_b0) hipEventDestroy(c->ev_b0);
+    if (c->ev_half_s) hipEventDestroy(c->ev_half_s);
+    if (c->ev_half_t) hipEventDestroy(c->ev_half_t);
+    if (c->ev_upper) hipEventDestroy(c->ev_upper);
+    if (c->aux) hipStreamDestroy(c->aux);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side) hipStreamDestroy(c->side);
@@ -585,6 +598,7 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
 static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
     *out = nullptr;
     if (!c->overlap || c->prof) return 0;
+    if (S.no_branch) return 0;
     if (!S.branch) {
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&S.branch, hipStreamNonBlocking));
         DYT_HIP_CHECK(hipEventCreateWithFlags(&S.ev_f, hipEventDisableTiming));
@@ -714,6 +728,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const bool dense = complete || masked_dense;
     const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
+    const uint64_t* seed_dev = (flags & DYT_F_DEVICE_SEED) ? c->seed_dev : nullptr;
     Slot& S = c->slots[slot];
     Transients& T = S.T;
     S.valid = false;
@@ -769,7 +784,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
             a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
             a.row_map = tail ? c->cls_rows : nullptr;
-            a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1);
+            a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1); a.seed_dev = seed_dev;
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
         {
@@ -785,7 +800,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             ga.g1 = g1 ? g1 + (size_t)l * B * NP : nullptr;
             ga.g2 = g2 ? g2 + (size_t)l * B * NP : nullptr;
             ga.batch = B; ga.training = training; ga.tau = c->cfg.tau; ga.threshold = c->cfg.threshold;
-            ga.seed = seed; ga.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2);
+            ga.seed = seed; ga.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2); ga.seed_dev = seed_dev;
             ga.soft = L.soft; ga.maskf = L.maskf;
             ga.out_select = token_select ? token_select + (size_t)l * NP : nullptr;
             ga.out_logits = token_logits ? token_logits + (size_t)l * NP : nullptr;
@@ -844,8 +859,10 @@ extern "C" int dyt_forward(dyt_ctx* c, int slot, const float* images, int batch,
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
+// ev_split (optional) is recorded on `s` once the gradients of the head and of every block >= split are enqueued
 static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const float* dlogits, const float* dtoken_select,
-                         const float* dtok, const float* dtoken_logits, float* grad, hipStream_t s) {
+                         const float* dtok, const float* dtoken_logits, float* grad, hipStream_t s,
+                         hipEvent_t ev_split = nullptr, int split = 0) {
     if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
     Slot& S = c->slots[slot];
     Transients& T = S.T;
@@ -937,6 +954,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.out_f32 = gin; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
             RUN_GEMM(EPI_STORE_F32, a);
         }
+
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
         if (!first || student) {
             TokBwdArgs a;
@@ -952,6 +970,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
             if (student) RUN(2, 0, launch_reduce_partials(T.tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s));
         }
+        if (ev_split && l == split) DYT_HIP_CHECK(hipEventRecord(ev_split, s));
         if (first) break;
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
@@ -1030,7 +1049,7 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     const size_t kz = (size_t)depth * batch * NT * c->cfg.ffn_num;
     float* ls = logits_s ? logits_s : c->logits_s;
     float* lt = logits_t ? logits_t : c->logits_t;
-    const int fl = (flags & DYT_F_MASKED_DENSE) | DYT_F_TRAINING | DYT_F_SAVE;
+    const int fl = (flags & (DYT_F_MASKED_DENSE | DYT_F_DEVICE_SEED)) | DYT_F_TRAINING | DYT_F_SAVE;
     // Two-stream schedule: student pass on the caller's stream, teacher pass on a side stream
     // (fork/join with events; graph-capturable).  Profiling mode runs serially for clean per-kernel times.
     const bool par = c->overlap && !c->prof;
@@ -1046,6 +1065,16 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     rc = prep_pool(c, trainable, s);
     if (rc) return rc;
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
+    {
+        // hipGraph stream capture (ROCm 7.2): a stream that forks from a stream which is itself a fork of the capture's
+        // origin stream crashes hipStreamEndCapture (bisected on MI355X: origin -> side is fine, origin -> branch is fine,
+        // side -> branch is not).  While capturing, the teacher pass (on the side stream) therefore keeps its adapter
+        // branch on its own stream; the graph still carries the two passes and the student's branch as parallel chains.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        DYT_HIP_CHECK(hipStreamIsCapturing(s, &cs));
+        c->slots[1].no_branch = par && cs == hipStreamCaptureStatusActive;
+        c->slots[0].no_branch = false;
+    }
     // The two passes see the same images and the same frozen weights, and nothing trainable or random sits
     // in front of block 0's attention branch: the teacher pass reuses the student's embedding, LN1, qkv,
     // attention and proj of block 0 (its block-0 `u` pointers alias the student's for this step).
@@ -1073,16 +1102,79 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
     if (!(flags & DYT_F_ACCUM_GRAD)) DYT_HIP_CHECK(hipMemsetAsync(grad_flat, 0, (size_t)c->n_train * sizeof(float), s));
     if (par) DYT_HIP_CHECK(hipMemsetAsync(c->grad2, 0, (size_t)c->n_train * sizeof(float), s2));
-    rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s);
+    // Chunked all-reduce support (DDP fires its buckets inside loss.backward(), misc.py:258-259): the backward runs
+    // block 11 -> 0, so the gradients of the head and of blocks >= depth/2 -- a contiguous tail of the flat buffer --
+    // are final half-way through.  ev_upper marks that point (both passes summed) for dyt_stream_wait_grads().
+    const int split = depth / 2;
+    const int64_t up_off = (int64_t)split * c->layer_stride, up_n = c->n_train - up_off;
+    if (!c->ev_upper) {
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_half_s, hipEventDisableTiming));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_half_t, hipEventDisableTiming));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_upper, hipEventDisableTiming));
+        DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    }
+    rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s, par ? c->ev_half_s : nullptr, split);
     if (rc) return rc;
-    rc = backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, gt, s2);
+    rc = backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, gt, s2, par ? c->ev_half_t : c->ev_upper, split);
     if (rc) return rc;
     if (par) {
+        // upper part: summed on the aux stream as soon as both passes have left block `split`
+        DYT_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_half_s, 0));
+        DYT_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_half_t, 0));
+        rc = launch_reduce_partials(c->grad2 + up_off, 1, 0, grad_flat + up_off, (int)up_n, 1.0f, c->aux);
+        if (rc) return rc;
+        DYT_HIP_CHECK(hipEventRecord(c->ev_upper, c->aux));
+        // lower part: after the teacher pass has finished
         DYT_HIP_CHECK(hipEventRecord(c->ev_join, s2));
         DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-        rc = launch_reduce_partials(c->grad2, 1, 0, grad_flat, (int)c->n_train, 1.0f, s);  // grad_flat += grad2
+        rc = launch_reduce_partials(c->grad2, 1, 0, grad_flat, (int)up_off, 1.0f, s);  // grad_flat[lower] += grad2[lower]
+        if (rc) return rc;
+        DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_upper, 0));   // the caller's stream owns the whole buffer on return
     }
+    c->upper_recorded = true;
+    if (flags & DYT_F_DEVICE_SEED) rc = launch_seed_advance(c->seed_dev, s);
     return rc;
+}
+
+extern "C" int dyt_seed(dyt_ctx* c, uint64_t seed, void* stream) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    return launch_seed_set(c->seed_dev, seed, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dyt_grad_part(const dyt_ctx* c, int part, int64_t* offset, int64_t* numel) {
+    if (!c || !offset || !numel || part < 0 || part > 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    const int64_t up_off = (int64_t)(c->cfg.depth / 2) * c->layer_stride;
+    if (part == 0) { *offset = up_off; *numel = c->n_train - up_off; }
+    else { *offset = 0; *numel = up_off; }
+    return DYT_OK;
+}
+
+extern "C" int dyt_stream_wait_grads(dyt_ctx* c, int part, void* stream) {
+    if (!c || part != 0) { set_error("dyt_stream_wait_grads: part 0 (head + upper blocks) is the only early part"); return DYT_ERR_ARG; }
+    if (!c->upper_recorded) { set_error("no dyt_step_fwd_bwd has been enqueued yet"); return DYT_ERR_STATE; }
+    DYT_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_upper, 0));
+    return DYT_OK;
+}
+
+extern "C" int dyt_clip_grad_norm(dyt_ctx* c, float* grad, int64_t numel, float max_norm, float pre_scale, float* norm_out,
+                                  void* stream) {
+    if (!c || !grad || numel < 1 || !(max_norm > 0.f)) { set_error("bad argument"); return DYT_ERR_ARG; }
+    return launch_clip_grad_norm(grad, numel, max_norm, pre_scale, c->clip_scratch, norm_out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dyt_debug_dispatch(dyt_ctx* c, int slot, int layer, int32_t* row_src, int32_t* dst_of, int32_t* counts,
+                                  int32_t* total, void* stream) {
+    if (!c || slot < 0 || slot >= c->cfg.slots || layer < 0 || layer >= c->cfg.depth) { set_error("bad slot / layer"); return DYT_ERR_ARG; }
+    const Slot& S = c->slots[slot];
+    if (S.batch < 1) { set_error("slot %d holds no pass", slot); return DYT_ERR_STATE; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t M = (size_t)S.batch * NT;
+    const LayerS& L = S.L[layer];
+    if (row_src) DYT_HIP_CHECK(hipMemcpyAsync(row_src, L.row_src, M * 4, hipMemcpyDeviceToDevice, s));
+    if (dst_of) DYT_HIP_CHECK(hipMemcpyAsync(dst_of, L.dst_of, M * 4, hipMemcpyDeviceToDevice, s));
+    if (counts) DYT_HIP_CHECK(hipMemcpyAsync(counts, S.counts + (size_t)layer * S.batch, (size_t)S.batch * 4, hipMemcpyDeviceToDevice, s));
+    if (total) DYT_HIP_CHECK(hipMemcpyAsync(total, L.total, 4, hipMemcpyDeviceToDevice, s));
+    return DYT_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1181,23 +1273,20 @@ extern "C" int dyt_gate_compact(const float* u, const float* w, const float* b, 
     Scratch sc;
     const size_t M = (size_t)batch * NT;
     float* soft = (float*)sc.get(M * 4); float* maskf = (float*)sc.get(M * 4);
-    int* keep_local = (int*)sc.get(M * 4); int* offsets = (int*)sc.get((size_t)batch * 4);
-    if (!soft || !maskf || !keep_local || !offsets) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    int* keep_local = (int*)sc.get(M * 4); int* dst_of = (int*)sc.get(M * 4);
+    float* xn = (float*)sc.get(M * D * 4); float2* st = (float2*)sc.get(M * sizeof(float2)); float* ones = (float*)sc.get(2 * D * 4);
+    if (!soft || !maskf || !keep_local || !dst_of || !xn || !st || !ones) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
     GateArgs ga;
     ga.u = u; ga.w = w; ga.b = b; ga.g1 = g1; ga.g2 = g2; ga.batch = batch; ga.training = training; ga.tau = tau;
     ga.threshold = threshold; ga.seed = 0; ga.subseq = 0; ga.soft = soft; ga.maskf = maskf; ga.out_select = mask;
     ga.out_logits = logits; ga.out_stride = NP; ga.keep_local = keep_local; ga.counts = counts;
     int rc = launch_gate(ga, s); if (rc) return rc;
-    rc = launch_scan(counts, offsets, total, batch, s); if (rc) return rc;
-    // flat ascending list of kept rows = what nonzero() returns in model_speed_test.py:300
-    std::vector<int> hc(batch), ho(batch), hk(M);
+    // flat ascending list of kept rows (= nonzero() of model_speed_test.py:300) built on the DEVICE by the product's own
+    // gather kernel: its row_src output is that list, its device-side total the length (the LayerNorm it also computes is discarded)
+    DYT_HIP_CHECK(hipMemsetAsync(keep_idx, 0xff, M * 4, s));
+    DYT_HIP_CHECK(hipMemsetAsync(ones, 0, 2 * D * 4, s));
+    rc = launch_ln_gather(0, u, ones, ones + D, keep_local, counts, total, maskf, xn, st, keep_idx, dst_of, batch, s);
+    if (rc) return rc;
     DYT_HIP_CHECK(hipStreamSynchronize(s));
-    DYT_HIP_CHECK(hipMemcpy(hc.data(), counts, batch * 4, hipMemcpyDeviceToHost));
-    DYT_HIP_CHECK(hipMemcpy(ho.data(), offsets, batch * 4, hipMemcpyDeviceToHost));
-    DYT_HIP_CHECK(hipMemcpy(hk.data(), keep_local, M * 4, hipMemcpyDeviceToHost));
-    std::vector<int> flat(M, -1);
-    for (int bb = 0; bb < batch; ++bb)
-        for (int j = 0; j < hc[bb]; ++j) flat[ho[bb] + j] = bb * NT + hk[(size_t)bb * NT + j];
-    DYT_HIP_CHECK(hipMemcpy(keep_idx, flat.data(), M * 4, hipMemcpyHostToDevice));
     return DYT_OK;
 }

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void gate_select_kernel(GateArgs a) {
                 if (a.g1) {
                     z = (l + a.g1[(size_t)b * NP + n - 1] - a.g2[(size_t)b * NP + n - 1]) / a.tau;
                 } else {
-                    Philox ph(a.seed, a.subseq, t);
+                    Philox ph(a.seed_dev ? *a.seed_dev : a.seed, a.subseq, t);
                     const float u = ph.u01(0);
                     z = (l + (logf(u) - log1pf(-u))) / a.tau;  // Gumbel - Gumbel ~ Logistic(0,1)
                 }
@@ -162,19 +162,6 @@ int launch_gate(const GateArgs& a, hipStream_t s) {
     const int M = a.batch * NT;
     hipLaunchKernelGGL(gate_logits_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.u, a.w, a.b, a.soft, M);
     hipLaunchKernelGGL(gate_select_kernel, dim3(a.batch), dim3(256), 0, s, a);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-__global__ void scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ total, int batch) {
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < batch; ++b) { offsets[b] = acc; acc += counts[b]; }
-        total[0] = acc;
-    }
-}
-int launch_scan(const int* counts, int* offsets, int* total, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, total, batch);
     LAUNCH_CHECK();
     return 0;
 }
@@ -557,6 +544,56 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
+__global__ void seed_set_kernel(uint64_t* seed_dev, uint64_t value, int advance) {
+    if (threadIdx.x == 0) seed_dev[0] = advance ? seed_dev[0] + 1 : value;
+}
+int launch_seed_set(uint64_t* seed_dev, uint64_t value, hipStream_t s) {
+    hipLaunchKernelGGL(seed_set_kernel, dim3(1), dim3(64), 0, s, seed_dev, value, 0);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_seed_advance(uint64_t* seed_dev, hipStream_t s) {
+    hipLaunchKernelGGL(seed_set_kernel, dim3(1), dim3(64), 0, s, seed_dev, 0ull, 1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- global-norm clipping of the flat gradient (engine_finetune.py:74 -> misc.py:262-266 clip_grad_norm_) ----
+__global__ __launch_bounds__(256) void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+    __shared__ float ws[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ part, int nparts,
+                                                         float max_norm, float pre_scale, float* __restrict__ norm_out) {
+    __shared__ float coef_s;
+    if (threadIdx.x < 64) {   // every block re-derives the (deterministic, fixed-order) total: no second launch, no atomics
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) {
+            const float norm = sqrtf(acc) * fabsf(pre_scale);
+            coef_s = fminf(1.0f, max_norm / (norm + 1e-6f));
+            if (blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+        }
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    if (coef >= 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] *= coef;
+}
+int launch_clip_grad_norm(float* g, int64_t n, float max_norm, float pre_scale, float* scratch, float* norm_out, hipStream_t s) {
+    const int nparts = 256;
+    hipLaunchKernelGGL(sqsum_kernel, dim3(nparts), dim3(256), 0, s, g, n, scratch);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(nparts), dim3(256), 0, s, g, n, scratch, nparts, max_norm, pre_scale, norm_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, float bc1, float bc2, float gscale, hipStream_t s) {
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,

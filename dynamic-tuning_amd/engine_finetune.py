@@ -29,50 +29,153 @@ def get_world_size():
     return dist.get_world_size() if is_dist_avail_and_initialized() else 1
 
 
+def _trainable_names(model):
+    """The order of main_image.py:285's `[p for name, p in model.named_parameters() if p.requires_grad]`."""
+    from _lib import is_trainable_param, key_to_param
+    return [(n, p) for n, p in model.named_parameters() if is_trainable_param(key_to_param(n)[0])]
+
+
 class FusedAdamW:
-    """Stands where ``torch.optim.AdamW([trainable params], lr, weight_decay)`` stands in
-    main_image.py:285; the update itself is libdyt_hip's flat AdamW kernel.  Exposes
-    ``param_groups`` so ``lr_sched.adjust_learning_rate`` works unchanged."""
+    """Stands where ``torch.optim.AdamW([trainable params], lr, weight_decay)`` stands in main_image.py:285; the update
+    itself is libdyt_hip's flat AdamW kernel.  Exposes ``param_groups`` so ``lr_sched.adjust_learning_rate`` works
+    unchanged.  The optimizer OWNS its state (step count and both moments, flat fp32 buffers in the library's trainable
+    layout, allocated lazily on the engine's device), so it survives a re-created engine (larger eval batch) and can be
+    restored right after construction, before any forward, as misc.load_model does.  ``state_dict()`` is in
+    ``torch.optim.AdamW.state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` in named_parameters
+    order, one param group), so the reference can resume from our checkpoints and we from its (misc.py:296-352)."""
 
     def __init__(self, model, lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8):
         self.model = getattr(model, "module", model)
-        self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
+        n = len(_trainable_names(self.model))
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                  foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(n)))]
+        self.step_count = 0
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self._pending = None        # per-parameter state loaded before an engine existed
+        self._synced = None         # engine whose trainables were broadcast from rank 0
 
     def zero_grad(self, set_to_none=True):
         pass  # dyt_step_fwd_bwd zeroes the flat gradient buffer itself
 
-    def step(self, grad_scale=1.0):
+    # ---- state ---------------------------------------------------------------------------------
+    def _state(self, eng):
+        """Moments as flat buffers on the engine's device (moved / re-built when the engine changed)."""
+        if self.exp_avg is None or self.exp_avg.numel() != eng.n_train:
+            self.exp_avg = torch.zeros(eng.n_train, device=eng.device, dtype=torch.float32)
+            self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        elif self.exp_avg.device != eng.device:
+            self.exp_avg, self.exp_avg_sq = self.exp_avg.to(eng.device), self.exp_avg_sq.to(eng.device)
+        if self._pending is not None:
+            for name, st in self._pending.items():
+                off, num = eng.trainable_slice(name)
+                self.exp_avg[off:off + num].copy_(st["exp_avg"].reshape(-1).to(eng.device, torch.float32))
+                self.exp_avg_sq[off:off + num].copy_(st["exp_avg_sq"].reshape(-1).to(eng.device, torch.float32))
+            self._pending = None
+        return self.exp_avg, self.exp_avg_sq
+
+    def sync_parameters(self, eng):
+        """What DistributedDataParallel does at construction (main_image.py:280-282): every rank starts from rank 0's
+        parameters.  Done once per engine, before its first step."""
+        if self._synced is eng:
+            return
+        if is_dist_avail_and_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(eng.flat, src=0)
+            m, v = self._state(eng)
+            dist.broadcast(m, src=0)
+            dist.broadcast(v, src=0)
+        self._synced = eng
+
+    def step(self, grad_scale=1.0, max_norm=0.0):
         g = self.param_groups[0]
-        self.model._engine.adamw(g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"], grad_scale)
+        eng = self.model._engine
+        if eng is None:
+            raise DyTError("FusedAdamW.step() before any forward / step of the model")
+        m, v = self._state(eng)
+        if max_norm is not None and max_norm > 0:
+            eng.clip_grad_norm(max_norm, grad_scale)
+        self.step_count += 1
+        eng.adamw(m, v, self.step_count, g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"], grad_scale)
 
     def state_dict(self):
-        e = self.model._engine
-        return dict(step=e.opt_step, exp_avg=e.exp_avg, exp_avg_sq=e.exp_avg_sq, param_groups=self.param_groups)
+        names = _trainable_names(self.model)
+        eng = self.model._engine
+        state = {}
+        if self.step_count > 0 or self._pending is not None:
+            if eng is not None:
+                m, v = self._state(eng)
+            for i, (name, p) in enumerate(names):
+                if eng is not None:
+                    off, num = eng.trainable_slice(name)
+                    ea, es = m[off:off + num].view(p.shape).clone(), v[off:off + num].view(p.shape).clone()
+                else:
+                    ea, es = self._pending[name]["exp_avg"], self._pending[name]["exp_avg_sq"]
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=ea, exp_avg_sq=es)
+        return dict(state=state, param_groups=[dict(self.param_groups[0])])
 
     def load_state_dict(self, sd):
-        e = self.model._engine
-        e.opt_step = sd["step"]
-        e.exp_avg, e.exp_avg_sq = sd["exp_avg"], sd["exp_avg_sq"]
-        self.param_groups = sd["param_groups"]
+        """Accepts torch.optim.AdamW.state_dict() of the reference (or our own): tensors may live on any device
+        (misc.load_model uses map_location='cpu'); they are applied when an engine exists."""
+        names = _trainable_names(self.model)
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(names):
+            raise ValueError("optimizer state has %d groups / %d params, the model has %d trainable tensors" % (
+                len(groups), len(groups[0]["params"]) if groups else 0, len(names)))
+        keep = {k: v for k, v in groups[0].items() if k != "params"}
+        self.param_groups[0].update(keep)
+        self.param_groups[0]["betas"] = tuple(self.param_groups[0]["betas"])
+        pending, step = {}, 0
+        for pos, pid in enumerate(groups[0]["params"]):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            name, p = names[pos]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state of %s has shape %s, parameter has %s" % (name, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            pending[name] = dict(exp_avg=st["exp_avg"].detach(), exp_avg_sq=st["exp_avg_sq"].detach())
+            step = max(step, int(float(st["step"])))
+        self.step_count = step
+        self._pending = pending if pending else None
+        if self._pending is not None and self.model._engine is not None:
+            self._state(self.model._engine)
 
 
-def allreduce_grads(engine, group=None):
-    """Sum the flat trainable-gradient buffer over ranks (RCCL over xGMI); the 1/world factor is
-    folded into the AdamW kernel.  Returns that factor."""
+def allreduce_grads(engine, group=None, overlap=True):
+    """Sum the flat trainable-gradient buffer over ranks (RCCL over xGMI); the 1/world factor is folded into the AdamW
+    kernel.  Returns that factor.  With `overlap` the head + upper-blocks half of the buffer (final half-way through the
+    backward pass, dyt_stream_wait_grads) is reduced on a side stream while the frozen-backbone backward of the lower
+    blocks is still running -- what DDP's bucket hooks do inside loss.backward() (misc.py:258-259)."""
     if not is_dist_avail_and_initialized():
         return 1.0
-    dist.all_reduce(engine.grad, op=dist.ReduceOp.SUM, group=group)
+    if overlap and engine.grad.is_cuda:
+        off, num = engine.grad_part(0)
+        comm, cur = engine.comm_stream(), torch.cuda.current_stream(engine.device)
+        engine.stream_wait_grads(comm)
+        with torch.cuda.stream(comm):
+            dist.all_reduce(engine.grad[off:off + num], op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(engine.grad[:off], op=dist.ReduceOp.SUM, group=group)
+        cur.wait_stream(comm)
+    else:
+        dist.all_reduce(engine.grad, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / dist.get_world_size(group)
+
+
+def step_seed(epoch, it, base=None):
+    """64-bit packing of (base seed, epoch, iteration): distinct for every step of a run."""
+    base = torch.initial_seed() if base is None else base
+    return ((base & 0xFFFF) << 47) | ((int(epoch) & 0xFFFF) << 31) | (int(it) & 0x7FFFFFFF)
 
 
 def train_step(model, samples, targets, optimizer, criterion=None, losses_out=None, gumbel=None, keep_mask=None,
                seed=0, target_ratio=None, token_minimal=None, token_minimal_weight=None, accumulate=False, update=True,
-               accum_iter=1):
+               accum_iter=1, max_norm=0.0, graph=False):
     """One fused step (reference engine_finetune.py:47-79) on device tensors; returns the device
-    tensor of loss components [loss, base, token, teacher, distillation, keep ratio, kept, 0]."""
+    tensor of loss components [loss, base, token, teacher, distillation, keep ratio, kept, 0].
+    graph=True replays the forward+backward from a captured hipGraph (on-device noise only)."""
     m = getattr(model, "module", model)
     samples = m.fold_input(samples.float()).contiguous()   # video: [b,c,t,h,w] -> [(b t),c,h,w]
     eng = m.engine(samples.shape[0], samples.device)
+    optimizer.sync_parameters(eng)
     tr = criterion.token_target_ratio if target_ratio is None else target_ratio
     ratio = criterion.token_loss_ratio if criterion is not None else 2.0
     tmin = (criterion.token_minimal if criterion is not None else 0.0) if token_minimal is None else token_minimal
@@ -80,26 +183,50 @@ def train_step(model, samples, targets, optimizer, criterion=None, losses_out=No
     g1 = g2 = None
     if gumbel is not None:
         g1, g2 = gumbel
-    out = eng.step_fwd_bwd(samples, targets, tr, ratio, tmin, tw, masked_dense=(m.train_mode == "masked"), g1=g1, g2=g2,
-                           keep_mask=keep_mask, seed=seed, losses=losses_out, accumulate=accumulate)
+    masked = m.train_mode == "masked"
+    use_graph = graph and gumbel is None and keep_mask is None
+    if use_graph:
+        out = eng.step_graph(samples, targets, tr, ratio, tmin, tw, masked_dense=masked, losses=losses_out, accumulate=accumulate,
+                             seed=seed)
+    else:
+        out = eng.step_fwd_bwd(samples, targets, tr, ratio, tmin, tw, masked_dense=masked, g1=g1, g2=g2,
+                               keep_mask=keep_mask, seed=seed, losses=losses_out, accumulate=accumulate)
     if update:   # reference :66-76: `loss /= accum_iter`, optimizer step on every accum_iter-th micro-batch
-        scale = allreduce_grads(eng)
-        optimizer.step(grad_scale=scale / accum_iter)
+        scale = allreduce_grads(eng, overlap=not use_graph)   # events recorded inside a graph cannot be waited on from outside
+        optimizer.step(grad_scale=scale / accum_iter, max_norm=max_norm)
     return out
+
+
+def _check_supported(model, criterion):
+    """The fused step hard-wires what every reference entry point uses; anything else must fail loudly."""
+    from _lib import is_trainable_param, key_to_param
+    base = getattr(criterion, "base_criterion", None)
+    if base is not None and not (isinstance(base, torch.nn.CrossEntropyLoss) and getattr(base, "label_smoothing", 0.0) == 0.0
+                                 and base.weight is None):
+        raise NotImplementedError("the fused step computes plain CrossEntropyLoss (main_image.py:292); got %r" % (base,))
+    for n, p in model.named_parameters():
+        tr = is_trainable_param(key_to_param(n)[0])
+        if tr != bool(p.requires_grad):
+            raise NotImplementedError("%s.requires_grad=%s: the fused step trains exactly the reference's freeze rule "
+                                      "(adapters, gates, head -- main_image.py:250-256); --fulltune / partial freezing is "
+                                      "not supported" % (n, p.requires_grad))
 
 
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
                     mixup_fn=None, log_writer=None, args=None, logger=None):
     """Reference engine_finetune.py:16-106.  ``optimizer`` must be a FusedAdamW; ``loss_scaler`` is
     unused (bf16 operands / fp32 accumulation need no loss scaling -- the reference's GradScaler,
-    misc.py:252-272, only exists for its fp16 autocast)."""
+    misc.py:252-272, only exists for its fp16 autocast); ``max_norm`` (--clip_grad) clips the global
+    gradient norm on the device before the update.  ``args.hip_graph`` replays the step from a hipGraph."""
     if not isinstance(optimizer, FusedAdamW):
         raise DyTError("train_one_epoch drives the fused HIP step; pass engine_finetune.FusedAdamW(model, ...)")
     if mixup_fn is not None:
         raise NotImplementedError("mixup is not used by train_IN21K.sh / train_vtab.sh / train_video.sh")
     accum_iter = max(1, int(getattr(args, "accum_iter", 1) or 1)) if args is not None else 1
+    use_graph = bool(getattr(args, "hip_graph", False)) if args is not None else False
     model.train(True)
     m = getattr(model, "module", model)
+    _check_supported(m, criterion)
     print_freq = 20
     nsteps = len(data_loader)
     acc = torch.zeros(8, device=device)
@@ -107,16 +234,19 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     sums = {k: 0.0 for k in LOSS_KEYS}
     count, pending = 0, 0
     t0 = time.time()
-    seed0 = (torch.initial_seed() + 7919 * epoch) & (2 ** 62 - 1)
     lr = optimizer.param_groups[0]["lr"]
     for it, batch in enumerate(data_loader):
         samples, targets = batch[0], batch[1]
+        # parity tests may append the random draws to inject: (samples, targets, (g1, g2), keep_mask)
+        gumbel = tuple(t.to(device).contiguous() for t in batch[2]) if len(batch) > 2 and batch[2] is not None else None
+        keep_mask = batch[3].to(device).contiguous() if len(batch) > 3 and batch[3] is not None else None
         if it % accum_iter == 0:   # per-iteration schedule, reference :43-46
             lr = lr_sched.adjust_learning_rate(optimizer, it / nsteps + epoch, args)
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
-        train_step(model, samples, targets, optimizer, criterion, losses_out=step_losses, seed=seed0 + it,
-                   accumulate=(it % accum_iter != 0), update=((it + 1) % accum_iter == 0), accum_iter=accum_iter)
+        train_step(model, samples, targets, optimizer, criterion, losses_out=step_losses, seed=step_seed(epoch, it),
+                   gumbel=gumbel, keep_mask=keep_mask, accumulate=(it % accum_iter != 0), update=((it + 1) % accum_iter == 0),
+                   accum_iter=accum_iter, max_norm=max_norm or 0.0, graph=use_graph)
         acc += step_losses
         pending += 1
         if (it + 1) % print_freq == 0 or it + 1 == nsteps:
@@ -197,6 +327,47 @@ def evaluate(data_loader, model, device, logger=None, base_flops=None, flops_dic
     elif metric == "mean_per_class_acc":
         status["metric"] = mean_per_class_accuracy(predictions, targets, args.nb_classes).item()
     status["keep_ratio"] = token_select.float().mean().item()
+    if logger is not None:
+        logger.info("* metric %.3f keep ratio %.4f" % (status["metric"], status["keep_ratio"]))
+    return status
+
+
+@torch.no_grad()
+def evaluate_video(data_loader, model, device, logger=None, base_flops=None, flops_dict=None, args=None):
+    """Reference engine_finetune.py:281-356: every sample carries V views [B,V,c,t,h,w]; views are folded into the batch,
+    the per-view logits averaged per sample (:302-305), then the same gather + accuracy as ``evaluate``."""
+    model.eval()
+    token_select, targets, predictions = [], [], []
+    for batch in data_loader:
+        images = batch[0].to(device, non_blocking=True)
+        target = batch[1].to(device, non_blocking=True)
+        B, V = images.shape[0], images.shape[1]
+        output, aux = model(images.flatten(0, 1))
+        predictions.append(output.view(B, V, -1).mean(dim=1))
+        token_select.append(aux["token_select"].to(torch.uint8))
+        targets.append(target)
+    targets = torch.cat(targets, dim=0)
+    predictions = torch.cat(predictions, dim=0)
+    token_select = torch.cat(token_select, dim=0)
+    if is_dist_avail_and_initialized():
+        targets = all_gather_concat(targets)
+        predictions = all_gather_concat(predictions)
+        token_select = all_gather_concat(token_select)
+    status = {}
+    metric = getattr(args, "metric", "accuracy")
+    if metric == "accuracy":
+        acc1, acc5 = accuracy(predictions, targets, topk=(1, 5))
+        status["metric"] = acc1.item()
+        status["acc5"] = acc5.item()
+    elif metric == "mean_per_class_acc":
+        status["metric"] = mean_per_class_accuracy(predictions, targets, args.nb_classes).item()
+    ts = token_select.float()
+    status["keep_ratio"] = ts.mean().item()
+    if flops_dict is not None and base_flops is not None:   # :341-345: analytic FLOPs from the masks
+        from block_flops_dict import batch_select_flops
+        fl = batch_select_flops(ts.shape[0], flops_dict=flops_dict, token_select=ts.unsqueeze(-1) if ts.dim() == 3 else ts,
+                                block_num=12, base_flops=base_flops)
+        status["gflops"] = float(fl.mean())
     if logger is not None:
         logger.info("* metric %.3f keep ratio %.4f" % (status["metric"], status["keep_ratio"]))
     return status

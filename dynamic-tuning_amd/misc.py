@@ -2,7 +2,8 @@
 
 Same file format: ``{'model': state_dict, 'optimizer': ..., 'epoch': ..., 'scaler': ..., 'args': ...}``
 with the reference's parameter names, so checkpoints interchange with the reference in both
-directions (the optimizer entry is this repo's flat AdamW state when FusedAdamW is used).
+directions; the optimizer entry is in torch.optim.AdamW.state_dict() layout (FusedAdamW.state_dict), so the
+reference's torch.optim.AdamW resumes from our files and FusedAdamW from the reference's.
 """
 import os
 from pathlib import Path
@@ -20,12 +21,22 @@ def save_on_master(*args, **kwargs):
         torch.save(*args, **kwargs)
 
 
+def _to_cpu(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
+
+
 def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler=None, save_force=False):
     if get_rank() == 0 and ((epoch + 1) % getattr(args, "save_freq", 1) == 0 or (epoch + 1) == args.epochs or save_force):
         output_dir = Path(args.output_dir)
         to_save = {
             'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
-            'optimizer': optimizer.state_dict() if optimizer is not None else None,
+            'optimizer': _to_cpu(optimizer.state_dict()) if optimizer is not None else None,
             'epoch': epoch,
             'scaler': loss_scaler.state_dict() if loss_scaler is not None else {},
             'args': args,

@@ -45,6 +45,9 @@ extern "C" {
                                   default is the compacted MLP of models/model_speed_test.py:274-310 */
 #define DYT_F_ACCUM_GRAD 32    /* dyt_step_fwd_bwd: add to grad_flat instead of overwriting it -- gradient accumulation over
                                   accum_iter micro-batches (engine_finetune.py:43-46,66-76; fold 1/accum_iter into dyt_adamw's grad_scale) */
+#define DYT_F_DEVICE_SEED 64   /* the Philox seed is read from the context's device-side seed word (dyt_seed) instead of the
+                                  `seed` argument, and dyt_step_fwd_bwd advances that word by one when it is done: a step
+                                  captured into a hipGraph then draws fresh Gumbel noise / dropout masks at every replay */
 #define DYT_F_GATE_ALWAYS 16   /* also evaluate the token dispatcher in a COMPLETE pass (the reference does,
                                   and discards it, :150-152) so token_select/token_logits are returned */
 
@@ -189,6 +192,32 @@ int dyt_step_fwd_bwd(dyt_ctx* ctx, const float* images, const int64_t* targets, 
                      float token_minimal, float token_minimal_weight,
                      float* grad_flat, float* out_losses, float* logits_s, float* logits_t,
                      float* token_select, void* stream);
+
+/* Set the device-side seed word used by DYT_F_DEVICE_SEED passes (one tiny launch on `stream`). */
+int dyt_seed(dyt_ctx* ctx, uint64_t seed, void* stream);
+
+/* Chunked all-reduce (what DDP's bucketed hooks do inside loss.backward(), misc.py:258-259 / main_image.py:280-282):
+ * the backward pass runs block 11 -> 0, so part 0 of the flat gradient = the head and blocks >= depth/2 (a contiguous
+ * tail of the buffer) is final while the frozen-backbone backward of the lower blocks is still running.
+ *   dyt_grad_part(ctx, part, &offset, &numel)   part 0: early (upper) range, part 1: the rest
+ *   dyt_stream_wait_grads(ctx, 0, comm_stream)  makes comm_stream wait (device-side) until part 0 of the last
+ *                                               dyt_step_fwd_bwd is complete, so its all-reduce overlaps the rest of
+ *                                               the backward; the step's own stream owns the whole buffer once
+ *                                               dyt_step_fwd_bwd's work is done, as before. */
+int dyt_grad_part(const dyt_ctx* ctx, int part, int64_t* offset, int64_t* numel);
+int dyt_stream_wait_grads(dyt_ctx* ctx, int part, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_ over the flat gradient (engine_finetune.py:74 -> misc.py:262-266, --clip_grad):
+ * norm_out[0] (device, may be NULL) = || pre_scale * grad ||_2 ; grad *= min(1, max_norm / (norm + 1e-6)).
+ * pre_scale is the factor AdamW will apply (1/world after a SUM all-reduce, 1/accum_iter). */
+int dyt_clip_grad_norm(dyt_ctx* ctx, float* grad, int64_t numel, float max_norm, float pre_scale, float* norm_out, void* stream);
+
+/* Test hook: the token dispatcher's index arrays of a pass still held in `slot` (compacted student pass), block `layer`:
+ *   row_src[K] compact row -> token row (ascending = nonzero() of model_speed_test.py:300), dst_of[B*197] token row ->
+ *   compact row or -1, counts[B] kept tokens per image incl. cls, total[1] = K.  Device-to-device copies on `stream`;
+ *   any pointer may be NULL. */
+int dyt_debug_dispatch(dyt_ctx* ctx, int slot, int layer, int32_t* row_src, int32_t* dst_of, int32_t* counts, int32_t* total,
+                       void* stream);
 
 /* ---- single-kernel entry points (unit tests; also the building blocks of the sub-module API) ---- */
 /* nn.LayerNorm(768, eps=1e-6) forward; out fp32 */

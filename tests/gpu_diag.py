@@ -41,6 +41,14 @@ class Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
+def D_adamw(eng, lr, wd):
+    """One flat AdamW update with moments kept on the engine object (the tests' stand-in for FusedAdamW's state)."""
+    if not hasattr(eng, "_t_m"):
+        eng._t_m, eng._t_v, eng._t_step = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat), 0
+    eng._t_step += 1
+    eng.adamw(eng._t_m, eng._t_v, eng._t_step, lr, wd)
+
+
 def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
@@ -169,7 +177,7 @@ def t_eval_golden():
     g = dict(np.load(os.path.join(ROOT, "tests/golden/eval_r64.npz")))
     B, C = int(g["meta_batch"]), int(g["meta_num_classes"])
     x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
-    for prec, tol in (("fp32", 1e-3), ("bf16", 0.25)):
+    for prec, tol in (("fp32", 1e-3), ("bf16", 0.03)):   # bf16 measured: 0.012
         model, sd = build_model(g, prec)
         model.eval()
         with torch.no_grad():
@@ -177,9 +185,9 @@ def t_eval_golden():
         report("eval logits vs golden prec=%s" % prec, float(np.abs(logits.cpu().numpy() - g["logits"]).max()), tol)
         ts = aux["token_select"].cpu().numpy().astype(np.uint8)
         flips = int((ts != g["token_select"]).sum())
-        report("eval masks vs golden prec=%s" % prec, flips, 0 if prec == "fp32" else 400, "of %d" % ts.size)
+        report("eval masks vs golden prec=%s" % prec, flips, 0 if prec == "fp32" else 30, "of %d" % ts.size)   # bf16 measured: 12 of 9408
         report("eval token_logits vs golden prec=%s" % prec, float(np.abs(aux["token_logits"].cpu().numpy() - g["token_logits"]).max()),
-               1e-3 if prec == "fp32" else 1.0)
+               1e-3 if prec == "fp32" else 1.0)   # bf16 measured 0.46: a flipped token changes every later block's gate input
 
 
 def t_step_golden():
@@ -200,14 +208,14 @@ def t_step_golden():
                                       g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
                                       token_select=ts).cpu()
             tag = "%s/%s" % (prec, mode)
-            ltol = 1e-3 if prec == "fp32" else 0.25
+            ltol = 1e-3 if prec == "fp32" else 0.03   # bf16 measured: 0.012
             report("step logits student %s" % tag, float(np.abs(ls.cpu().numpy() - g["s0_logits_student"]).max()), ltol)
             report("step logits teacher %s" % tag, float(np.abs(lt.cpu().numpy() - g["s0_logits_teacher"]).max()), ltol)
             flips = int((ts.cpu().numpy().astype(np.uint8) != g["s0_token_select"][..., 0]).sum())
-            report("step masks %s" % tag, flips, 0 if prec == "fp32" else 400, "of %d" % ts.numel())
+            report("step masks %s" % tag, flips, 0 if prec == "fp32" else 8, "of %d" % ts.numel())   # bf16 measured: 1 of 4704
             for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
                 ref = float(g["s0_stat_" + k])
-                report("step %s %s" % (k, tag), abs(float(losses[i]) - ref), (1e-4 if prec == "fp32" else 0.05) * max(1.0, abs(ref)))
+                report("step %s %s" % (k, tag), abs(float(losses[i]) - ref), (1e-4 if prec == "fp32" else 0.02) * max(1.0, abs(ref)))
             if mode == "masked":
                 gref = {n[len("s0_grad/"):]: torch.from_numpy(v) for n, v in g.items() if n.startswith("s0_grad/")}
             else:
@@ -220,10 +228,10 @@ def t_step_golden():
                 e = float((got - gr).norm() / (gr.norm() + 1e-20))
                 if e > worst:
                     worst, wname = e, n
-            report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.2, wname)
+            report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.15, wname)   # bf16 measured: 0.045-0.11 (gate tensors)
             # AdamW on the flat buffer
             if prec == "fp32" and mode == "masked":
-                eng.adamw(float(g["meta_lr"]), float(g["meta_wd"]))
+                D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
                 worst = 0.0
                 for n in gref:
                     key = "s0_param_after/" + n
@@ -311,7 +319,7 @@ def t_video_golden():
                     worst, wname = e, n
             report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.2, wname)
             if prec == "fp32" and mode == "masked":
-                eng.adamw(float(g["meta_lr"]), float(g["meta_wd"]))
+                D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
                 worst = 0.0
                 for key in g:
                     if key.startswith("param_after/"):

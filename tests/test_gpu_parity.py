@@ -103,7 +103,7 @@ def test_vtab_shape_two_steps(golden_dir):
         for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
             ref = float(g["s%d_stat_%s" % (s, k)])
             assert abs(float(losses[i]) - ref) < 1e-4 * max(1.0, abs(ref)), (s, k, float(losses[i]), ref)
-        eng.adamw(float(g["meta_lr"]), float(g["meta_wd"]))
+        D.D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
         for key in g:
             if key.startswith("s%d_param_after/" % s):
                 n = key.split("/", 1)[1]

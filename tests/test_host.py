@@ -184,3 +184,40 @@ def test_checkpoint_roundtrip(tmp_path):
     assert args.start_epoch == 2
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_fused_adamw_state_dict_is_torch_adamw_layout():
+    """FusedAdamW.load_state_dict / state_dict speak torch.optim.AdamW's layout (the reference's optimizer, main_image.py:285;
+    checkpoint format misc.py:296-352) -- checked without a GPU: the state of a real torch.optim.AdamW over the 74 trainable
+    tensors loads before any engine exists and comes back identical."""
+    from engine_finetune import FusedAdamW
+    m = _model()
+    names = [n for n, p in m.named_parameters() if synth.is_trainable(n)]
+    params = [torch.nn.Parameter(torch.zeros_like(dict(m.named_parameters())[n])) for n in names]
+    topt = torch.optim.AdamW(params, lr=3e-4, weight_decay=0.05)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(2):
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g)
+        topt.step()
+    sd = topt.state_dict()
+    opt = FusedAdamW(m, lr=1.0, weight_decay=0.0)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 2 and opt.param_groups[0]["lr"] == 3e-4 and opt.param_groups[0]["weight_decay"] == 0.05
+    back = opt.state_dict()
+    assert back["param_groups"][0]["params"] == list(range(74)) and len(back["state"]) == 74
+    for i in range(74):
+        assert torch.equal(back["state"][i]["exp_avg"], sd["state"][i]["exp_avg"])
+        assert torch.equal(back["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+        assert float(back["state"][i]["step"]) == 2.0
+    topt2 = torch.optim.AdamW(params, lr=1.0)
+    topt2.load_state_dict(back)                       # and torch accepts what we write
+    assert topt2.param_groups[0]["lr"] == 3e-4
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"state": {}, "param_groups": [{"params": [0, 1]}]})
+
+
+def test_step_seed_is_unique_across_epochs():
+    from engine_finetune import step_seed
+    seen = {step_seed(e, it, base=1234) for e in range(40) for it in range(9000)}
+    assert len(seen) == 40 * 9000
