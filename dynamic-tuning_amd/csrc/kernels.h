@@ -39,7 +39,7 @@ struct GemmArgs {
     void* out_at3 = nullptr;
     const float* resid = nullptr;
     const void* aux_at = nullptr;     // z (GELU_BWD) / d_act (AD_DGRAD_UP)
-    const int* row_map = nullptr;     // FC2 / AD_UP scatter, AD_DOWN mask index: compact row -> token row
+    const int* row_map = nullptr;     // FC2 / AD_UP scatter, AD_DOWN mask index, GELU_BWD aux index: compact row -> token row
     const float* row_mask = nullptr;  // FC2 masked-dense: per-token mask
     void* h_out = nullptr;            // FC2: save h (AT)
     const uint8_t* keep = nullptr;    // AD_DOWN injected keep mask [M, r]
@@ -109,6 +109,10 @@ int launch_gate(const GateArgs& a, hipStream_t s);
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
                      int* row_src, int* dst_of, int batch, hipStream_t s);
+
+// the index half of launch_ln_gather alone (dense forward that is followed by a compacted backward): row_src, dst_of, total
+int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,
+                        int batch, hipStream_t s);
 
 // last block: LayerNorm of the cls rows only (out[b] = LN(u[b*197])), stats[b*197], u_cls[b] = AT(u[b*197])
 int launch_ln_cls(int precision, const float* u, const float* w, const float* b, void* out, float2* stats, void* u_cls,

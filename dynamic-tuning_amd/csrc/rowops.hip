@@ -211,6 +211,40 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
     }
 }
 
+// token dispatcher index arrays without the gather (one thread per token): see ln_gather_kernel for the roles
+__global__ __launch_bounds__(256) void gather_index_kernel(const int* __restrict__ keep_local, const int* __restrict__ counts,
+                                                           int* __restrict__ total, const float* __restrict__ maskf,
+                                                           int* __restrict__ row_src, int* __restrict__ dst_of, int batch) {
+    __shared__ int off_s;
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j < 64) {   // exclusive prefix of the per-image counts (block 0 also publishes the grand total)
+        const int lim = b == 0 ? batch : b;
+        int part = 0;
+        for (int i = j; i < lim; i += 64) part += counts[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (j == 0) {
+            off_s = b == 0 ? 0 : part;
+            if (b == 0) total[0] = part;
+        }
+    }
+    __syncthreads();
+    if (j >= NT) return;
+    const int slot = b * NT + j;
+    if (maskf[slot] == 0.f) dst_of[slot] = -1;
+    if (j < counts[b]) {
+        const int src = b * NT + keep_local[(size_t)b * NT + j];
+        row_src[off_s + j] = src;
+        dst_of[src] = off_s + j;
+    }
+}
+int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,
+                        int batch, hipStream_t s) {
+    hipLaunchKernelGGL(gather_index_kernel, dim3(batch), dim3(256), 0, s, keep_local, counts, total, maskf, row_src, dst_of, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
                      int* row_src, int* dst_of, int batch, hipStream_t s) {

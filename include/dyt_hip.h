@@ -41,8 +41,11 @@ extern "C" {
 #define DYT_F_COMPLETE 2       /* forward(x, complete_model=True): mask not applied (vision_transformer_IN21K.py:161) */
 #define DYT_F_SAVE 4           /* keep activations of this pass in `slot` for dyt_backward */
 #define DYT_F_MASKED_DENSE 8   /* student pass computes the MLP for every token and multiplies by the
-                                  mask, exactly as the reference trains (vision_transformer_IN21K.py:159-162);
-                                  default is the compacted MLP of models/model_speed_test.py:274-310 */
+                                  mask, exactly as the reference trains (vision_transformer_IN21K.py:159-162), so
+                                  the gate of a DROPPED token still receives <dL/dx', mlp(x)>; its backward is
+                                  compacted all the same (rows of mask * dL/dx' of dropped tokens are exactly zero):
+                                  the reference's gradients at 133.5 instead of 139.6 GFLOP / image.
+                                  Default is the compacted MLP of models/model_speed_test.py:274-310, forward too */
 #define DYT_F_ACCUM_GRAD 32    /* dyt_step_fwd_bwd: add to grad_flat instead of overwriting it -- gradient accumulation over
                                   accum_iter micro-batches (engine_finetune.py:43-46,66-76; fold 1/accum_iter into dyt_adamw's grad_scale) */
 #define DYT_F_DEVICE_SEED 64   /* the Philox seed is read from the context's device-side seed word (dyt_seed) instead of the
