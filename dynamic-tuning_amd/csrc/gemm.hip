@@ -161,14 +161,16 @@ struct EpiFc2 {
     }
 };
 
-template <class AT>
+// MAPPED: gp is indexed by TOKEN row (dense "masked" forward) while this GEMM runs on compact rows.  A separate
+// instantiation: the extra index load in front of every gelu' load costs the unmapped kernel 37 % (142 -> 195 us at B=128)
+template <class AT, bool MAPPED>
 struct EpiGeluBwd {
     const AT* gp; AT* out; int ld;   // gp = gelu'(z) saved by the fc1 epilogue
-    const int* row_map;              // gp is indexed by TOKEN row (dense forward) while this GEMM runs on compact rows, or null
+    const int* row_map;
     typedef NoCtx Col; typedef Raw4<AT> Pre;
     __device__ __forceinline__ Col col_init(int) const { return {}; }
     __device__ __forceinline__ Pre pre(int row, int col) const {   // gelu'(z) is read exactly once: streaming load
-        const size_t src = (size_t)(row_map ? row_map[row] : row) * ld + col;
+        const size_t src = (size_t)(MAPPED ? row_map[row] : row) * ld + col;
         if constexpr (sizeof(AT) == 2) {
             Pre p;
             p.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(gp + src));
@@ -800,7 +802,9 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             if (a.out_at2) return run<AT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
             return run<AT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
         case EPI_FC2: return run<AT>(a, EpiFc2<AT>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out}, s);
-        case EPI_GELU_BWD: return run<AT>(a, EpiGeluBwd<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
+        case EPI_GELU_BWD:
+            if (a.row_map) return run<AT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
+            return run<AT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
         case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
         case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
@@ -848,8 +852,8 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 14: return launch_bf16_cfg<256, 256, 2, 4, 2>(a, epi, s);
         case 60: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
         case 65: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
-        case 66: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiGeluBwd<bf16>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N, nullptr}, s);
-        case 62: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiGeluBwd<bf16>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N, nullptr}, s);
+        case 66: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiGeluBwd<bf16, false>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N, nullptr}, s);
+        case 62: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiGeluBwd<bf16, false>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N, nullptr}, s);
     }
     set_error("gemm_raw: unknown variant %d", variant);
     return -1;

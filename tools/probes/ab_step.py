@@ -1,0 +1,34 @@
+"""A/B timing of the fused step (B=128, bf16, compact) with the library given by DYT_LIB_PATH (default: in-tree)."""
+import os, sys, time, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import _lib, synth
+if os.environ.get("DYT_LIB_PATH"):
+    _lib.LIB_PATH = os.environ["DYT_LIB_PATH"]
+    L = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
+    probe = ctypes.CDLL(_lib.LIB_PATH)
+    _lib.SYMBOLS = {k: v for k, v in _lib.SYMBOLS.items() if hasattr(probe, k)}
+import test_gpu_round2 as T
+B = 128
+mode = os.environ.get("PMODE", "compact")
+m, _ = T._bench_model("bf16", mode, B, 0.85)
+m.train()
+x, y = synth.make_batch(B, 100, seed=61)
+x, y = x.cuda(), y.cuda()
+eng = m.engine(B, x.device)
+mm, vv = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+if os.environ.get("DYT_NO_OVERLAP"):
+    eng.set_option(_lib.OPT_STREAM_OVERLAP, 0)
+def step(i):
+    eng.step_fwd_bwd(x, y, 0.7, 2.0, 0.0, 0.0, seed=900 + i, masked_dense=(mode == "masked"))
+    _lib.check(eng.L.dyt_adamw(_lib.ptr(eng.flat), _lib.ptr(eng.grad), _lib.ptr(mm), _lib.ptr(vv), eng.n_train, i + 1, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, _lib.stream_ptr()))
+for i in range(5):
+    step(i)
+torch.cuda.synchronize()
+for rep in range(3):
+    t0 = time.perf_counter()
+    for i in range(20):
+        step(5 + i)
+    torch.cuda.synchronize()
+    print("%s: %.2f ms/step" % (os.environ.get("DYT_LIB_PATH", "in-tree"), (time.perf_counter() - t0) / 20 * 1e3), flush=True)
