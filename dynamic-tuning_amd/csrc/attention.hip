@@ -70,43 +70,88 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ src, int ld,
     }
 }
 
+// The same staging in two halves, so that a persistent workgroup can have the NEXT head's rows in flight (registers) while it
+// computes on the current one: 896 tasks (row pair x 16-B chunk) over 448 threads = 2 tasks = 4 x 16 B per thread and matrix.
+struct StageRegs { bf16x8 a[2], b[2]; };
+__device__ __forceinline__ void stage_load(StageRegs& r, const bf16* __restrict__ src, int ld, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + u * 448, pr = t >> 3, c = t & 7, r0 = pr * 2;
+        // unconditional loads from clamped rows (no exec-masked branches in front of the loads); pad rows are zeroed afterwards
+        r.a[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)min(r0, NT - 1) * ld + c * 8);
+        r.b[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)min(r0 + 1, NT - 1) * ld + c * 8);
+    }
+}
+__device__ __forceinline__ void stage_store(const StageRegs& r, bf16* rowimg, bf16* trimg, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + u * 448, pr = t >> 3, c = t & 7, r0 = pr * 2;
+        const bf16x8 a = r0 < NT ? r.a[u] : zero8(), b = r0 + 1 < NT ? r.b[u] : zero8();
+        if (rowimg) {
+            *reinterpret_cast<bf16x8*>(rowimg + r0 * RLD + c * 8) = a;
+            *reinterpret_cast<bf16x8*>(rowimg + (r0 + 1) * RLD + c * 8) = b;
+        }
+        if (trimg) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                bf16x2 pv = {a[i], b[i]};
+                *reinterpret_cast<bf16x2*>(trimg + (c * 8 + i) * TLD + r0) = pv;
+            }
+        }
+    }
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------
 // forward, bf16
 // ------------------------------------------------------------------------------------------
+// Persistent: workgroup w walks the (image, head) pairs w, w + gridDim.x, ...; while it computes on one head the K, V and
+// Q rows of the next are already in flight into registers (the staging's HBM/L2 latency was 1/3 of the kernel).
 __global__ __launch_bounds__(448) void attn_fwd_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                             const bf16* __restrict__ v, bf16* __restrict__ out,
-                                                            float* __restrict__ lse) {
+                                                            float* __restrict__ lse, int nheads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);
     bf16* Vt = reinterpret_cast<bf16*>(smem + ROW_IMG);
-    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
-    const bf16* qb = q + (size_t)bh * NT * HD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_rows<448>(k + (size_t)bh * NT * HD, HD, Ks, nullptr, tid);
-    stage_rows<448>(v + (size_t)bh * NT * HD, HD, nullptr, Vt, tid);
-    __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5;
-
-    {   // one 32-row query tile per wave (7 waves)
-        const int qt = wave;
-        const int qrow = qt * 32 + l31;
-        const int qr = min(qrow, NT - 1);
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);   // one 32-row query tile per wave (7 waves)
+    StageRegs kr, vr;
+    bf16x8 qn[4];
+    auto prefetch = [&](int bh) {
+        stage_load(kr, k + (size_t)bh * NT * HD, HD, tid);
+        stage_load(vr, v + (size_t)bh * NT * HD, HD, tid);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qn[ks] = *reinterpret_cast<const bf16x8*>(q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8);
+    };
+    int bh = blockIdx.x;
+    if (bh < nheads) prefetch(bh);
+    for (; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        stage_store(kr, Ks, nullptr, tid);
+        stage_store(vr, nullptr, Vt, tid);
         bf16x8 qf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + qr * HD + ks * 16 + hi * 8);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+        __syncthreads();
+        if (bh + gridDim.x < nheads) prefetch(bh + gridDim.x);   // lands while this head is computed
         f32x16 st[7];
 #pragma unroll
-        for (int kt = 0; kt < 7; ++kt) {
+        for (int kt = 0; kt < 7; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+        // S^T = K Q^T: the seven key tiles are independent accumulators -- walk them inside each k step so that consecutive
+        // MFMAs never depend on each other, and read a whole k step's fragments ahead of its MFMAs
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
-                st[kt] = MFMA32(a, qf[ks], st[kt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[7];
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt) a[kt] = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt) st[kt] = MFMA32(a[kt], qf[ks], st[kt]);
         }
         // st[kt][r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*hi][q = l31]; mask the pad keys
 #pragma unroll
@@ -114,40 +159,42 @@ __global__ __launch_bounds__(448) void attn_fwd_bf16_kernel(const bf16* __restri
             const int key = 192 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (key >= NT) st[6][r] = -INFINITY;
         }
-        float m = -INFINITY;
+        float mp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // independent chains: the reductions are latency-, not issue-bound
 #pragma unroll
         for (int kt = 0; kt < 7; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, st[kt][r]);
+            for (int r = 0; r < 16; ++r) mp[r & 3] = fmaxf(mp[r & 3], st[kt][r]);
+        float m = fmaxf(fmaxf(mp[0], mp[1]), fmaxf(mp[2], mp[3]));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 7; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(st[kt][r] - m);
-                st[kt][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = m + __logf(sum);
-
+        // exp, row sum and O^T = V^T P^T per key tile in one loop: the 4 MFMAs of tile kt execute while the VALU works on the
+        // exponentials of tile kt+1 (as two separate loops the matrix pipe idled through the whole softmax and vice versa)
+        float sp[4] = {0.f, 0.f, 0.f, 0.f};
         f32x16 o[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
 #pragma unroll
-        for (int kt = 0; kt < 7; ++kt)
+        for (int kt = 0; kt < 7; ++kt) {
+            bf16x8 vf[2][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) vf[half][dt] = join44(Vt + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(st[kt][r] - m);
+                st[kt][r] = p;
+                sp[r & 3] += p;
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const bf16x8 pf = pack8(st[kt], half * 8);
-                const int keybase = kt * 32 + half * 16 + 4 * hi;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 vf = join44(Vt + (dt * 32 + l31) * TLD + keybase);
-                    o[dt] = MFMA32(vf, pf, o[dt]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(vf[half][dt], pf, o[dt]);
             }
+        }
+        float sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        sum += __shfl_xor(sum, 32, 64);
+        if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = m + __logf(sum);
         if (qrow < NT) {
             const float inv = 1.0f / sum;
             bf16* op = out + ((size_t)b * NT + qrow) * D + h * HD;
@@ -158,6 +205,7 @@ __global__ __launch_bounds__(448) void attn_fwd_bf16_kernel(const bf16* __restri
                     store4(op + dt * 32 + 8 * g + 4 * hi, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
                            o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         }
+        __syncthreads();   // every wave is done with this head's K / V images before they are overwritten
     }
 }
 
@@ -613,8 +661,8 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
                            (const float*)v, (float*)out, lse);
     } else {
         const size_t lds = ROW_IMG + TR_IMG;
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(grid), dim3(448), lds, s, (const bf16*)q, (const bf16*)k,
-                           (const bf16*)v, (bf16*)out, lse);
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (bf16*)out, lse, grid);
     }
     DYT_HIP_CHECK(hipGetLastError());
     return 0;

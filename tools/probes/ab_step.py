@@ -23,12 +23,13 @@ if os.environ.get("DYT_NO_OVERLAP"):
 def step(i):
     eng.step_fwd_bwd(x, y, 0.7, 2.0, 0.0, 0.0, seed=900 + i, masked_dense=(mode == "masked"))
     _lib.check(eng.L.dyt_adamw(_lib.ptr(eng.flat), _lib.ptr(eng.grad), _lib.ptr(mm), _lib.ptr(vv), eng.n_train, i + 1, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, _lib.stream_ptr()))
-for i in range(5):
+NS = int(os.environ.get("PSTEPS", "20"))
+for i in range(min(5, NS)):
     step(i)
 torch.cuda.synchronize()
-for rep in range(3):
+for rep in range(int(os.environ.get("PREPS", "3"))):
     t0 = time.perf_counter()
-    for i in range(20):
+    for i in range(NS):
         step(5 + i)
     torch.cuda.synchronize()
-    print("%s: %.2f ms/step" % (os.environ.get("DYT_LIB_PATH", "in-tree"), (time.perf_counter() - t0) / 20 * 1e3), flush=True)
+    print("%s: %.2f ms/step" % (os.environ.get("DYT_LIB_PATH", "in-tree"), (time.perf_counter() - t0) / NS * 1e3), flush=True)
