@@ -212,72 +212,90 @@ __global__ __launch_bounds__(448) void attn_fwd_bf16_kernel(const bf16* __restri
 // ------------------------------------------------------------------------------------------
 // backward, bf16: dQ (+ delta = rowsum(dO * O)) per query tile
 // ------------------------------------------------------------------------------------------
+// Persistent over heads like the forward kernel (next head's K, V and this wave's q / dO / O rows in flight during the
+// current one).
 __global__ __launch_bounds__(448) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                                const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ dout,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
-                                                               bf16* __restrict__ dqkv) {
+                                                               bf16* __restrict__ dqkv, int nheads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);
     bf16* Vs = reinterpret_cast<bf16*>(smem + ROW_IMG);
     bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG);
-    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
-    const bf16* qb = q + (size_t)bh * NT * HD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_rows<448>(k + (size_t)bh * NT * HD, HD, Ks, Kt, tid);
-    stage_rows<448>(v + (size_t)bh * NT * HD, HD, Vs, nullptr, tid);
-    __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5;
-
-    {   // one 32-row query tile per wave (7 waves)
-        const int qt = wave;
-        const int qrow = qt * 32 + l31;
-        const int qr = min(qrow, NT - 1);
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);   // one 32-row query tile per wave (7 waves)
+    StageRegs kr, vr;
+    bf16x8 qn[4], don[4], on[4];
+    float Ln = 0.f;
+    auto prefetch = [&](int bh) {
+        const int b = bh / NH, h = bh - b * NH;
+        stage_load(kr, k + (size_t)bh * NT * HD, HD, tid);
+        stage_load(vr, v + (size_t)bh * NT * HD, HD, tid);
         const size_t trow = ((size_t)b * NT + qr) * D + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qn[ks] = *reinterpret_cast<const bf16x8*>(q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8);
+            don[ks] = *reinterpret_cast<const bf16x8*>(dout + trow + ks * 16 + hi * 8);
+            on[ks] = *reinterpret_cast<const bf16x8*>(o + trow + ks * 16 + hi * 8);
+        }
+        Ln = lse[(size_t)bh * NT + qr];
+    };
+    int bh = blockIdx.x;
+    if (bh < nheads) prefetch(bh);
+    for (; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        stage_store(kr, Ks, Kt, tid);
+        stage_store(vr, Vs, nullptr, tid);
         bf16x8 qf[4], dof[4];
         float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(qb + qr * HD + ks * 16 + hi * 8);
-            dof[ks] = *reinterpret_cast<const bf16x8*>(dout + trow + ks * 16 + hi * 8);
-            const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + trow + ks * 16 + hi * 8);
+            qf[ks] = qn[ks]; dof[ks] = don[ks];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dl += (float)dof[ks][i] * (float)of[i];
+            for (int i = 0; i < 8; ++i) dl += (float)don[ks][i] * (float)on[ks][i];
         }
+        const float L = Ln;
         dl += __shfl_xor(dl, 32, 64);
-        const float L = lse[(size_t)bh * NT + qr];
         if (hi == 0 && qrow < NT) delta[(size_t)bh * NT + qrow] = dl;
+        __syncthreads();
+        if (bh + gridDim.x < nheads) prefetch(bh + gridDim.x);
 
         f32x16 dq[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
-#pragma unroll 1
-        for (int kt = 0; kt < 7; ++kt) {
-            f32x16 s, dp;
+        auto scores = [&](int kt, f32x16& s_, f32x16& dp_) {   // S^T[key][q], dP^T[key][q] of key tile kt
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp_[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
                 const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
-                s = MFMA32(ka, qf[ks], s);      // S^T[key][q]
-                dp = MFMA32(va, dof[ks], dp);   // dP^T[key][q]
+                s_ = MFMA32(ka, qf[ks], s_);
+                dp_ = MFMA32(va, dof[ks], dp_);
             }
+        };
+#pragma unroll 1
+        for (int kt = 0; kt < 7; ++kt) {
+            f32x16 s_, dp_;
+            scores(kt, s_, dp_);
+            bf16x8 kf[2][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) kf[half][dt] = join44(Kt + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float p = key < NT ? __expf(s[r] - L) : 0.f;
-                s[r] = p * (dp[r] - dl);        // dS^T
+                const float p = key < NT ? __expf(s_[r] - L) : 0.f;
+                s_[r] = p * (dp_[r] - dl);        // dS^T
             }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const bf16x8 dsf = pack8(s, half * 8);
-                const int keybase = kt * 32 + half * 16 + 4 * hi;
+                const bf16x8 dsf = pack8(s_, half * 8);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 kf = join44(Kt + (dt * 32 + l31) * TLD + keybase);
-                    dq[dt] = MFMA32(kf, dsf, dq[dt]);  // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-                }
+                for (int dt = 0; dt < 2; ++dt) dq[dt] = MFMA32(kf[half][dt], dsf, dq[dt]);  // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
             }
         }
         if (qrow < NT) {
@@ -289,18 +307,20 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_bf16_kernel(const bf16* __res
                     store4(op + dt * 32 + 8 * g + 4 * hi, dq[dt][4 * g] * 0.125f, dq[dt][4 * g + 1] * 0.125f,
                            dq[dt][4 * g + 2] * 0.125f, dq[dt][4 * g + 3] * 0.125f);
         }
+        __syncthreads();   // every wave is done with this head's images before they are overwritten
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, bf16: dK, dV per key tile (8 waves, waves 0..6 own one 32-key tile each)
+// backward, bf16: dK, dV per key tile
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+// 7 waves, one 32-key tile each; persistent over heads with the next head's Q / dO rows (and lse, delta) in flight.
+__global__ __launch_bounds__(448) void attn_bwd_dkv_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                                 const bf16* __restrict__ v,
                                                                 const bf16* __restrict__ dout,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
-                                                                bf16* __restrict__ dqkv) {
+                                                                bf16* __restrict__ dqkv, int nheads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Qs = reinterpret_cast<bf16*>(smem);
     bf16* dOs = reinterpret_cast<bf16*>(smem + ROW_IMG);
@@ -308,85 +328,96 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16* __re
     bf16* dOt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG + TR_IMG);
     float* lse_s = reinterpret_cast<float*>(smem + 2 * ROW_IMG + 2 * TR_IMG);
     float* del_s = lse_s + NPAD;
-    const int bh = blockIdx.x, b = bh / NH, h = bh - b * NH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_rows<512>(q + (size_t)bh * NT * HD, HD, Qs, Qt, tid);
-    stage_rows<512>(dout + (size_t)b * NT * D + h * HD, D, dOs, dOt, tid);
-    if (tid < NPAD) {
-        lse_s[tid] = tid < NT ? lse[(size_t)bh * NT + tid] : 0.f;
-        del_s[tid] = tid < NT ? delta[(size_t)bh * NT + tid] : 0.f;
-    }
-    __syncthreads();
-    if (wave >= 7) return;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int kt = wave;
-    const int key = kt * 32 + l31;
-    const int kr = min(key, NT - 1);
-    const bf16* kb = k + ((size_t)bh * NT + kr) * HD;
-    const bf16* vb = v + ((size_t)bh * NT + kr) * HD;
-    bf16x8 kf[4], vf[4];
+    const int key = wave * 32 + l31, kr_ = min(key, NT - 1);
+    StageRegs qr, dr;
+    float ln = 0.f, dn = 0.f;
+    auto prefetch = [&](int bh) {
+        const int b = bh / NH, h = bh - b * NH;
+        stage_load(qr, q + (size_t)bh * NT * HD, HD, tid);
+        stage_load(dr, dout + (size_t)b * NT * D + h * HD, D, tid);
+        if (tid < NPAD) {
+            ln = tid < NT ? lse[(size_t)bh * NT + tid] : 0.f;
+            dn = tid < NT ? delta[(size_t)bh * NT + tid] : 0.f;
+        }
+    };
+    int bh = blockIdx.x;
+    if (bh < nheads) prefetch(bh);
+    for (; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        const bf16* kb = k + ((size_t)bh * NT + kr_) * HD;
+        const bf16* vb = v + ((size_t)bh * NT + kr_) * HD;
+        bf16x8 kf[4], vf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(kb + ks * 16 + hi * 8);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(vb + ks * 16 + hi * 8);
-    }
-    f32x16 aK[2], aV[2];
+        for (int ks = 0; ks < 4; ++ks) {   // this head's key / value rows of the wave's tile: land during the staging stores
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kb + ks * 16 + hi * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vb + ks * 16 + hi * 8);
+        }
+        stage_store(qr, Qs, Qt, tid);
+        stage_store(dr, dOs, dOt, tid);
+        if (tid < NPAD) { lse_s[tid] = ln; del_s[tid] = dn; }
+        __syncthreads();
+        if (bh + gridDim.x < nheads) prefetch(bh + gridDim.x);
+        f32x16 aK[2], aV[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
 
 #pragma unroll 1
-    for (int qt = 0; qt < 7; ++qt) {
-        f32x16 s, dp;
+        for (int qt = 0; qt < 7; ++qt) {
+            f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
-            const bf16x8 da = *reinterpret_cast<const bf16x8*>(dOs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
-            s = MFMA32(qa, kf[ks], s);     // S[q][key]   (rows q in registers, column key = lane)
-            dp = MFMA32(da, vf[ks], dp);   // dP[q][key]
-        }
-        f32x16 p;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int q0 = qt * 32 + 8 * g + 4 * hi;
-            const float4 L4 = *reinterpret_cast<const float4*>(lse_s + q0);
-            const float4 D4 = *reinterpret_cast<const float4*>(del_s + q0);
-            const float Ls[4] = {L4.x, L4.y, L4.z, L4.w};
-            const float Ds[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const bool ok = (q0 + e < NT) && (key < NT);
-                const float pv = ok ? __expf(s[r] - Ls[e]) : 0.f;
-                p[r] = pv;
-                s[r] = pv * (dp[r] - Ds[e]);  // dS
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                const bf16x8 da = *reinterpret_cast<const bf16x8*>(dOs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                s = MFMA32(qa, kf[ks], s);     // S[q][key]   (rows q in registers, column key = lane)
+                dp = MFMA32(da, vf[ks], dp);   // dP[q][key]
             }
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bf16x8 pf = pack8(p, half * 8);
-            const bf16x8 dsf = pack8(s, half * 8);
-            const int qbase = qt * 32 + half * 16 + 4 * hi;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 dot = join44(dOt + (dt * 32 + l31) * TLD + qbase);
-                const bf16x8 qtf = join44(Qt + (dt * 32 + l31) * TLD + qbase);
-                aV[dt] = MFMA32(dot, pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
-                aK[dt] = MFMA32(qtf, dsf, aK[dt]);  // dK^T[d][key] += Q^T[d][q] dS[q][key]
-            }
-        }
-    }
-    if (key < NT) {
-        bf16* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            f32x16 p;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + 8 * g + 4 * hi;
-                store4(op + D + d, aK[dt][4 * g], aK[dt][4 * g + 1], aK[dt][4 * g + 2], aK[dt][4 * g + 3]);
-                store4(op + 2 * D + d, aV[dt][4 * g], aV[dt][4 * g + 1], aV[dt][4 * g + 2], aV[dt][4 * g + 3]);
+                const int q0 = qt * 32 + 8 * g + 4 * hi;
+                const float4 L4 = *reinterpret_cast<const float4*>(lse_s + q0);
+                const float4 D4 = *reinterpret_cast<const float4*>(del_s + q0);
+                const float Ls[4] = {L4.x, L4.y, L4.z, L4.w};
+                const float Ds[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const bool ok = (q0 + e < NT) && (key < NT);
+                    const float pv = ok ? __expf(s[r] - Ls[e]) : 0.f;
+                    p[r] = pv;
+                    s[r] = pv * (dp[r] - Ds[e]);  // dS
+                }
             }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8 pf = pack8(p, half * 8);
+                const bf16x8 dsf = pack8(s, half * 8);
+                const int qbase = qt * 32 + half * 16 + 4 * hi;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 dot = join44(dOt + (dt * 32 + l31) * TLD + qbase);
+                    const bf16x8 qtf = join44(Qt + (dt * 32 + l31) * TLD + qbase);
+                    aV[dt] = MFMA32(dot, pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                    aK[dt] = MFMA32(qtf, dsf, aK[dt]);  // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                }
+            }
+        }
+        if (key < NT) {
+            bf16* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * hi;
+                    store4(op + D + d, aK[dt][4 * g], aK[dt][4 * g + 1], aK[dt][4 * g + 2], aK[dt][4 * g + 3]);
+                    store4(op + 2 * D + d, aV[dt][4 * g], aV[dt][4 * g + 1], aV[dt][4 * g + 2], aV[dt][4 * g + 3]);
+                }
+        }
+        __syncthreads();   // every wave is done with this head's images before they are overwritten
     }
 }
 
@@ -693,10 +724,10 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
             if (set_lds((const void*)attn_bwd_dkv_bf16_kernel, lds2)) return -2;
             once = true;
         }
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(grid), dim3(448), lds1, s, (const bf16*)q, (const bf16*)k,
-                           (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv);
-        hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(grid), dim3(512), lds2, s, (const bf16*)q, (const bf16*)k,
-                           (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds1, s, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
     }
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
