@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
 F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED = 1, 2, 4, 8, 16, 32, 64
-OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0 = 1, 2, 3
+OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS = 1, 2, 3, 4
 
 # enum dyt_param (include/dyt_hip.h)
 (P_CLS, P_POS, P_PE_W, P_PE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_PROJ_W, P_PROJ_B, P_LN2_W, P_LN2_B,

@@ -100,6 +100,7 @@ struct GateArgs {
     float* out_select;       // user tensor [B,depth,196] (pointer already offset to this layer) or null
     float* out_logits;       // idem
     int out_stride;          // depth*196
+    int force_first = 0;     // > 0: keep exactly the tokens n < force_first (Block.forward_count_flops), ignore the gate
     int* keep_local;         // [B,197] kept token ids per image, ascending
     int* counts;             // [B]
 };

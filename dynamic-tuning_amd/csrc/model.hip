@@ -168,6 +168,7 @@ struct dyt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_b0 = nullptr;
     bool overlap = true;
     bool share_block0 = true;  // step: the teacher pass reuses the student's embedding + block-0 attention branch
+    int count_flops_tokens = 0;  // > 0: Block.forward_count_flops -- MLP on the first n tokens of every image
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -538,6 +539,9 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_STREAM_OVERLAP: c->overlap = value != 0; return DYT_OK;
         case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0 && c->frames <= 1; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
+        case DYT_OPT_COUNT_FLOPS_TOKENS:
+            if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
+            c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
     }
     set_error("unknown option %d", option);
     return DYT_ERR_ARG;
@@ -804,7 +808,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             ga.out_select = token_select ? token_select + (size_t)l * NP : nullptr;
             ga.out_logits = token_logits ? token_logits + (size_t)l * NP : nullptr;
             ga.out_stride = depth * NP;
-            ga.keep_local = L.keep_local; ga.counts = counts;
+            ga.keep_local = L.keep_local; ga.counts = counts; ga.force_first = c->count_flops_tokens;
             RUN(2, 0, launch_gate(ga, s));
         }
         if (tail) {

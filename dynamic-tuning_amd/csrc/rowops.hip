@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gate_select_kernel(GateArgs a) {
                 }
             }
             const float sft = sigmoidf(z);
-            keep = sft > a.threshold;
+            keep = a.force_first > 0 ? n < a.force_first : sft > a.threshold;
             a.soft[t] = sft;
             a.maskf[t] = keep ? 1.0f : 0.0f;
             if (a.out_select) a.out_select[(size_t)b * a.out_stride + n - 1] = keep ? 1.0f : 0.0f;

@@ -265,6 +265,16 @@ class VisionTransformer(nn.Module):
             raise DyTError("DyT VisionTransformer runs on a HIP device only (input is on %s); there is no CPU path" % x.device)
         x = self.fold_input(x.float()).contiguous()
         eng = self.engine(x.shape[0], x.device)
+        # FLOP-probe variant (reference Block.forward_count_flops :167-185, set through
+        # `model.apply(lambda m: setattr(m, "count_flops", True))` / `token_select_num` as block_flops_dict.get_block_flops
+        # :33-55 does): every block runs its MLP on the first `token_select_num` tokens
+        probe = [int(b.token_select_num or 0) if b.count_flops else 0 for b in self.blocks]
+        if len(set(probe)) != 1:
+            raise NotImplementedError("count_flops / token_select_num must be set on every block alike (apply(setattr) does)")
+        if probe[0] != getattr(eng, "_count_flops_tokens", 0):
+            from _lib import OPT_COUNT_FLOPS_TOKENS
+            eng.set_option(OPT_COUNT_FLOPS_TOKENS, probe[0])
+            eng._count_flops_tokens = probe[0]
         g1 = g2 = None
         if gumbel is not None:
             g1, g2 = (t.to(x.device, torch.float32).contiguous() for t in gumbel)

@@ -242,8 +242,9 @@ class DyTEngine:
         return row_src, dst_of, counts, total
 
     def set_option(self, option, value):
-        """_lib.OPT_STREAM_OVERLAP / OPT_CLS_TAIL (scheduling only; results do not change)."""
-        check(self.L.dyt_ctx_set_option(self.h, int(option), int(bool(value))))
+        """_lib.OPT_STREAM_OVERLAP / OPT_CLS_TAIL / OPT_SHARE_BLOCK0 (scheduling only; results do not change);
+        OPT_COUNT_FLOPS_TOKENS takes the token count n (0 = off) of Block.forward_count_flops."""
+        check(self.L.dyt_ctx_set_option(self.h, int(option), int(value)))
 
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on):

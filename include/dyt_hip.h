@@ -124,6 +124,13 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
 #define DYT_OPT_STREAM_OVERLAP 1
 #define DYT_OPT_CLS_TAIL 2
 #define DYT_OPT_SHARE_BLOCK0 3
+/*   DYT_OPT_COUNT_FLOPS_TOKENS  value n in 1..197 (0 = off): the FLOP-probe variant of the reference,
+ *                           Block.forward_count_flops (vision_transformer_IN21K.py:167-185, driven by
+ *                           block_flops_dict.get_block_flops :33-55 through `count_flops` / `token_select_num`): every
+ *                           block runs its MLP on the FIRST n tokens of each image (cls + the first n-1 patch tokens)
+ *                           whatever the gate decides; token_select reports that forced pattern.  This one DOES change
+ *                           results. */
+#define DYT_OPT_COUNT_FLOPS_TOKENS 4
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library

@@ -99,7 +99,7 @@ def mlp(sd, p, x):
 
 
 def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="masked",
-          tau=5.0, threshold=0.5, drop_p=0.1):
+          tau=5.0, threshold=0.5, drop_p=0.1, count_flops_tokens=0):
     """Block.forward, models/vision_transformer_IN21K.py:144-165.
 
     mode="masked":   the reference's training semantics -- MLP on every token, multiplied by
@@ -114,6 +114,11 @@ def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="ma
     x = x + attention(sd, p, layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))  # :148
     sel, logits = token_select(sd, p, x, g1, g2, training, tau, threshold)  # :150-152
     adapt = adapter(sd, p, x, scale, keep_mask, drop_p)  # :157
+    if count_flops_tokens:  # Block.forward_count_flops :167-185: MLP on the first n tokens, gate result unused
+        n = count_flops_tokens
+        out = x + adapt
+        out[:, :n, :] = out[:, :n, :] + mlp(sd, p, layer_norm(x[:, :n, :], sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+        return out, sel, logits
     if complete_model or mode != "gather":
         h = mlp(sd, p, layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))  # :159
         if not complete_model:
@@ -157,7 +162,7 @@ def attentive_pool(sd, t, frames):
 
 def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=False,
             training=True, mode="masked", tau=5.0, threshold=0.5, drop_p=0.1, depth=DEPTH,
-            return_blocks=False, frames=1):
+            return_blocks=False, frames=1, count_flops_tokens=0):
     """VisionTransformer.forward, models/vision_transformer_IN21K.py:343-385.
 
     g1, g2: [depth, B, 196] Gumbel draws (None in eval); keep_masks: [depth, B*197, r]
@@ -177,7 +182,7 @@ def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=
         if training and keep_masks is not None:
             km = keep_masks[i].reshape(B, NTOK, -1)
         t, sel, lg = block(sd, i, t, a, b, km, scale, complete_model, training, mode,
-                           tau, threshold, drop_p)
+                           tau, threshold, drop_p, count_flops_tokens)
         sels.append(sel)
         logs.append(lg)
         xs.append(t)

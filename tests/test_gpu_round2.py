@@ -459,3 +459,28 @@ def test_unsupported_training_configurations_fail_loudly():
     m.blocks[3].adaptmlp.up_proj.weight.requires_grad = False
     with pytest.raises(NotImplementedError, match="freeze rule"):
         train_one_epoch(m, crit, [(x, y)], opt, dev, 0, args=args)
+
+
+@pytest.mark.parametrize("n", [1, 57, 197])
+def test_forward_count_flops_variant(n):
+    """Block.forward_count_flops (reference vision_transformer_IN21K.py:167-185), switched on the way
+    block_flops_dict.get_block_flops does (apply(setattr) of count_flops / token_select_num): MLP on the first n tokens of
+    every image, whatever the gate says -- logits vs the reference's own (tests/golden/count_flops.npz), and the dispatcher
+    really ran that pattern; switching it off restores the gated forward."""
+    g = dict(np.load(os.path.join(GOLDEN, "count_flops.npz")))
+    B = int(g["meta_batch"])
+    m, sd = D.build_model(g, "fp32")
+    m.eval()
+    x, _ = synth.make_batch(B, int(g["meta_num_classes"]), seed=int(g["meta_seed"]))
+    m.apply(lambda mod: setattr(mod, "count_flops", True))
+    m.apply(lambda mod: setattr(mod, "token_select_num", n))
+    with torch.no_grad():
+        got, aux = m(x.cuda())
+    assert float(np.abs(got.cpu().numpy() - g["logits_n%d" % n]).max()) < 1e-3
+    want = (torch.arange(1, 197) < n).float()
+    assert torch.equal(aux["token_select"][..., 0].cpu(), want.expand(B, 12, 196))
+    m.apply(lambda mod: setattr(mod, "count_flops", None))
+    with torch.no_grad():
+        back, aux2 = m(x.cuda())
+        ref2, tok2 = O.forward(sd, x, scale=0.1, training=False)
+    assert float((back.cpu() - ref2).abs().max()) < 1e-3 and not torch.equal(aux2["token_select"], aux["token_select"])

@@ -193,3 +193,15 @@ def test_video_trainable_grads(video):
         if "gradrows/" + n in g:
             ref = g["gradrows/" + n]
             assert np.abs(gr[::stride].numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, n
+
+
+def test_oracle_count_flops_variant_vs_reference(golden_dir):
+    """Block.forward_count_flops (reference :167-185) through the reference's own blocks: logits for 1 / 57 / 197 MLP tokens."""
+    g = dict(np.load(os.path.join(golden_dir, "count_flops.npz")))
+    sd = synth.make_state_dict(int(g["meta_num_classes"]), int(g["meta_ffn_num"]), seed=int(g["meta_seed"]), kind="test",
+                               gate_bias=float(g["meta_gate_bias"]))
+    x, _ = synth.make_batch(int(g["meta_batch"]), int(g["meta_num_classes"]), seed=int(g["meta_seed"]))
+    for n in g["tokens"]:
+        with torch.no_grad():
+            logits, _ = O.forward(sd, x, scale=float(g["meta_scale"]), training=False, count_flops_tokens=int(n))
+        assert np.abs(logits.numpy() - g["logits_n%d" % n]).max() < 2e-5, n
