@@ -15,6 +15,7 @@
 // Reference ops replaced: nn.Linear of Attention.qkv / .proj (models/vision_transformer_IN21K.py:56,73),
 // timm Mlp fc1/fc2 (:124-129,159), Adapter.down_proj/up_proj (models/dynamic_adapter.py:124-128),
 // PatchEmbed's Conv2d (:272-278) and their autograd dgrads.
+#include <type_traits>
 #include "kernels.h"
 
 namespace dyt {
@@ -139,25 +140,38 @@ struct EpiFc1 {
     }
 };
 
-template <class AT>
+// PLAIN = no row map and no row mask (teacher pass / dense rows): the per-chunk context is then just the 16 B of the residual,
+// small enough for the kernels to issue a whole pass of residual loads ahead of the staging barriers (PRE_ALL); with the
+// 32-byte {dst, mask, residual} context of the general form the loads sit right in front of their use.
+template <class AT, bool PLAIN>
 struct EpiFc2 {
     const float* bias; float* x; const int* row_map; const float* row_mask; AT* h_out;
     typedef Bias4 Col;
-    struct Pre { int dst; float m; Raw4<float> r; };
+    struct PreG { int dst; float m; Raw4<float> r; };
+    typedef typename std::conditional<PLAIN, Raw4<float>, PreG>::type Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int row, int col) const {
-        Pre p;
-        p.dst = row_map ? row_map[row] : row;
-        p.m = row_mask ? row_mask[p.dst] : 1.0f;
-        p.r = load_raw4(x + (size_t)p.dst * D + col);   // in place: this chunk is the only writer of these 4 values
-        return p;
+        if constexpr (PLAIN) {
+            return load_raw4(x + (size_t)row * D + col);
+        } else {
+            Pre p;
+            p.dst = row_map ? row_map[row] : row;
+            p.m = row_mask ? row_mask[p.dst] : 1.0f;
+            p.r = load_raw4(x + (size_t)p.dst * D + col);   // in place: this chunk is the only writer of these 4 values
+            return p;
+        }
     }
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         const float h0 = a[0] + c.b[0], h1 = a[1] + c.b[1], h2 = a[2] + c.b[2], h3 = a[3] + c.b[3];
         if (h_out) store4_nt(h_out + (size_t)row * D + col, h0, h1, h2, h3);   // read again only by the backward pass
         float r[4];
-        p.r.get(r);
-        store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);
+        if constexpr (PLAIN) {
+            p.get(r);
+            store4(x + (size_t)row * D + col, r[0] + h0, r[1] + h1, r[2] + h2, r[3] + h3);
+        } else {
+            p.r.get(r);
+            store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);
+        }
     }
 };
 
@@ -254,21 +268,28 @@ struct EpiAdDown {
     }
 };
 
+template <bool MAPPED>   // MAPPED: rows go through row_map (cls-only tail of the last block); see EpiFc2 for why two forms
 struct EpiAdUp {
     const float* bias; const float* u; float* out; float scale; const int* row_map;
     typedef Bias4 Col;
-    struct Pre { int dst; Raw4<float> r; };
+    struct PreG { int dst; Raw4<float> r; };
+    typedef typename std::conditional<MAPPED, PreG, Raw4<float>>::type Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int row, int col) const {
-        Pre p;
-        p.dst = row_map ? row_map[row] : row;
-        p.r = load_raw4(u + (size_t)p.dst * D + col);
-        return p;
+        if constexpr (MAPPED) {
+            Pre p;
+            p.dst = row_map[row];
+            p.r = load_raw4(u + (size_t)p.dst * D + col);
+            return p;
+        } else {
+            return load_raw4(u + (size_t)row * D + col);
+        }
     }
-    __device__ __forceinline__ void apply(int, int col, const float (&a)[4], const Col& c, const Pre& p) const {
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         float r[4];
-        p.r.get(r);
-        store4(out + (size_t)p.dst * D + col, r[0] + scale * (a[0] + c.b[0]), r[1] + scale * (a[1] + c.b[1]),
+        size_t dst = row;
+        if constexpr (MAPPED) { p.r.get(r); dst = p.dst; } else { p.get(r); }
+        store4(out + dst * D + col, r[0] + scale * (a[0] + c.b[0]), r[1] + scale * (a[1] + c.b[1]),
                r[2] + scale * (a[2] + c.b[2]), r[3] + scale * (a[3] + c.b[3]));
     }
 };
@@ -801,7 +822,9 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_FC1:
             if (a.out_at2) return run<AT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
             return run<AT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
-        case EPI_FC2: return run<AT>(a, EpiFc2<AT>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out}, s);
+        case EPI_FC2:
+            if (!a.row_map && !a.row_mask) return run<AT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out}, s);
+            return run<AT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out}, s);
         case EPI_GELU_BWD:
             if (a.row_map) return run<AT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
             return run<AT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
@@ -809,7 +832,9 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
             return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
-        case EPI_AD_UP: return run<AT>(a, EpiAdUp{a.bias, a.resid, a.out_f32, a.scale, a.row_map}, s);
+        case EPI_AD_UP:
+            if (a.row_map) return run<AT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map}, s);
+            return run<AT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
         case EPI_EMBED: return run<AT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
@@ -859,10 +884,14 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
     return -1;
 }
 
-// measurement hook: plain fp32 GEMM (exact-fp32 MFMA kernel, product dispatch) into an fp32 C
-int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s) {
+// measurement hook: fp32 GEMM (exact-fp32 MFMA kernel, product dispatch) into an fp32 C [M,N]
+// variant 0: plain store; 1: EpiAdUp reading the residual from C + M*N and writing C; 2: EpiStoreF32 accumulate (C += A W^T)
+int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s) {
     GemmArgs a; a.A = A; a.W = W; a.M = M; a.N = N; a.K = K;
-    return run_f32(a, EpiStoreAT<float>{static_cast<float*>(C), N}, s);
+    float* c = static_cast<float*>(C);
+    if (variant == 1) return run_f32(a, EpiAdUp<false>{nullptr, c + (size_t)M * N, c, 0.1f, nullptr}, s);
+    if (variant == 2) return run_f32(a, EpiStoreF32{c, N, 1}, s);
+    return run_f32(a, EpiStoreAT<float>{c, N}, s);
 }
 
 int gemm_debug_counters(unsigned long long* out4, int reset) {

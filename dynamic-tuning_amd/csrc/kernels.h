@@ -60,7 +60,7 @@ int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s);
 int gemm_debug_counters(unsigned long long* out4, int reset);
 long long gemm_kernel_launch_count(int reset);
 int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s);
-int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s);
+int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // attention (N = 197, d = 64, 12 heads); q pre-scaled by 1/8 in the QKV epilogue

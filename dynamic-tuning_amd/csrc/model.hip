@@ -1193,9 +1193,9 @@ extern "C" int dyt_gemm_bf16_raw(const void* a, const void* w, void* cmat, int M
     return launch_gemm_raw(a, w, cmat, M, N, K, variant, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int dyt_gemm_f32_raw(const float* a, const float* w, float* cmat, int M, int N, int K, void* stream) {
+extern "C" int dyt_gemm_f32_raw(const float* a, const float* w, float* cmat, int M, int N, int K, int variant, void* stream) {
     if (!a || !w || !cmat) { set_error("null argument"); return DYT_ERR_ARG; }
-    return launch_gemm_f32_raw(a, w, cmat, M, N, K, static_cast<hipStream_t>(stream));
+    return launch_gemm_f32_raw(a, w, cmat, M, N, K, variant, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dyt_debug_counters(uint64_t* out4, int reset) {

@@ -252,8 +252,9 @@ int dyt_gate_compact(const float* u, const float* w, const float* b, const float
  * (0 = product kernel; others are ablations used to attribute time, see csrc/gemm.hip) */
 int dyt_gemm_bf16_raw(const void* a, const void* w, void* c, int M, int N, int K, int variant, void* stream);
 /* C[M,N] (fp32) = A[M,K] (fp32) @ W[N,K]^T (fp32) on the exact-fp32 MFMA kernel of the parity mode (csrc/gemm_f32_mfma.h);
- * N % 64 == 0, K % 64 == 0; no synchronisation */
-int dyt_gemm_f32_raw(const float* a, const float* w, float* c, int M, int N, int K, void* stream);
+ * N % 64 == 0, K % 64 == 0; no synchronisation.  variant 0: plain store; 1: the adapter up-projection epilogue (residual read
+ * from c + M*N, c = resid + 0.1 * acc); 2: accumulate (c += acc) */
+int dyt_gemm_f32_raw(const float* a, const float* w, float* c, int M, int N, int K, int variant, void* stream);
 /* phase timers of the instrumented GEMM variants: cycles {prologue, main loop, epilogue} summed over
  * workgroups and the workgroup count; synchronises; optionally resets */
 int dyt_debug_counters(uint64_t* out4, int reset);
