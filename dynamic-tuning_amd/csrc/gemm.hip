@@ -344,8 +344,7 @@ __device__ unsigned long long g_gemm_dbg[4];
 //   128x128, 2x2 waves, 64 KB LDS, 2 workgroups / CU  -- N = 768 GEMMs (tile quantisation) and default
 //   256x256, 2x4 waves, 128 KB LDS, 1 workgroup / CU  -- wide-N GEMMs: half the L2->LDS bytes per FLOP
 //   128x64,  2x2 waves                                 -- adapter bottleneck (N = 64)
-// ABL (measurement only): 0 = product, 1 = no MFMA (loads + LDS reads only), 2 = no global loads,
-// 5 = per-k-step fragment loads (the first version's ordering)
+// ABL: 0 = product, 9 = the same kernel with the three phase timers (tools/gemm_bench.py)
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
@@ -477,10 +476,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
             // ---- block A: 32 MFMAs on set A, the 12 fragment reads of (kt, ks=1) -> set B slotted in between
             read_b(kt & 1);
             DYT_MMA(fwA, faA)
-            if (ABL != 3) {
-                DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R   // 24 MFMA, 8 reads
-                DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R                                       //  8 MFMA, 4 reads
-            }
+            DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R   // 24 MFMA, 8 reads
+            DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R                                       //  8 MFMA, 4 reads
             __builtin_amdgcn_sched_barrier(0);
             dma_wait_all();   // this wave's pieces of stage kt+1 have landed ...
             __syncthreads();  // ... everywhere; every wave's reads of slot kt&1 have returned
@@ -495,41 +492,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
                 const int so = fslot0 * 16;
 #define DYT_RA(i) faA[i] = *reinterpret_cast<const bf16x8*>(base + a_off + (i) * 2048 + so);
 #define DYT_RW(j) fwA[j] = *reinterpret_cast<const bf16x8*>(base + b_off + (j) * 2048 + so);
-                if (ABL == 6) {   // probe: all DMA pieces early in the block (more time to land), reads after
-#pragma unroll
-                    for (int d = 0; d < NDMA; ++d) stage_one(kt & 1, nxt, d);
-                    DYT_RA(0) DYT_RA(1) DYT_RA(2) DYT_RA(3) DYT_RA(4) DYT_RA(5) DYT_RA(6) DYT_RA(7)
-                    DYT_RW(0) DYT_RW(1) DYT_RW(2) DYT_RW(3)
-                } else {
                 DYT_RA(0) DYT_RA(1) stage_one(kt & 1, nxt, 0); DYT_RA(2) stage_one(kt & 1, nxt, 1);
                 DYT_RA(3) DYT_RA(4) stage_one(kt & 1, nxt, 2); DYT_RA(5) stage_one(kt & 1, nxt, 3);
                 DYT_RA(6) DYT_RA(7) stage_one(kt & 1, nxt, 4); DYT_RW(0) stage_one(kt & 1, nxt, 5);
                 DYT_RW(1) DYT_RW(2) stage_one(kt & 1, nxt, 6); DYT_RW(3) stage_one(kt & 1, nxt, 7);
-                }
 #undef DYT_RA
 #undef DYT_RW
             }
             DYT_MMA(fwB, faB)
-            if (ABL == 6) {
-#define DYT_SGD __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
-#define DYT_SGR1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-#define DYT_SGR2 __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD DYT_SGD                  // 16 MFMA, 8 DMA
-                DYT_SGR1 DYT_SGR1 DYT_SGR2 DYT_SGR1 DYT_SGR1 DYT_SGR2 DYT_SGR1 DYT_SGR1 DYT_SGR2 DYT_SGR1 DYT_SGR1 DYT_SGR2  // 16 MFMA, 12 reads
-#undef DYT_SGD
-#undef DYT_SGR1
-#undef DYT_SGR2
-            } else
-            if (ABL != 3) { DYT_SGB DYT_SGB DYT_SGB DYT_SGB }
+            DYT_SGB DYT_SGB DYT_SGB DYT_SGB
             __builtin_amdgcn_sched_barrier(0);
         }
         {   // last stage: nothing left to prefetch
             read_b((nk - 1) & 1);
             DYT_MMA(fwA, faA)
-            if (ABL != 3) {
-                DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R
-                DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R
-            }
+            DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R
+            DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R
             __builtin_amdgcn_sched_barrier(0);
             DYT_MMA(fwB, faB)
         }
@@ -538,63 +516,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
 #undef DYT_SG2R
 #undef DYT_SGB
     } else {
-    if (ABL != 2) stage(0, 0);
+    stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         dma_wait_all();
         __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
-        if (ABL != 2 && ABL != 4 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
-        if (BOTH_KS && ABL != 5 && ABL != 1) {
-            // issue all fragment reads of the K step, then the MFMAs: one LDS-latency exposure per step
-            // (ABL 4: the next stage's DMA pieces are issued one per few MFMAs instead of in a burst)
-            bf16x8 af[2][TM], wf[2][TN];
+        // issue all fragment reads of the K step, then the MFMAs: one LDS-latency exposure per step
+        bf16x8 af[2][TM], wf[2][TN];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = (ks == 0 ? fslot0 : fslot1) * 16;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
+            for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int NDMA = A_INSTR + B_INSTR, PER = 2 * TM * TN / NDMA;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-                        if (ABL == 4) {
-                            const int q = (ks * TM + i) * TN + j;
-                            if (PER > 0 && q % PER == PER - 1 && q / PER < NDMA) {
-                                if (kt + 1 < nk) stage_one((kt + 1) & 1, kt + 1, q / PER);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                    }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
-                bf16x8 af[TM], wf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + so);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (ABL == 1) {  // keep the fragment reads alive without the matrix pipe
-                            asm volatile("" ::"v"(wf[j]), "v"(af[i]));
-                        } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                        }
-                    }
-            }
+            for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     }  // main-loop variants
@@ -705,11 +651,13 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
     const int grid = ((m_end - m_begin + BM - 1) / BM) * (a.N / BN);
     const size_t lds = 2 * (BM + BN) * 64 * 2;
     auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per device: the attribute belongs to the (kernel, device) pair
+    int dev = 0;
+    DYT_HIP_CHECK(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
         DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi);
@@ -783,11 +731,13 @@ static int launch_f32_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     const size_t lds = 2 * (BM + BN) * 128;
     auto kern = gemm_f32_mfma_nt_kernel<BM, BN, 2, 2, Epi>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    DYT_HIP_CHECK(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
         DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, static_cast<const float*>(a.A), static_cast<const float*>(a.W),
                        a.M, a.N, a.K, a.m_dev, a.a_map, 0, epi);
@@ -851,34 +801,23 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
     EpiStoreAT<bf16> epi{static_cast<bf16*>(C), N};
     switch (variant) {
         case 0: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
-        case 1: return launch_bf16_cfg<128, 128, 2, 2, 1>(a, epi, s);
-        case 2: return launch_bf16_cfg<128, 128, 2, 2, 2>(a, epi, s);
-        case 4: return launch_bf16_cfg<128, 128, 2, 2, 4>(a, epi, s);
-        case 5: return launch_bf16_cfg<128, 128, 2, 2, 5>(a, epi, s);
-        case 9: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, epi, s);
-        case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
+        case 9: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, epi, s);     // + phase timers
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
-        case 30: return run_bf16(a, epi, s);
-        case 70: case 79: case 71: {   // pre-shuffled-weight kernel (test-only: shuffles W into a cached scratch buffer first)
+        case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
+        case 30: return run_bf16(a, epi, s);                               // the product dispatch (incl. the split-row scheme)
+        case 70: case 79: {   // pre-shuffled-weight kernel (test-only: shuffles W into a cached scratch buffer first)
             static bf16* wp = nullptr; static size_t wp_elems = 0;
             const size_t need = (size_t)N * K;
-            if (need > wp_elems) { if (wp) hipFree(wp); DYT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), need * 2)); wp_elems = need; }
+            if (need > wp_elems) {
+                if (wp) (void)hipFree(wp);
+                DYT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), need * 2));
+                wp_elems = need;
+            }
             if (launch_preshuffle_w(W, wp, N, K, s)) return -2;
             GemmArgs b = a; b.W = wp;
             if (variant == 70) return launch_bf16_bpre<0>(b, epi, s);
-            if (variant == 79) return launch_bf16_bpre<9>(b, epi, s);
-            return launch_bf16_bpre<0>(b, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
-        }   // the product dispatch (incl. the split-row scheme for narrow N)
-        case 15: return launch_bf16_cfg<256, 256, 2, 4, 3>(a, epi, s);
-        case 16: return launch_bf16_cfg<256, 256, 2, 4, 6>(a, epi, s);
-        case 11: return launch_bf16_cfg<256, 128, 4, 2, 0>(a, epi, s);
-        case 12: return launch_bf16_cfg<128, 256, 2, 4, 0>(a, epi, s);
-        case 13: return launch_bf16_cfg<256, 256, 2, 4, 1>(a, epi, s);
-        case 14: return launch_bf16_cfg<256, 256, 2, 4, 2>(a, epi, s);
-        case 60: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
-        case 65: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiFc1<bf16, true>{(const float*)W, static_cast<bf16*>(C), static_cast<bf16*>(C) + (size_t)M * N, N}, s);
-        case 66: return launch_bf16_cfg<128, 128, 2, 2, 0>(a, EpiGeluBwd<bf16, false>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N, nullptr}, s);
-        case 62: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiGeluBwd<bf16, false>{static_cast<const bf16*>(C) + (size_t)M * N, static_cast<bf16*>(C), N, nullptr}, s);
+            return launch_bf16_bpre<9>(b, epi, s);
+        }
     }
     set_error("gemm_raw: unknown variant %d", variant);
     return -1;

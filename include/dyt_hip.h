@@ -249,7 +249,7 @@ int dyt_gate_compact(const float* u, const float* w, const float* b, const float
 
 /* ---- measurement hooks (bench.py, tools/gemm_bench.py) ---- */
 /* C[M,N] (bf16) = A[M,K] (bf16) @ W[N,K]^T (bf16), fp32 accumulate; `variant` selects a kernel build
- * (0 = product kernel; others are ablations used to attribute time, see csrc/gemm.hip) */
+ * (0 / 10 / 70: the 128x128, 256x256 and pre-shuffled-weight kernels, 30: the product dispatch, 9 / 19 / 79: with phase timers) */
 int dyt_gemm_bf16_raw(const void* a, const void* w, void* c, int M, int N, int K, int variant, void* stream);
 /* C[M,N] (fp32) = A[M,K] (fp32) @ W[N,K]^T (fp32) on the exact-fp32 MFMA kernel of the parity mode (csrc/gemm_f32_mfma.h);
  * N % 64 == 0, K % 64 == 0; no synchronisation.  variant 0: plain store; 1: the adapter up-projection epilogue (residual read
