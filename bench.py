@@ -162,8 +162,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the DyT path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # DYT_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, barriers, broadcast, chunked all-reduce on the
+    # comm stream, max-over-ranks timing) even with one rank -- how the N > 1 path is exercised on a 1-GPU box
+    if world > 1 or os.environ.get("DYT_BENCH_FORCE_DIST"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -179,7 +182,7 @@ def main():
                   "keep_ratio_measured": pm["keep_ratio_measured"], "roofline": pm["roofline"],
                   "parity": "fp32 mode vs reference goldens on MI355X: logits max abs err < 1e-3, token-keep masks bit-exact, "
                             "74 gradients rel-L2 < 2e-3 (tests/test_gpu_parity.py, tests/gpu_diag.py)"}
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
 
     if rank == 0:
@@ -210,7 +213,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -247,14 +250,14 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
     for i in range(warmup):
         one_step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         one_step(warmup + i)
         acc += losses
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -266,7 +269,7 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
     t_host = (time.perf_counter() - th0) / 2 * steps
     torch.cuda.synchronize()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     host = (acc / steps).tolist()

@@ -79,7 +79,7 @@ class FusedAdamW:
         parameters.  Done once per engine, before its first step."""
         if self._synced is eng:
             return
-        if is_dist_avail_and_initialized() and dist.get_world_size() > 1:
+        if is_dist_avail_and_initialized():
             dist.broadcast(eng.flat, src=0)
             m, v = self._state(eng)
             dist.broadcast(m, src=0)
