@@ -48,27 +48,24 @@ def _grad_tol(name, precision):
     return 0.1
 
 
-@pytest.mark.parametrize("mode", ["masked", "compact"])
-def test_step_at_b16_vs_oracle(mode):
-    """BASELINE configs[0] size: M = 3152 token rows -> the bf16 path takes the 256x256 pipelined and the pre-shuffled-weight
-    GEMMs with EpiQKV / EpiFc1 / EpiGeluBwd / EpiFc2 / EpiBiasResid, the fp32 path the exact-fp32 MFMA kernels.  Logits, masks,
-    the five loss components and all 74 gradients of one fused step against the oracle on the same seeded inputs and draws."""
-    B, C, r = 16, 100, 64
-    x, y = synth.make_batch(B, C, seed=31)
-    g1, g2 = synth.make_noise(B, seed=32)
-    keep = synth.make_dropout_masks(B, r, seed=33)
+def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
+    """One fused step (logits, masks, the five loss components, all 74 gradients) against the oracle on the same seeded inputs
+    and draws, in both precisions."""
+    x, y = synth.make_batch(B, C, seed=seed)
+    g1, g2 = synth.make_noise(B, seed=seed + 1)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 2)
     sd = synth.make_state_dict(C, r, seed=0, kind="test", gate_bias=0.85)
-    d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=0.5)
+    d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
     ref_ls, ref_lt, ref_ts = ref_ls.detach(), ref_lt.detach(), tok["token_select"].detach()
     z = ((tok["token_logits"].detach()[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0).abs()   # decision margins [12,B,196]
     for prec in ("fp32", "bf16"):
-        m, _ = _bench_model(prec, mode, B, 0.85, kind="test")
+        m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
         ls = torch.empty(B, C, device="cuda")
         lt = torch.empty(B, C, device="cuda")
         ts = torch.zeros(B, 12, 196, device="cuda")
-        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
                                   g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
                                   token_select=ts).cpu()
         ltol = 1e-3 if prec == "fp32" else 0.03
@@ -79,7 +76,7 @@ def test_step_at_b16_vs_oracle(mode):
             assert int((flip & (z.permute(1, 0, 2) > 2e-5)).sum()) == 0, int(flip.sum())
             assert int(flip.sum()) <= 2
         else:
-            assert int(flip.sum()) <= 24, int(flip.sum())        # of 37632 decisions (measured: a handful)
+            assert int(flip.sum()) <= max(8, B * 3 // 2), int(flip.sum())   # of B*2352 decisions (measured: a handful at B=16)
         for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
             ref = float(d_ref[k])
             assert abs(float(losses[i]) - ref) < (1e-4 if prec == "fp32" else 0.02) * max(1.0, abs(ref)), (prec, k, float(losses[i]), ref)
@@ -89,9 +86,24 @@ def test_step_at_b16_vs_oracle(mode):
             e = float((got - gr).norm() / (gr.norm() + 1e-20))
             assert e < _grad_tol(n, prec), (prec, mode, n, e)
             worst[n.split(".", 2)[-1]] = max(worst.get(n.split(".", 2)[-1], 0.0), e)
-        print("B=16 %s/%s worst rel-L2 per tensor kind:" % (prec, mode), {k: "%.2e" % v for k, v in worst.items()})
+        print("%s %s/%s worst rel-L2 per tensor kind:" % (label, prec, mode), {k: "%.2e" % v for k, v in worst.items()})
         del m, eng
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["masked", "compact"])
+def test_step_at_b16_vs_oracle(mode):
+    """BASELINE configs[0] size: M = 3152 token rows -> the bf16 path takes the 256x256 pipelined and the pre-shuffled-weight
+    GEMMs with EpiQKV / EpiFc1 / EpiGeluBwd / EpiFc2 / EpiBiasResid, the fp32 path the exact-fp32 MFMA kernels."""
+    _step_vs_oracle(16, 100, 64, mode, 0.5)
+
+
+@pytest.mark.parametrize("B,C", [(8, 2), (8, 5), (64, 397)])
+def test_vtab_task_shapes_vs_oracle(B, C):
+    """BASELINE configs[2] (VTAB-1K sweep, train_vtab.sh: --batch_size 64 --ffn_num 16 --token_target_ratio 0.5): the smallest
+    (patch_camelyon 2, diabetic_retinopathy 5) and the largest (sun397) class counts of the 19 tasks with the rank-16 adapter,
+    the largest at the script's batch size; the reference's masked training mode."""
+    _step_vs_oracle(B, C, 16, "masked", 0.5, seed=131, label="VTAB B=%d C=%d" % (B, C))
 
 
 @pytest.mark.parametrize("precision,mode", [("fp32", "compact"), ("bf16", "compact"), ("bf16", "masked")])
