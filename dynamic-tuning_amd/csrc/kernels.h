@@ -177,7 +177,7 @@ int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s);
 //   du[t] = du[t] + LN2bwd(dA2[dst_of[t]]) (kept tokens) + dlogit[t]*wg ; du_at = AT(du)
 //   dlogit = (dmask[t] + dm_ext) * s(1-s)/tau + dtoken_logits ; partial dwg / dbg per block of rows
 struct TokBwdArgs {
-    float* du;                 // [M,768] in/out (holds g + adapter dgrad on entry)
+    float* du;                 // [M,768] in/out (holds g (+ the adapter dgrad when `dad` is null) on entry)
     const void* dA2;           // [K,768] AT gradient w.r.t. LN2 output (null: skip MLP part)
     const int* dst_of;         // [M] compact row of a token or -1 ; null = identity (dense)
     const float* u;            // [M,768]
@@ -197,6 +197,7 @@ struct TokBwdArgs {
     float* partial;            // [nblocks][769] dwg / dbg partials
     int M;
     int write_du;              // 0 for block 0 (du itself is not needed)
+    const void* dad = nullptr;     // [M,768] AT adapter dgrad to add to du (null: already accumulated into du)
     const float* g_cls = nullptr;  // last block: incoming gradient exists for the cls rows only ([B,768]);
                                    // du/dA2 are then read as (n == 0 ? g_cls[b] / dA2[b] : 0)
 };

@@ -102,7 +102,7 @@ struct LayerS {  // saved activations of one pass
     int *keep_local, *offsets, *total, *row_src, *dst_of;
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
-    void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn;
+    void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
     float *g, *delta, *dmask, *tok_partial, *wg_partial;
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
@@ -278,6 +278,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.dZ = carve_at(c, M * DM, dry);
         T.ddz = carve_at(c, M * RP, dry);
         T.du_at = carve_at(c, M * D, dry);
+        T.dad = c->prec != DYT_PREC_FP32 ? carve_at(c, M * D, dry) : nullptr;
         T.dO = carve_at(c, M * D, dry);
         T.dqkv = carve_at(c, M * 3 * D, dry);
         T.dA2 = carve_at(c, M * D, dry);
@@ -959,10 +960,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             }
         }
         JOIN(sb);
+        // adapter dgrad ddz Wdown.  fp32 mode / cls tail: accumulated into g in place (fp32 read-modify-write of [M,768]);
+        // bf16 mode: stored as a bf16 [M,768] operand that tok_bwd adds (half the bytes of the in-place update)
+        const bool dad_at = P != 0 && !tail && !first;
         if (!first) {
             GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
-            a.out_f32 = gin; a.accumulate = 1;  // g <- g + ddz Wdown  (= dL/du so far)
-            RUN_GEMM(EPI_STORE_F32, a);
+            if (dad_at) { a.out_at = T.dad; RUN_GEMM(EPI_STORE_AT, a); }
+            else { a.out_f32 = gin; a.accumulate = 1; RUN_GEMM(EPI_STORE_F32, a); }   // g <- g + ddz Wdown
         }
 
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
@@ -972,6 +976,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
             a.dmask = tail ? nullptr : T.dmask;
             a.g_cls = tail ? S.gcls : nullptr;
+            a.dad = dad_at ? T.dad : nullptr;
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;

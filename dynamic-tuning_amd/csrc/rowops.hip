@@ -710,6 +710,12 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] = 0.f;
         }
+        if (a.dad) {
+            Row12 e;
+            e.load_at(reinterpret_cast<const AT*>(a.dad) + (size_t)t * D, lane);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) du.v[i] += e.v[i];
+        }
         if (a.dA2 && a.write_du) {
             const int r = a.g_cls ? (n == 0 ? b : -1) : (a.dst_of ? a.dst_of[t] : t);
             if (r >= 0) {
