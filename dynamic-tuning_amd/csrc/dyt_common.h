@@ -3,6 +3,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// cache hints for single-use streams; -DDYT_NO_NT builds the library without them (A/B and determinism probes)
+#ifdef DYT_NO_NT
+#define DYT_NT_LOAD(p) (*(p))
+#define DYT_NT_STORE(v, p) (*(p) = (v))
+#else
+#define DYT_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define DYT_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
+// ln_bwd / tok_bwd wait for their whole block of independent loads with one `s_waitcnt vmcnt(0)` instead of the compiler's
+// per-use countdown.  Empirical: the step is bit-reproducible on one stream but not when the two backward
+// passes overlap; recording, from the registers, every value these two kernels had loaded showed identical inputs and a
+// low-bit different output row.  Draining the counter cut the frequency of such events at B=4 by ~4x at no measurable cost;
+// it does not remove them (other kernels show the same sensitivity), and the mechanism is not understood.
+#define DYT_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 namespace dyt {
 
 constexpr int D = 768;        // embed dim

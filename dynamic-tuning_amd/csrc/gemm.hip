@@ -54,11 +54,11 @@ __device__ __forceinline__ Raw4<bf16> load_raw4(const bf16* p) { return {*reinte
 // write burst out of the L2 lines the main loops of the other workgroups are hitting
 __device__ __forceinline__ void store4_nt(float* p, float a, float b, float c, float d) {
     f32x4 v = {a, b, c, d};
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    DYT_NT_STORE(v, reinterpret_cast<f32x4*>(p));
 }
 __device__ __forceinline__ void store4_nt(bf16* p, float a, float b, float c, float d) {
     bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
-    __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
+    DYT_NT_STORE(v, reinterpret_cast<bf16x4*>(p));
 }
 struct EpiBiasF32 {
     const float* bias; float* out; int ld;
@@ -187,7 +187,7 @@ struct EpiGeluBwd {
         const size_t src = (size_t)(MAPPED ? row_map[row] : row) * ld + col;
         if constexpr (sizeof(AT) == 2) {
             Pre p;
-            p.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(gp + src));
+            p.v = DYT_NT_LOAD(reinterpret_cast<const bf16x4*>(gp + src));
             return p;
         } else {
             return load_raw4(gp + src);

@@ -216,6 +216,8 @@ struct WgradArgs {
     float* out_ysum = nullptr; float alpha_y = 0.f;   // out_ysum[j] += alpha_y * sum_m Y[m][j], j < r
 };
 int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s);
+// two products with the same M and r (separate `partial` buffers) as one launch + one reduce launch
+int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // video model: attentive pooling head (pool.hip)
 // ------------------------------------------------------------------------------------------

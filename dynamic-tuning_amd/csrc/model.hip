@@ -103,7 +103,7 @@ struct LayerS {  // saved activations of one pass
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
-    float *g, *delta, *dmask, *tok_partial, *wg_partial;
+    float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
     float *xf = nullptr, *P = nullptr, *o = nullptr, *y = nullptr, *qn = nullptr, *qhat = nullptr, *qs = nullptr, *st_q = nullptr;
@@ -166,7 +166,9 @@ struct dyt_ctx {
     // second stream: the student and the teacher pass of a step are independent and run concurrently
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_b0 = nullptr;
-    bool overlap = true;
+    bool overlap = true;                 // any stream overlap
+    bool ov_pass = true, ov_branch = false;  // student / teacher passes on two streams; adapter branch on its own stream
+    bool ov_bwd_serial = false;          // the teacher's backward starts after the student's (bit-reproducible schedule)
     bool share_block0 = true;  // step: the teacher pass reuses the student's embedding + block-0 attention branch
     int count_flops_tokens = 0;  // > 0: Block.forward_count_flops -- MLP on the first n tokens of every image
     // profiling
@@ -288,6 +290,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.dmask = carve<float>(c, M, dry);
         T.tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
         T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
+        T.wg_partial2 = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
     c->cls_rows = carve<int>(c, B, dry);
@@ -537,7 +540,10 @@ struct ProfScope {
 extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
     switch (option) {
-        case DYT_OPT_STREAM_OVERLAP: c->overlap = value != 0; return DYT_OK;
+        case DYT_OPT_STREAM_OVERLAP:   // 0 off, 1 on (the two passes), 2 passes + adapter branches, 3 adapter branches only, 4 forward passes only
+            c->overlap = value != 0; c->ov_pass = value == 1 || value == 2 || value == 4; c->ov_branch = value == 2 || value == 3;
+            c->ov_bwd_serial = value == 4;
+            return DYT_OK;
         case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0 && c->frames <= 1; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
         case DYT_OPT_COUNT_FLOPS_TOKENS:
@@ -601,7 +607,7 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
 // adapter-branch side stream of a pass (created on first use); null when overlap is off / profiling
 static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
     *out = nullptr;
-    if (!c->overlap || c->prof) return 0;
+    if (!c->overlap || !c->ov_branch || c->prof) return 0;
     if (S.no_branch) return 0;
     if (!S.branch) {
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&S.branch, hipStreamNonBlocking));
@@ -933,18 +939,18 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s));
         }
-        {
-            WgradArgs a; a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = T.wg_partial;
+        {   // both weight gradients (+ the two bias gradients as ones columns / rows) in one launch
+            WgradArgs w[2];
+            WgradArgs& a = w[0];
+            a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = T.wg_partial;
             a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
             a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
-            RUN_ON(sb, 2, 2.0 * Mr * D * (double)RP, launch_wgrad(P, a, s));
-        }
-        {
-            WgradArgs a; a.X = tail ? S.ucls_at : L.u_at; a.Y = T.ddz; a.M = Mr; a.r = r; a.partial = T.wg_partial;
-            a.out_w = gbase + c->off_dw; a.sc = 1; a.sj = D; a.alpha = 1.0f;        // down_proj.weight [r, 768]
-            a.out_xsum = nullptr; a.alpha_x = 0.f;
-            a.out_ysum = gbase + c->off_db; a.alpha_y = 1.0f;                       // down_proj.bias
-            RUN_ON(sb, 2, 2.0 * Mr * D * (double)RP, launch_wgrad(P, a, s));
+            WgradArgs& b = w[1];
+            b.X = tail ? S.ucls_at : L.u_at; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = T.wg_partial2;
+            b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = 1.0f;        // down_proj.weight [r, 768]
+            b.out_xsum = nullptr; b.alpha_x = 0.f;
+            b.out_ysum = gbase + c->off_db; b.alpha_y = 1.0f;                       // down_proj.bias
+            RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s));
         }
         // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
@@ -1065,7 +1071,7 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     const int fl = (flags & (DYT_F_MASKED_DENSE | DYT_F_DEVICE_SEED)) | DYT_F_TRAINING | DYT_F_SAVE;
     // Two-stream schedule: student pass on the caller's stream, teacher pass on a side stream
     // (fork/join with events; graph-capturable).  Profiling mode runs serially for clean per-kernel times.
-    const bool par = c->overlap && !c->prof;
+    const bool par = c->overlap && c->ov_pass && !c->prof;
     if (par && !c->side) {
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1128,6 +1134,7 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     }
     rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s, par ? c->ev_half_s : nullptr, split);
     if (rc) return rc;
+    if (par && c->ov_bwd_serial) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
     rc = backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, gt, s2, par ? c->ev_half_t : c->ev_upper, split);
     if (rc) return rc;
     if (par) {

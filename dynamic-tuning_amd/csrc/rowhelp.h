@@ -20,7 +20,7 @@ struct Row12 {
     __device__ __forceinline__ void load_nt(const float* p, int lane) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i * 256 + lane * 4));
+            const f32x4 t = DYT_NT_LOAD(reinterpret_cast<const f32x4*>(p + i * 256 + lane * 4));
             v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
         }
     }

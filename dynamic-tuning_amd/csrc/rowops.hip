@@ -53,10 +53,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     g.load_at(dy + (size_t)row * D, lane);
     xr.load_nt(x + (size_t)row * D, lane);   // residual snapshot of the forward pass: last use
     wr.load(w, lane);
+    DYT_VMEM_DRAIN();
     ln_bwd_row(g, xr, wr, stats[row]);
     if (base) {
         Row12 br;
         br.load(base + (size_t)row * D, lane);
+        DYT_VMEM_DRAIN();
 #pragma unroll
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
     for (int i = 0; i < 3; ++i) {
         const int ch = tid + 256 * i;
         float acc = 0.f;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) acc = fmaf(dl[c], hw[(size_t)c * D + ch], acc);
         xh[i] = (x[(size_t)b * NT * D + ch] - st.x) * st.y;
         dy[i] = acc * nw[ch];
@@ -449,14 +452,39 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ dlogits, const float* __restrict__ cls_n,
                                                           float* __restrict__ dW, float* __restrict__ db, int batch, int C) {
+    // one class per workgroup; the batch loop is a latency chain (52 us at B=128 when every iteration waited for its own
+    // loads), so the class's dlogits column goes to LDS first and the row loads of 8 images are issued together; the fmaf
+    // chain per output keeps the image order
+    __shared__ float dl[1024];
     const int c = blockIdx.x, tid = threadIdx.x;
     float acc[3] = {0.f, 0.f, 0.f};
     float sb = 0.f;
-    for (int b = 0; b < batch; ++b) {
-        const float d = dlogits[(size_t)b * C + c];
-        sb += d;
+    for (int b0 = 0; b0 < batch; b0 += 1024) {
+        const int nb = min(1024, batch - b0);
+        __syncthreads();
+        for (int b = tid; b < nb; b += 256) dl[b] = dlogits[(size_t)(b0 + b) * C + c];
+        __syncthreads();
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {
+            float v[8][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] = fmaf(d, cls_n[(size_t)b * D + tid + 256 * i], acc[i]);
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[u][i] = cls_n[(size_t)(b0 + b + u) * D + tid + 256 * i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = dl[b + u];
+                sb += d;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] = fmaf(d, v[u][i], acc[i]);
+            }
+        }
+        for (; b < nb; ++b) {
+            const float d = dl[b];
+            sb += d;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = fmaf(d, cls_n[(size_t)(b0 + b) * D + tid + 256 * i], acc[i]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) dW[(size_t)c * D + tid + 256 * i] += acc[i];
@@ -710,17 +738,20 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] = 0.f;
         }
+        Row12 e;
+        if (a.dad) e.load_at(reinterpret_cast<const AT*>(a.dad) + (size_t)t * D, lane);
+        int r = -1;
+        if (a.dA2 && a.write_du) r = a.g_cls ? (n == 0 ? b : -1) : (a.dst_of ? a.dst_of[t] : t);
+        DYT_VMEM_DRAIN();
         if (a.dad) {
-            Row12 e;
-            e.load_at(reinterpret_cast<const AT*>(a.dad) + (size_t)t * D, lane);
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] += e.v[i];
         }
         if (a.dA2 && a.write_du) {
-            const int r = a.g_cls ? (n == 0 ? b : -1) : (a.dst_of ? a.dst_of[t] : t);
             if (r >= 0) {
                 Row12 dy;
                 dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
+                DYT_VMEM_DRAIN();
                 ln_bwd_row(dy, ur, ln2w, a.stats2[t]);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i];
@@ -807,8 +838,12 @@ constexpr int WG_CHUNK = 512;   // minimum tokens per workgroup (the partial buf
 // of X ride along as a ones COLUMN of the B operand (-> partial[..][c][64]); the column sums of Y as a
 // ones ROW of the A operand, computed by wave 0 of the first channel block (-> partial[..][768][j]).
 constexpr int WG_ROWS = D + 8;  // partial rows per chunk: 768 channels + 1 row of Y column sums (+pad)
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Y, int M,
-                                                         float* __restrict__ partial, int chunk) {
+struct WgSrc { const void* X; const void* Y; float* partial; };
+struct WgPair { WgSrc p[2]; };   // blockIdx.z selects the product: both adapter weight gradients of a block are ONE launch
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgPair src, int M, int chunk) {
+    const bf16* __restrict__ X = static_cast<const bf16*>(src.p[blockIdx.z].X);
+    const bf16* __restrict__ Y = static_cast<const bf16*>(src.p[blockIdx.z].Y);
+    float* __restrict__ partial = src.p[blockIdx.z].partial;
     constexpr int TS = 64;        // tokens per step
     constexpr int LDT = TS + 8;   // bf16 per LDS row (144 B: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) bf16 Xt[128 * LDT];
@@ -907,8 +942,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const bf16* __restrict_
 }
 
 // fp32 exact variant: 64 channels x 64 columns per workgroup, 4x4 outputs per thread
-__global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M,
-                                                        float* __restrict__ partial, int chunk) {
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgPair src, int M, int chunk) {
+    const float* __restrict__ X = static_cast<const float*>(src.p[blockIdx.z].X);
+    const float* __restrict__ Y = static_cast<const float*>(src.p[blockIdx.z].Y);
+    float* __restrict__ partial = src.p[blockIdx.z].partial;
     __shared__ float Xs[16][64 + 4];
     __shared__ float Ys[16][64 + 4];
     const int tid = threadIdx.x;
@@ -959,38 +996,51 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int r, float* __restrict__ out_w,
-                                    int sc, int sj, float alpha, float* __restrict__ out_xsum, float alpha_x,
-                                    float* __restrict__ out_ysum, float alpha_y) {
+struct WgOut {
+    const float* partial; float* out_w; int sc, sj; float alpha; float* out_xsum; float alpha_x; float* out_ysum; float alpha_y;
+};
+struct WgOutPair { WgOut p[2]; };
+__global__ void wgrad_reduce_kernel(WgOutPair outs, int nchunks, int r) {
+    const WgOut& o = outs.p[blockIdx.y];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= (D + 1) * (r + 1)) return;
     const int c = idx / (r + 1), j = idx - c * (r + 1);
     const int col = j < r ? j : 64;
     if (c == D && j == r) return;
     float acc = 0.f;
-    for (int p = 0; p < nchunks; ++p) acc += partial[((size_t)p * WG_ROWS + c) * WG_J + col];
-    if (c == D) { if (out_ysum) out_ysum[j] += alpha_y * acc; }
-    else if (j < r) out_w[(size_t)c * sc + (size_t)j * sj] += alpha * acc;
-    else if (out_xsum) out_xsum[c] += alpha_x * acc;
+    for (int p = 0; p < nchunks; ++p) acc += o.partial[((size_t)p * WG_ROWS + c) * WG_J + col];
+    if (c == D) { if (o.out_ysum) o.out_ysum[j] += o.alpha_y * acc; }
+    else if (j < r) o.out_w[(size_t)c * o.sc + (size_t)j * o.sj] += o.alpha * acc;
+    else if (o.out_xsum) o.out_xsum[c] += o.alpha_x * acc;
 }
 
-int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
-    // tokens per workgroup: at least WG_CHUNK, and large enough that the (channel blocks x chunks) grid is ONE round
-    // of the 256 CUs (B=128: 6 x 50 = 300 workgroups would leave a 44-workgroup second round; 6 x 40 does not)
+// one or two products (same M and r; separate partial buffers) in one launch + one reduce launch
+int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
+    // tokens per workgroup: at least WG_CHUNK, and large enough that the (channel blocks x chunks) grid of ONE product is
+    // one round of the 256 CUs (B=128: 6 x 50 = 300 workgroups would leave a 44-workgroup second round; 6 x 40 does not);
+    // a pair is two workgroups per CU, which hides the staging latency of the single-product launch
+    const int M = a[0].M, r = a[0].r;
+    if (n < 1 || n > 2 || (n == 2 && (a[1].M != M || a[1].r != r || a[1].partial == a[0].partial))) {
+        set_error("launch_wgrad: bad pair");
+        return -1;
+    }
     const int cblocks = precision == 0 ? D / 64 : D / 128;
-    const int want = (a.M + 256 / cblocks - 1) / (256 / cblocks);
+    const int want = (M + 256 / cblocks - 1) / (256 / cblocks);
     const int chunk = max(WG_CHUNK, (want + 63) / 64 * 64);
-    const int nchunks = (a.M + chunk - 1) / chunk;
-    if (precision == 0)
-        hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 64, nchunks), dim3(256), 0, s, (const float*)a.X, (const float*)a.Y,
-                           a.M, a.partial, chunk);
-    else
-        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks), dim3(256), 0, s, (const bf16*)a.X, (const bf16*)a.Y,
-                           a.M, a.partial, chunk);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (a.r + 1) + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.r,
-                       a.out_w, a.sc, a.sj, a.alpha, a.out_xsum, a.alpha_x, a.out_ysum, a.alpha_y);
+    const int nchunks = (M + chunk - 1) / chunk;
+    WgPair src;
+    WgOutPair outs;
+    for (int i = 0; i < 2; ++i) {
+        const WgradArgs& w = a[i < n ? i : 0];
+        src.p[i] = WgSrc{w.X, w.Y, w.partial};
+        outs.p[i] = WgOut{w.partial, w.out_w, w.sc, w.sj, w.alpha, w.out_xsum, w.alpha_x, w.out_ysum, w.alpha_y};
+    }
+    if (precision == 0) hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 64, nchunks, n), dim3(256), 0, s, src, M, chunk);
+    else hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (r + 1) + 255) / 256, n), dim3(256), 0, s, outs, nchunks, r);
     LAUNCH_CHECK();
     return 0;
 }
+int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) { return launch_wgrad(precision, &a, 1, s); }
 
 }  // namespace dyt

@@ -115,8 +115,13 @@ int dyt_ctx_destroy(dyt_ctx* ctx);
 int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
 
 /* Scheduling options (results are identical either way; both default to on):
- *   DYT_OPT_STREAM_OVERLAP  run the student / teacher passes and the adapter branch of every block on
- *                           internal side streams (fork/join with events on the caller's stream)
+ *   DYT_OPT_STREAM_OVERLAP  0: everything on the caller's stream.  1 (default): dyt_step_fwd_bwd runs the student and the
+ *                           teacher pass on two streams (fork/join with events on the caller's stream).  2: additionally
+ *                           the adapter branch of every block on its own stream, 3: only that -- both measured SLOWER
+ *                           than 1 whenever the branch streams really get their own hardware queues (26.1 vs 31.5 /
+ *                           30.0 ms per step at B=128 with GPU_MAX_HW_QUEUES=8; the serial step is 29.5 ms), kept for
+ *                           measurement only.  4: the two FORWARD passes overlap, the teacher's backward starts after the
+ *                           student's -- like 0 a bit-reproducible schedule, 29.0 instead of 26.1 ms
  *   DYT_OPT_CLS_TAIL        last block: evaluate MLP + adapter (forward and backward) for the cls rows
  *                           only -- only x[:,0] reaches forward_head (vision_transformer_IN21K.py:375-380)
  *   DYT_OPT_SHARE_BLOCK0    dyt_step_fwd_bwd: the teacher pass reuses the student pass's patch embedding and

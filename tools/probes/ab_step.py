@@ -20,6 +20,8 @@ eng = m.engine(B, x.device)
 mm, vv = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
 if os.environ.get("DYT_NO_OVERLAP"):
     eng.set_option(_lib.OPT_STREAM_OVERLAP, 0)
+if os.environ.get("DYT_OVERLAP"):
+    eng.set_option(_lib.OPT_STREAM_OVERLAP, int(os.environ["DYT_OVERLAP"]))
 def step(i):
     eng.step_fwd_bwd(x, y, 0.7, 2.0, 0.0, 0.0, seed=900 + i, masked_dense=(mode == "masked"))
     _lib.check(eng.L.dyt_adamw(_lib.ptr(eng.flat), _lib.ptr(eng.grad), _lib.ptr(mm), _lib.ptr(vv), eng.n_train, i + 1, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, _lib.stream_ptr()))

@@ -16,15 +16,29 @@ def run(overlap):
     x, y = x.cuda(), y.cuda()
     eng = m.engine(B, x.device)
     eng.set_option(_lib.OPT_STREAM_OVERLAP, overlap)
+    if os.environ.get('PSHARE'): eng.set_option(_lib.OPT_SHARE_BLOCK0, int(os.environ['PSHARE']))
+    if os.environ.get('PTAIL'): eng.set_option(_lib.OPT_CLS_TAIL, int(os.environ['PTAIL']))
     out = []
     for i in range(2):
         eng.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, seed=900 + i)
         torch.cuda.synchronize()
         out.append(eng.grad.clone())
     return out
-for overlap in (0, 1):
+for overlap in [int(v) for v in os.environ.get('POVERLAP', '1').split(',')]:
     runs = [run(overlap) for _ in range(4)]
     for i in (1, 2, 3):
         d = [(runs[0][k] - runs[i][k]).abs() for k in range(2)]
         print("overlap", overlap, "run0 vs run%d:" % i, [bool(torch.equal(runs[0][k], runs[i][k])) for k in range(2)],
               [float(x.max()) for x in d], [int((x > 0).sum()) for x in d], [int(x.argmax()) for x in d])
+if os.environ.get("PDETAIL"):
+    m, _ = T._bench_model(prec, "compact", B, 0.85)
+    eng = m.engine(B, torch.device("cuda", 0))
+    names = [n for n, p in m.named_parameters() if synth.is_trainable(n)]
+    for i in (1, 2, 3):
+        bad = []
+        for n in names:
+            off, num = eng.trainable_slice(n)
+            d = (runs[0][0][off:off + num] - runs[i][0][off:off + num]).abs()
+            if float(d.max()) > 0:
+                bad.append("%s:%d/%d" % (n.replace("blocks.", "b").replace("adaptmlp.", "").replace("mlp_token_select.mlp_head", "gate"), int((d > 0).sum()), num))
+        print("run0 vs run%d step0 differing tensors:" % i, bad[-14:])
