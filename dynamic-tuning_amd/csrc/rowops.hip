@@ -941,58 +941,104 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgPair src, int M, int 
     }
 }
 
-// fp32 exact variant: 64 channels x 64 columns per workgroup, 4x4 outputs per thread
+// fp32 exact variant on the matrix cores: v_mfma_f32_32x32x2_f32 with the TOKEN dimension as k.  One fp32 per lane and
+// operand: lane l supplies (row l % 32, k = l / 32), so an A operand is X[token m + l/32][channel] and a B operand
+// Y[token m + l/32][column] -- both straight from global memory, no transposition and no LDS staging.  A lane loads a
+// float4 of X (4 consecutive channels) and a float2 of Y per token pair and feeds register t / u to MFMA (t, u): that
+// MFMA owns channels c0 + 4*row + t and columns 2*col + u (only the ownership is permuted).  A wave covers 128 channels x
+// 64 columns (8 MFMAs, 128 accumulator registers) and every 4th token pair of the chunk; the 4 waves of a workgroup are
+// summed through LDS in wave order (deterministic).  Column sums of X / Y ride along on the vector ALU.
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgPair src, int M, int chunk) {
     const float* __restrict__ X = static_cast<const float*>(src.p[blockIdx.z].X);
     const float* __restrict__ Y = static_cast<const float*>(src.p[blockIdx.z].Y);
     float* __restrict__ partial = src.p[blockIdx.z].partial;
-    __shared__ float Xs[16][64 + 4];
-    __shared__ float Ys[16][64 + 4];
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * 64;
-    const int m0 = blockIdx.y * chunk;
-    const int ty = tid >> 4, tx = tid & 15;
-    const int lr = tid >> 4, lc = (tid & 15) * 4;
-    float acc[4][4] = {};
-    float xs[4] = {0.f, 0.f, 0.f, 0.f};
-    float ys[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int tb = m0; tb < min(m0 + chunk, M); tb += 16) {
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yv = xv;
-        if (tb + lr < M) {
-            xv = *reinterpret_cast<const float4*>(X + (size_t)(tb + lr) * D + c0 + lc);
-            yv = *reinterpret_cast<const float4*>(Y + (size_t)(tb + lr) * RP + lc);
+    __shared__ float red[134 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * chunk, mend = min(m0 + chunk, M);
+    const int lr = lane & 31, lk = lane >> 5;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+    float xs[4] = {0.f, 0.f, 0.f, 0.f}, ys[2] = {0.f, 0.f};
+    const float* xp = X + (size_t)c0 + 4 * lr;
+    const float* yp = Y + 2 * lr;
+    constexpr int PF = 4;   // token pairs in flight per wave
+    f32x4 xa[PF];
+    f32x2 yb[PF];
+    auto load_pair = [&](int slot, int m) {   // m = first token of the pair; this lane reads token m + lk
+        const int t = m + lk;
+        xa[slot] = f32x4{0.f, 0.f, 0.f, 0.f};
+        yb[slot] = f32x2{0.f, 0.f};
+        if (t < mend) {
+            xa[slot] = *reinterpret_cast<const f32x4*>(xp + (size_t)t * D);
+            yb[slot] = *reinterpret_cast<const f32x2*>(yp + (size_t)t * RP);
         }
-        __syncthreads();
-        *reinterpret_cast<float4*>(&Xs[lr][lc]) = xv;
-        *reinterpret_cast<float4*>(&Ys[lr][lc]) = yv;
-        __syncthreads();
+    };
+    int m = m0 + 2 * wave;   // this wave's token pairs: m, m + 8, m + 16, ...
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&Xs[k][ty * 4]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Ys[k][tx * 4]);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    for (int q = 0; q < PF; ++q) load_pair(q, m + 8 * q);
+    for (; m < mend; m += 8 * PF) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        for (int q = 0; q < PF; ++q) {
+            const f32x4 a = xa[q];
+            const f32x2 b = yb[q];
+            load_pair(q, m + 8 * (PF + q));   // refill the slot (zeros beyond the chunk)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-                xs[i] += av[i];
+            for (int t = 0; t < 4; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[0], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[1], acc[t][1], 0, 0, 0);
+                xs[t] += a[t];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ys[j] += bv[j];
+            ys[0] += b[0]; ys[1] += b[1];
         }
     }
+    // ---- sum the 4 waves in wave order through LDS: element k of lane l lives at red[k * 64 + l] ----
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float* q = &red[((t * 2 + u) * 16 + i) * 64 + lane];
+                        if (w == 0) *q = acc[t][u][i]; else if (w < 3) *q += acc[t][u][i]; else acc[t][u][i] += *q;
+                    }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { float* q = &red[(128 + t) * 64 + lane]; if (w == 0) *q = xs[t]; else if (w < 3) *q += xs[t]; else xs[t] += *q; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { float* q = &red[(132 + u) * 64 + lane]; if (w == 0) *q = ys[u]; else if (w < 3) *q += ys[u]; else ys[u] += *q; }
+        }
+        __syncthreads();
+    }
+    if (wave != 3) return;
+    // D register i of MFMA (t, u): row = (i / 4) * 8 + lk * 4 + (i % 4), col = lr -> channel c0 + 4 * row + t, column 2 * lr + u
     float* pp = partial + (size_t)blockIdx.y * WG_ROWS * WG_J;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty * 4 + i;
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pp[(size_t)c * WG_J + tx * 4 + j] = acc[i][j];
-        if (tx == 0) pp[(size_t)c * WG_J + 64] = xs[i];
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i >> 2) * 8 + lk * 4 + (i & 3);
+            const int c = c0 + 4 * row + t;
+            *reinterpret_cast<f32x2*>(&pp[(size_t)c * WG_J + 2 * lr]) = f32x2{acc[t][0][i], acc[t][1][i]};
+        }
+    // column sums: the two token parities (lanes l and l ^ 32) are still separate
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float v = xs[t] + __shfl_xor(xs[t], 32, 64);
+        if (lk == 0) pp[(size_t)(c0 + 4 * lr + t) * WG_J + 64] = v;
     }
-    if (blockIdx.x == 0 && ty == 0) {  // column sums of Y
+    if (blockIdx.x == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pp[(size_t)D * WG_J + tx * 4 + j] = ys[j];
+        for (int u = 0; u < 2; ++u) {
+            const float v = ys[u] + __shfl_xor(ys[u], 32, 64);
+            if (lk == 0) pp[(size_t)D * WG_J + 2 * lr + u] = v;
+        }
     }
 }
 
@@ -1024,7 +1070,7 @@ int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
         set_error("launch_wgrad: bad pair");
         return -1;
     }
-    const int cblocks = precision == 0 ? D / 64 : D / 128;
+    const int cblocks = D / 128;
     const int want = (M + 256 / cblocks - 1) / (256 / cblocks);
     const int chunk = max(WG_CHUNK, (want + 63) / 64 * 64);
     const int nchunks = (M + chunk - 1) / chunk;
@@ -1035,7 +1081,7 @@ int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
         src.p[i] = WgSrc{w.X, w.Y, w.partial};
         outs.p[i] = WgOut{w.partial, w.out_w, w.sc, w.sj, w.alpha, w.out_xsum, w.alpha_x, w.out_ysum, w.alpha_y};
     }
-    if (precision == 0) hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 64, nchunks, n), dim3(256), 0, s, src, M, chunk);
+    if (precision == 0) hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
     else hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (r + 1) + 255) / 256, n), dim3(256), 0, s, outs, nchunks, r);
     LAUNCH_CHECK();
