@@ -106,6 +106,8 @@ SYMBOLS = {
     "dyt_gate_compact": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dyt_gemm_bf16_raw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_gemm_f32_raw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dyt_wgrad_scratch_floats": (ctypes.c_int64, [_i]),
+    "dyt_wgrad_raw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dyt_debug_counters": (_i, [ctypes.POINTER(ctypes.c_uint64), _i]),
     "dyt_profile_enable": (_i, [_vp, _i]),
     "dyt_profile_read": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),

@@ -1205,6 +1205,17 @@ extern "C" int dyt_gemm_bf16_raw(const void* a, const void* w, void* cmat, int M
     return launch_gemm_raw(a, w, cmat, M, N, K, variant, static_cast<hipStream_t>(stream));
 }
 
+// adapter weight-gradient kernel alone (unit tests / probes): out_w[c*r + j] += sum_m X[m][c] Y[m][j], out_xsum[c] += sum_m X[m][c],
+// out_ysum[j] += sum_m Y[m][j]; X [M,768], Y [M,64] in the precision's operand type; partial = scratch of dyt_wgrad_scratch_floats(M)
+extern "C" int64_t dyt_wgrad_scratch_floats(int M) { return (int64_t)((M + 511) / 512) * (D + 8) * 80; }
+extern "C" int dyt_wgrad_raw(const void* X, const void* Y, int M, int r, int precision, float* partial, float* out_w, float* out_xsum,
+                             float* out_ysum, void* stream) {
+    if (!X || !Y || !partial || !out_w || M < 1 || r < 1 || r > RP) { set_error("bad argument"); return DYT_ERR_ARG; }
+    WgradArgs a; a.X = X; a.Y = Y; a.M = M; a.r = r; a.partial = partial;
+    a.out_w = out_w; a.sc = r; a.sj = 1; a.alpha = 1.0f; a.out_xsum = out_xsum; a.alpha_x = 1.0f; a.out_ysum = out_ysum; a.alpha_y = 1.0f;
+    return launch_wgrad(precision, a, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int dyt_gemm_f32_raw(const float* a, const float* w, float* cmat, int M, int N, int K, int variant, void* stream) {
     if (!a || !w || !cmat) { set_error("null argument"); return DYT_ERR_ARG; }
     return launch_gemm_f32_raw(a, w, cmat, M, N, K, variant, static_cast<hipStream_t>(stream));

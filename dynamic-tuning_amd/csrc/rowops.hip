@@ -832,15 +832,15 @@ int launch_reduce_partials(const float* partial, int nparts, int stride, float* 
 constexpr int WG_J = 80;        // 64 adapter columns + the ones column (+ pad)
 constexpr int WG_CHUNK = 512;   // minimum tokens per workgroup (the partial buffers are sized for M / 512 chunks)
 
-// bf16: MFMA 16x16x32 with the token dimension as K; tiles are transposed while staged to LDS.
+// bf16: MFMA 32x32x16 with the token dimension as K; tiles are transposed while staged to LDS.
 // 64 tokens per step; the next step's rows are prefetched into registers while the current step's
 // fragments are read and multiplied (the loads were fully exposed before: 1.3 TB/s).  The column sums
-// of X ride along as a ones COLUMN of the B operand (-> partial[..][c][64]); the column sums of Y as a
-// ones ROW of the A operand, computed by wave 0 of the first channel block (-> partial[..][768][j]).
+// of X (-> partial[..][c][64]) and of Y (wave 0 of the first channel block, -> partial[..][768][j]) are
+// taken from the same fragments on the vector ALU.
 constexpr int WG_ROWS = D + 8;  // partial rows per chunk: 768 channels + 1 row of Y column sums (+pad)
 struct WgSrc { const void* X; const void* Y; float* partial; };
 struct WgPair { WgSrc p[2]; };   // blockIdx.z selects the product: both adapter weight gradients of a block are ONE launch
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgPair src, int M, int chunk) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, int chunk) {
     const bf16* __restrict__ X = static_cast<const bf16*>(src.p[blockIdx.z].X);
     const bf16* __restrict__ Y = static_cast<const bf16*>(src.p[blockIdx.z].Y);
     float* __restrict__ partial = src.p[blockIdx.z].partial;
@@ -853,16 +853,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgPair src, int M, int 
     const int c0 = blockIdx.x * 128;
     const int m0 = blockIdx.y * chunk;
     const int mend = min(m0 + chunk, M);
-    f32x4 acc[2][5], accy[4];
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) accy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (lane & 15) == 0 ? (bf16)1.0f : (bf16)0.0f;
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    float xs = 0.f, ys[2] = {0.f, 0.f};   // column sums of X (own channel) / Y (own columns) over this lane's tokens
     const bool do_ysum = blockIdx.x == 0 && wave == 0;
 
     // loader roles: X tile = 32 token pairs x 16 channel chunks = 512 tasks (2 / thread); Y = 32 x 8 (1 / thread)
@@ -903,41 +899,45 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgPair src, int M, int 
         }
         __syncthreads();
         if (tb + TS < mend) load_step(tb + TS);  // in flight during the reads + MFMAs below
-        const int kg = lane >> 4, fr = lane & 15;
+        const int lr = lane & 31, lk = lane >> 5;
+        auto sum8 = [](const bf16x8& v) {   // sum of 8 bf16 in fp32 (bf16 -> fp32 is a 16-bit shift)
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            const u32x4 u = __builtin_bit_cast(u32x4, v);
+            float t = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {  // two 32-token k blocks
-            bf16x8 xf[2], yf[4];
+            for (int i = 0; i < 4; ++i) t += __builtin_bit_cast(float, u[i] << 16) + __builtin_bit_cast(float, u[i] & 0xffff0000u);
+            return t;
+        };
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                xf[i] = *reinterpret_cast<const bf16x8*>(&Xt[(wave * 32 + i * 16 + fr) * LDT + kk * 32 + kg * 8]);
+        for (int kk = 0; kk < 4; ++kk) {  // four 16-token k blocks; lane = (row lr, tokens kk*16 + lk*8 .. +7)
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&Xt[(wave * 32 + lr) * LDT + kk * 16 + lk * 8]);
+            bf16x8 yf[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 16 + fr) * LDT + kk * 32 + kg * 8]);
+            for (int j = 0; j < 2; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 32 + lr) * LDT + kk * 16 + lk * 8]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
-                acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], ones, acc[i][4], 0, 0, 0);
-            }
-            if (do_ysum) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) accy[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[j], accy[j], 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf[j], acc[j], 0, 0, 0);
+            xs += sum8(xf);
+            if (do_ysum) { ys[0] += sum8(yf[0]); ys[1] += sum8(yf[1]); }
         }
     }
-    // D[c][j]: col j = lane & 15, row c = (lane >> 4) * 4 + reg
+    // D register i of block j: row = (i / 4) * 8 + (lane >> 5) * 4 + (i % 4) -> channel, col = lane & 31 -> column j * 32 + col
     float* pp = partial + (size_t)blockIdx.y * WG_ROWS * WG_J;
+    const int lr = lane & 31, lk = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + wave * 32 + (i >> 2) * 8 + lk * 4 + (i & 3);
+            pp[(size_t)c * WG_J + j * 32 + lr] = acc[j][i];
+        }
+    xs += __shfl_xor(xs, 32, 64);   // the two token groups of a channel
+    if (lk == 0) pp[(size_t)(c0 + wave * 32 + lr) * WG_J + 64] = xs;
+    if (do_ysum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = c0 + wave * 32 + i * 16 + (lane >> 4) * 4 + e;
-                pp[(size_t)c * WG_J + j * 16 + (lane & 15)] = acc[i][j][e];
-            }
-    if (do_ysum && lane < 16) {  // ones row 0 of the A operand: D row 0 = lanes 0..15, register 0
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pp[(size_t)D * WG_J + j * 16 + lane] = accy[j][0];
+        for (int j = 0; j < 2; ++j) {
+            const float v = ys[j] + __shfl_xor(ys[j], 32, 64);
+            if (lk == 0) pp[(size_t)D * WG_J + j * 32 + lr] = v;
+        }
     }
 }
 

@@ -260,6 +260,11 @@ int dyt_gemm_bf16_raw(const void* a, const void* w, void* c, int M, int N, int K
  * N % 64 == 0, K % 64 == 0; no synchronisation.  variant 0: plain store; 1: the adapter up-projection epilogue (residual read
  * from c + M*N, c = resid + 0.1 * acc); 2: accumulate (c += acc) */
 int dyt_gemm_f32_raw(const float* a, const float* w, float* c, int M, int N, int K, int variant, void* stream);
+/* the adapter weight-gradient kernel alone: out_w[c*r + j] += sum_m X[m][c] Y[m][j] (X [M,768], Y [M,64], fp32 or bf16 by
+ * `precision`), out_xsum[c] += sum_m X[m][c], out_ysum[j] += sum_m Y[m][j]; `partial` = dyt_wgrad_scratch_floats(M) floats */
+int64_t dyt_wgrad_scratch_floats(int M);
+int dyt_wgrad_raw(const void* X, const void* Y, int M, int r, int precision, float* partial, float* out_w, float* out_xsum,
+                  float* out_ysum, void* stream);
 /* phase timers of the instrumented GEMM variants: cycles {prologue, main loop, epilogue} summed over
  * workgroups and the workgroup count; synchronises; optionally resets */
 int dyt_debug_counters(uint64_t* out4, int reset);

@@ -247,11 +247,12 @@ def test_scheduling_options_do_not_change_results(precision):
         assert float((r[3] - base[3]).norm() / base[3].norm()) < tol * 10   # flat gradient
 
 
-@pytest.mark.parametrize("overlap", [0, 4])
+@pytest.mark.parametrize("overlap", [0, 4, 1])
 def test_reproducible_schedules_are_bitwise(overlap):
     """DYT_OPT_STREAM_OVERLAP 0 (one stream) and 4 (forward passes overlapped, backward passes one after the other) give the
-    same bits on every run: B=16 (256x256 / pre-shuffled-weight GEMMs included), fast mode, two steps each, contexts rebuilt.
-    (The default schedule overlaps the two backward passes and is reproducible to ~1e-5 relative only: DESIGN.md 7b.)"""
+    same bits on every run at every size; so does the default schedule (1: both passes overlap end to end) at this size since
+    the adapter weight-gradient kernel was rewritten (at B=128 it still differs by ~1e-6).  B=16 (pre-shuffled-
+    weight GEMMs included), fast mode, two steps each, contexts rebuilt."""
     import _lib
     B = 16
     x, y = synth.make_batch(B, 100, seed=21)
@@ -273,6 +274,34 @@ def test_reproducible_schedules_are_bitwise(overlap):
             assert torch.equal(r[i][0], runs[0][i][0])
             assert torch.equal(r[i][1], runs[0][i][1])
             assert float(r[i][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("M", [4, 788, 25216])
+def test_adapter_weight_gradient_kernel(precision, M):
+    """models/dynamic_adapter.py:117-134 backward, the products with the token dimension as contraction: dW[c][j] = sum_m
+    X[m][c] Y[m][j] plus both column sums (the bias gradients), against fp64 torch; M = cls tail of B=4, B=4, B=128."""
+    import _lib
+    from _lib import check, lib, ptr
+    L = lib()
+    P = 0 if precision == "fp32" else 1
+    gen = torch.Generator(device="cuda").manual_seed(M)
+    X = torch.randn(M, 768, device="cuda", generator=gen) * 1e-2
+    Y = torch.randn(M, 64, device="cuda", generator=gen)
+    Y[:, 40:] = 0.0                                         # rank 40 of the 64-wide tile
+    if P:
+        X, Y = X.bfloat16(), Y.bfloat16()
+    part = torch.zeros(int(L.dyt_wgrad_scratch_floats(M)), device="cuda")
+    w = torch.full((768 * 40,), 0.5, device="cuda")         # the kernel accumulates into its outputs
+    xs = torch.zeros(768, device="cuda")
+    ys = torch.zeros(40, device="cuda")
+    check(L.dyt_wgrad_raw(ptr(X), ptr(Y), M, 40, P, ptr(part), ptr(w), ptr(xs), ptr(ys), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = X.double().t() @ Y.double()[:, :40]
+    tol = 2e-6
+    assert float((w.view(768, 40).double() - 0.5 - ref).abs().max() / ref.abs().max()) < tol
+    assert float((xs.double() - X.double().sum(0)).abs().max() / X.double().sum(0).abs().max()) < tol
+    assert float((ys.double() - Y.double()[:, :40].sum(0)).abs().max() / Y.double()[:, :40].sum(0).abs().max()) < tol
 
 
 def test_c_abi_error_paths():

@@ -16,13 +16,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 // one wave per 768-channel row
-__global__ __launch_bounds__(256) void row_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
-                                                  const float* __restrict__ base, float* __restrict__ out, int rows) {
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+__global__ __launch_bounds__(256) void row_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ base, float* __restrict__ out, __bf16* __restrict__ out16, int rows) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float g[12], xv[12], wv[12], b[12];
     for (int i = 0; i < 3; ++i) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(dy + (size_t)row * 768 + i * 256 + lane * 4);
+        const bf16x4 a16 = *reinterpret_cast<const bf16x4*>(dy + (size_t)row * 768 + i * 256 + lane * 4);
+        const f32x4 a = {(float)a16[0], (float)a16[1], (float)a16[2], (float)a16[3]};
         const f32x4 c = *reinterpret_cast<const f32x4*>(x + (size_t)row * 768 + i * 256 + lane * 4);
         const f32x4 d = *reinterpret_cast<const f32x4*>(w + i * 256 + lane * 4);
         const f32x4 e = *reinterpret_cast<const f32x4*>(base + (size_t)row * 768 + i * 256 + lane * 4);
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void row_kernel(const float* __restrict__ dy, 
         f32x4 o;
         for (int k = 0; k < 4; ++k) o[k] = b[4 * i + k] + rstd * (g[4 * i + k] - s1 - xh[4 * i + k] * s2);
         *reinterpret_cast<f32x4*>(out + (size_t)row * 768 + i * 256 + lane * 4) = o;
+        *reinterpret_cast<bf16x4*>(out16 + (size_t)row * 768 + i * 256 + lane * 4) = bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
     }
 }
 // small MFMA kernel: few workgroups, 4 waves each, bursts of v_mfma_f32_16x16x32_bf16 between barriers
@@ -71,13 +74,13 @@ __global__ __launch_bounds__(256) void mfma_kernel(float* __restrict__ out, int 
 }
 int main() {
     const int rows = 788, n = rows * 768;
-    float *dy, *x, *w, *base, *out, *ref, *mo;
-    hipMalloc(&dy, n * 4); hipMalloc(&x, n * 4); hipMalloc(&w, 768 * 4); hipMalloc(&base, n * 4); hipMalloc(&out, 2 * n * 4); hipMalloc(&ref, n * 4);
+    float *dy32, *x, *w, *base, *out, *ref, *mo; __bf16 *dy, *out16;
+    hipMalloc(&dy32, n * 4); hipMalloc(&dy, n * 2); hipMalloc(&out16, n * 2); hipMalloc(&x, n * 4); hipMalloc(&w, 768 * 4); hipMalloc(&base, n * 4); hipMalloc(&out, 2 * n * 4); hipMalloc(&ref, n * 4);
     hipMalloc(&mo, 1024 * 256 * 4);
     float* h = (float*)malloc(n * 4);
     srand(1);
     for (int i = 0; i < n; ++i) h[i] = ((float)rand() / RAND_MAX - 0.5f) * 1e-3f;
-    hipMemcpy(dy, h, n * 4, hipMemcpyHostToDevice);
+    { unsigned short* hb = (unsigned short*)malloc(n * 2); for (int i = 0; i < n; ++i) { unsigned u; memcpy(&u, &h[i], 4); hb[i] = (unsigned short)(u >> 16); } hipMemcpy(dy, hb, n * 2, hipMemcpyHostToDevice); }
     for (int i = 0; i < n; ++i) h[i] = ((float)rand() / RAND_MAX - 0.5f) * 4.f;
     hipMemcpy(x, h, n * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < n; ++i) h[i] = ((float)rand() / RAND_MAX - 0.5f) * 1e-3f;
@@ -86,7 +89,7 @@ int main() {
     hipMemcpy(w, h, 768 * 4, hipMemcpyHostToDevice);
     hipStream_t s1, s2;
     hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-    row_kernel<<<(rows + 3) / 4, 256, 0, s1>>>(dy, x, w, base, ref, rows);
+    row_kernel<<<(rows + 3) / 4, 256, 0, s1>>>(dy, x, w, base, ref, out16, rows);
     hipDeviceSynchronize();
     float* href = (float*)malloc(n * 4); float* hout = (float*)malloc(n * 4);
     hipMemcpy(href, ref, n * 4, hipMemcpyDeviceToHost);
@@ -96,7 +99,7 @@ int main() {
             // a long-running neighbour on every CU (1024 workgroups x 4 waves, ~ms), then 20 row-kernel launches under it
             if (mode) mfma_kernel<<<1024, 256, 0, s2>>>(mo, 4000, mode == 2);
             for (int k = 0; k < 20; ++k) {
-                row_kernel<<<(rows + 3) / 4, 256, 0, s1>>>(dy, x, w, base, out + (size_t)(k % 2) * n, rows);
+                row_kernel<<<(rows + 3) / 4, 256, 0, s1>>>(dy, x, w, base, out + (size_t)(k % 2) * n, out16, rows);
             }
             hipDeviceSynchronize();
             for (int k = 0; k < 2; ++k) {
