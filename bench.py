@@ -24,6 +24,12 @@ import os
 import sys
 import time
 
+# The step keeps two streams busy (student / teacher pass) next to torch's current stream, the gradient-sum stream, the
+# all-reduce stream and RCCL's own.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin, and two
+# streams that share a queue run one after the other: measured with the 1-rank RCCL path, 30.6 ms/step with 4 queues vs
+# 25.9 with 8 (without RCCL: 25.9 either way).  Must be set before the HIP runtime initialises, i.e. before `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "dynamic-tuning_amd")):
     if p not in sys.path:

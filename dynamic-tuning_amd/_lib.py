@@ -7,6 +7,12 @@ device memory, streams and torch.distributed.
 import ctypes
 import os
 
+# dyt_step_fwd_bwd runs its two passes on two streams; with DDP-style training there are also the gradient-sum stream, the
+# all-reduce stream and RCCL's.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that
+# share one are serialised (measured: 30.6 vs 25.9 ms/step in the 1-rank RCCL path with 4 vs 8 queues).  Effective only if this
+# module is imported before the HIP runtime initialises (first torch.cuda call); launch scripts should export it themselves.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
 
