@@ -85,7 +85,10 @@ def _worker(rank, world, port, q):
 def test_gather_and_grad_allreduce_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:   # a port that is free right now (a pid-derived one collided with a lingering listener once)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
