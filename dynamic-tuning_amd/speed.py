@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--ffn_num", type=int, default=64)
     ap.add_argument("--nb_classes", type=int, default=100)
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--keep", type=float, default=0.7, help="gate bias is set to logit(keep)")
+    ap.add_argument("--keep", type=float, default=0.7, help="target keep ratio of the deterministic (eval) gate")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="leave the gate biases at logit(keep) (the eval gate then keeps whatever fraction has a positive logit)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     tuning = Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none",
@@ -43,6 +45,17 @@ def main():
     model = model.to(dev).eval()
     x, _ = synth.make_batch(args.batch_size, args.nb_classes, seed=0)
     x = x.to(dev)
+    if not args.no_calibrate:
+        # the reference learns the keep ratio; the harness pins it: shift every block's gate bias so that the target quantile
+        # of its token logits sits at the decision threshold 0 (three sweeps: shifting a block moves the ones after it)
+        with torch.no_grad():
+            for _ in range(3):
+                _, aux = model(x)
+                tl = aux["token_logits"].float()                      # [B, depth, 196, 1] or [B, depth, 196]
+                tl = tl.reshape(tl.shape[0], tl.shape[1], -1).permute(1, 0, 2).reshape(tl.shape[1], -1)
+                q = torch.quantile(tl, 1.0 - args.keep, dim=1)
+                for i, blk in enumerate(model.blocks):
+                    blk.mlp_token_select.mlp_head.bias.sub_(q[i].to(blk.mlp_token_select.mlp_head.bias.device))
     sample, total = 0, 0.0
     aux = None
     with torch.no_grad():
