@@ -209,6 +209,8 @@ def main():
             "images_per_s_per_gpu": round(head["value"] / world, 2),
             "step_gflop_per_image": head["step_gflop_per_image"],
             "step_mfma_frac": head["step_mfma_frac"],
+            "step_gflop_executed_per_image": head["step_gflop_executed_per_image"],
+            "step_mfma_frac_executed": head["step_mfma_frac_executed"],
             "loss": head["loss"],
             "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
             "roofline": head["roofline"],
@@ -314,13 +316,30 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
                 "attention_ms_per_step": round(ms_a, 3), "attention_tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2) if ms_a else None,
                 "other_kernels_ms_per_step": round(ms_o, 3), "other_launches": n_o}
     ips = args.batch * world * steps / dt
-    gflop = STEP_GFLOP_AT_07 + STEP_GFLOP_SLOPE * (keep_meas - 0.7) if mode == "compact" else 139.614
+    # algorithmic FLOPs per image.  compact: MLP forward AND backward on the kept tokens of the student pass;
+    # masked: the student forward is dense (mask-multiply, as the reference), its backward is compacted all the same
+    # (rows of mask * dL/dx' of dropped tokens are zero) -> 133.510 G at k = 0.7 with the backward's share of the slope (11 of 23
+    # block-passes: the forward's 12 are dense, block 0 has no MLP backward).  (Round 2 charged the reference-as-written 139.614.)
+    if mode == "compact":
+        gflop = STEP_GFLOP_AT_07 + STEP_GFLOP_SLOPE * (keep_meas - 0.7)
+    else:
+        gflop = 133.510 + STEP_GFLOP_SLOPE * 11.0 / 23.0 * (keep_meas - 0.7)
+    # what the library EXECUTES is less: the teacher pass reuses the student's patch embedding + block-0 attention branch
+    # (DYT_OPT_SHARE_BLOCK0) and the last block's MLP / adapter run on the cls rows only, forward and backward (DYT_OPT_CLS_TAIL)
+    mlp_tok = 9.437184e-3            # GFLOP per token of one MLP pass (fc1 + fc2)
+    k_fwd = keep_meas if mode == "compact" else 1.0
+    skipped = (0.231211 + 0.697172 + 2 * 0.059609 + 0.232391) + mlp_tok * 196 * (k_fwd + 1.0 + keep_meas + 1.0) \
+        + 2 * 3 * 0.038732 * 196 / 197
+    gflop_exec = gflop - skipped
     if args.video_frames > 1:   # + k/v projections of the pooling head per frame: fwd + dgrad + wgrad, two passes
         gflop += 2 * 3 * 2 * (2 * 197 * 768 * 768) / 1e9
+        gflop_exec = gflop - (0.231211 + 0.697172 + 2 * 0.059609 + 0.232391)   # no cls-only tail in the video model
     res = {"value": round(ips, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 3), "keep_ratio_measured": round(keep_meas, 4),
            "keep_ratio_calibrated": round(keep_cal, 4), "loss": round(host[0], 4), "step_gflop_per_image": round(gflop, 3),
-           "step_mfma_frac": round(ips / world * gflop * 1e9 / (PEAK[precision] * 1e12), 4), "roofline": roof,
+           "step_mfma_frac": round(ips / world * gflop * 1e9 / (PEAK[precision] * 1e12), 4),
+           "step_gflop_executed_per_image": round(gflop_exec, 3),
+           "step_mfma_frac_executed": round(ips / world * gflop_exec * 1e9 / (PEAK[precision] * 1e12), 4), "roofline": roof,
            "hip_graph": bool(args.hip_graph) and not os.environ.get("DYT_NO_OVERLAP")}
     del opt, model, eng
     torch.cuda.empty_cache()

@@ -680,14 +680,21 @@ static int set_lds(const void* f, size_t bytes) {
     DYT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
+// the attribute belongs to the (kernel, device) pair: one flag per device and kernel family
+static bool* attr_flag(int family) {
+    static bool done[3][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return &done[family][dev & 63];
+}
 
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
                     hipStream_t s) {
     const int grid = batch * NH;
     if (precision == 0) {
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);
-        static bool once = false;
-        if (!once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; once = true; }
+        bool* once = attr_flag(0);
+        if (!*once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; *once = true; }
         hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid), dim3(448), lds, s, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, lse);
     } else {
@@ -705,11 +712,11 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
     if (precision == 0) {
         const size_t lds1 = 2 * F_IMG;
         const size_t lds2 = 2 * F_IMG + 2 * NPAD * sizeof(float);
-        static bool once = false;
-        if (!once) {
+        bool* once = attr_flag(1);
+        if (!*once) {
             if (set_lds((const void*)attn_bwd_dq_f32_kernel, lds1)) return -2;
             if (set_lds((const void*)attn_bwd_dkv_f32_kernel, lds2)) return -2;
-            once = true;
+            *once = true;
         }
         hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3(grid), dim3(448), lds1, s, (const float*)q, (const float*)k,
                            (const float*)v, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv);
@@ -718,11 +725,11 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
     } else {
         const size_t lds1 = 2 * ROW_IMG + TR_IMG;
         const size_t lds2 = 2 * ROW_IMG + 2 * TR_IMG + 2 * NPAD * sizeof(float);
-        static bool once = false;
-        if (!once) {
+        bool* once = attr_flag(2);
+        if (!*once) {
             if (set_lds((const void*)attn_bwd_dq_bf16_kernel, lds1)) return -2;
             if (set_lds((const void*)attn_bwd_dkv_bf16_kernel, lds2)) return -2;
-            once = true;
+            *once = true;
         }
         hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds1, s, (const bf16*)q, (const bf16*)k,
                            (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);

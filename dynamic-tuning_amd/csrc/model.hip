@@ -11,8 +11,10 @@
 //   step body                                        engine_finetune.py:47-79
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "../../include/dyt_hip.h"
@@ -872,6 +874,108 @@ extern "C" int dyt_forward(dyt_ctx* c, int slot, const float* images, int batch,
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
+// Measurement hook (tools/probes/determinism_trace.py): DYT_DBG_CKSUM=1 -> after every backward launch an order-independent
+// integer checksum of its output buffer is taken on the same stream into a per-pass log; two runs of the same step are then
+// compared launch by launch: the first differing entry names the kernel whose output is not reproducible.
+__global__ void dbg_checksum_kernel(const uint32_t* __restrict__ p, size_t nwords, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256)
+        acc += (unsigned long long)p[i] * (unsigned long long)((i & 0xffff) + 1);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+struct DbgCk { unsigned long long* dev = nullptr; int n[2] = {0, 0}; int on = -1; std::vector<std::string> label[2]; };
+static DbgCk g_ck;
+constexpr int DBG_CK_MAX = 1024;
+static bool dbg_ck_on() {
+    if (g_ck.on < 0) { const char* e = getenv("DYT_DBG_CKSUM"); g_ck.on = e && atoi(e) ? 1 : 0; }
+    return g_ck.on == 1;
+}
+static int dbg_ck_reset(hipStream_t s) {
+    if (!dbg_ck_on()) return 0;
+    if (!g_ck.dev) DYT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_ck.dev), 2 * DBG_CK_MAX * sizeof(unsigned long long)));
+    DYT_HIP_CHECK(hipMemsetAsync(g_ck.dev, 0, 2 * DBG_CK_MAX * sizeof(unsigned long long), s));
+    for (int i = 0; i < 2; ++i) { g_ck.n[i] = 0; g_ck.label[i].clear(); }
+    return 0;
+}
+static int dbg_ck(int slot, hipStream_t s, const char* what, int layer, const void* p, size_t bytes) {
+    if (!dbg_ck_on() || !p || slot > 1 || g_ck.n[slot] >= DBG_CK_MAX) return 0;
+    char buf[64];
+    snprintf(buf, sizeof(buf), "L%d %s", layer, what);
+    static const char* only = getenv("DYT_DBG_CKSUM_ONLY");   // comma-separated substrings: trace only the matching launches
+    if (only && only[0]) {
+        bool hit = false;
+        std::string pats(only);
+        for (size_t a = 0; a <= pats.size();) {
+            const size_t e = pats.find(',', a) == std::string::npos ? pats.size() : pats.find(',', a);
+            if (e > a && strstr(buf, pats.substr(a, e - a).c_str())) hit = true;
+            a = e + 1;
+        }
+        if (!hit) return 0;
+    }
+    g_ck.label[slot].push_back(buf);
+    hipLaunchKernelGGL(dbg_checksum_kernel, dim3(128), dim3(256), 0, s, static_cast<const uint32_t*>(p), bytes / 4,
+                       g_ck.dev + slot * DBG_CK_MAX + g_ck.n[slot]++);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+#define CK(what, ptr, bytes) do { int _r = dbg_ck(slot, s, (what), l, (ptr), (bytes)); if (_r) return _r; } while (0)
+extern "C" int dyt_debug_checksums(int slot, uint64_t* out, int max_n, int* n_out) {
+    if (!out || !n_out || slot < 0 || slot > 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    *n_out = 0;
+    if (!g_ck.dev) return DYT_OK;
+    DYT_HIP_CHECK(hipDeviceSynchronize());
+    const int n = g_ck.n[slot] < max_n ? g_ck.n[slot] : max_n;
+    DYT_HIP_CHECK(hipMemcpy(out, g_ck.dev + slot * DBG_CK_MAX, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return DYT_OK;
+}
+extern "C" const char* dyt_debug_checksum_label(int slot, int i) {
+    if (slot < 0 || slot > 1 || i < 0 || i >= (int)g_ck.label[slot].size()) return "";
+    return g_ck.label[slot][i].c_str();
+}
+
+// Measurement hook (tools/probes/determinism_cumask.py, PMASK=iso): DYT_DBG_ISO = bit mask of backward kernel classes that are
+// launched on a per-pass stream pinned to ONE shader engine of every XCD (mask bits 24..31 of each word), fork/joined with
+// events around every launch; the probe pins the two pass streams to the other three engines.  Finds which kernel class
+// must share CUs with the other pass for the run-to-run differences of DESIGN.md 7b to appear.
+//   1 attention bwd   2 tok_bwd (+ its reduce)   4 ln_bwd   8 frozen-weight dgrad GEMMs   16 adapter dgrad GEMMs   32 wgrad   64 prep / head
+struct DbgIso { hipStream_t st[4] = {}; hipEvent_t a[4] = {}, b[4] = {}; int mask = -1; };
+static DbgIso g_iso;
+static int dbg_iso_mask() {
+    if (g_iso.mask < 0) { const char* e = getenv("DYT_DBG_ISO"); g_iso.mask = e ? atoi(e) : 0; }
+    return g_iso.mask;
+}
+static int dbg_iso_enter(int slot, int cls, hipStream_t* s, hipStream_t* keep) {
+    *keep = *s;
+    if (!(dbg_iso_mask() & cls)) return 0;
+    if (!g_iso.st[slot]) {
+        uint32_t words[8];
+        for (int i = 0; i < 8; ++i) words[i] = 0xFF000000u;
+        DYT_HIP_CHECK(hipExtStreamCreateWithCUMask(&g_iso.st[slot], 8, words));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&g_iso.a[slot], hipEventDisableTiming));
+        DYT_HIP_CHECK(hipEventCreateWithFlags(&g_iso.b[slot], hipEventDisableTiming));
+    }
+    DYT_HIP_CHECK(hipEventRecord(g_iso.a[slot], *s));
+    DYT_HIP_CHECK(hipStreamWaitEvent(g_iso.st[slot], g_iso.a[slot], 0));
+    *s = g_iso.st[slot];
+    return 0;
+}
+static int dbg_iso_leave(int slot, hipStream_t* s, hipStream_t keep) {
+    if (*s == keep) return 0;
+    DYT_HIP_CHECK(hipEventRecord(g_iso.b[slot], *s));
+    *s = keep;
+    DYT_HIP_CHECK(hipStreamWaitEvent(*s, g_iso.b[slot], 0));
+    return 0;
+}
+#define ISO(cls, body)                                                        \
+    do {                                                                      \
+        hipStream_t _iso_keep;                                                \
+        { int _r = dbg_iso_enter(slot, (cls), &s, &_iso_keep); if (_r) return _r; } \
+        body                                                                  \
+        { int _r = dbg_iso_leave(slot, &s, _iso_keep); if (_r) return _r; }   \
+    } while (0)
+
 // ev_split (optional) is recorded on `s` once the gradients of the head and of every block >= split are enqueued
 static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const float* dlogits, const float* dtoken_select,
                          const float* dtok, const float* dtoken_logits, float* grad, hipStream_t s,
@@ -907,6 +1011,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         RUN(2, 0, launch_head_bwd(dlogits, S.xs[depth], S.cls_n, S.head_stats, c->norm_w, trainable + c->off_hw,
                                   cls_tail ? S.gcls : g, grad + c->off_hw, grad + c->off_hb, B, c->cfg.num_classes,
                                   cls_tail ? 1 : 0, s));
+        { const int l = depth; CK("head_bwd g", cls_tail ? S.gcls : g, (size_t)(cls_tail ? B : M) * D * 4); CK("head_bwd dW", grad + c->off_hw, (size_t)c->cfg.num_classes * D * 4); }
     }
 
     bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
@@ -928,7 +1033,9 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.row_mask = nullptr;
             a.g_at = g_at; a.dH = nullptr; a.dmask = (student && !tail) ? T.dmask : nullptr;
             a.M = Mr;
-            RUN(2, 0, launch_bwd_prep(P, a, s));
+            ISO(64, RUN(2, 0, launch_bwd_prep(P, a, s)););
+            if (g_at) CK("bwd_prep g_at", g_at, (size_t)Mr * D * c->at);
+            if (a.dmask) CK("bwd_prep dmask", T.dmask, (size_t)Mr * 4);
         }
         const void* A_g = g_at ? g_at : (const void*)gin;
         const int* kdev = (dense || tail) ? nullptr : L.total;
@@ -937,7 +1044,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {
             GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
             a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
-            RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s));
+            ISO(16, RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s)););
+            CK("ad_dgrad_up ddz", T.ddz, (size_t)Mr * RP * c->at);
         }
         {   // both weight gradients (+ the two bias gradients as ones columns / rows) in one launch
             WgradArgs w[2];
@@ -950,7 +1058,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = 1.0f;        // down_proj.weight [r, 768]
             b.out_xsum = nullptr; b.alpha_x = 0.f;
             b.out_ysum = gbase + c->off_db; b.alpha_y = 1.0f;                       // down_proj.bias
-            RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s));
+            ISO(32, RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s)););
+            CK("wgrad up_w", gbase + c->off_uw, (size_t)D * r * 4); CK("wgrad down_w", gbase + c->off_dw, (size_t)D * r * 4);
         }
         // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
@@ -958,11 +1067,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
                 a.row_map = (h_by_token && !tail) ? L.row_src : nullptr;
-                RUN_GEMM(EPI_GELU_BWD, a);
+                ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
+                CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
             }
             {
                 GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
-                RUN_GEMM(EPI_STORE_AT, a);
+                ISO(8, RUN_GEMM(EPI_STORE_AT, a););
+                CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * c->at);
             }
         }
         JOIN(sb);
@@ -971,8 +1082,9 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         const bool dad_at = P != 0 && !tail && !first;
         if (!first) {
             GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
-            if (dad_at) { a.out_at = T.dad; RUN_GEMM(EPI_STORE_AT, a); }
-            else { a.out_f32 = gin; a.accumulate = 1; RUN_GEMM(EPI_STORE_F32, a); }   // g <- g + ddz Wdown
+            if (dad_at) { a.out_at = T.dad; ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
+            else { a.out_f32 = gin; a.accumulate = 1; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
+            if (dad_at) CK("ad_dgrad_down dad", T.dad, (size_t)Mr * D * c->at);   // g <- g + ddz Wdown
         }
 
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
@@ -988,27 +1100,41 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
             a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = T.tok_partial; a.M = M; a.write_du = !first;
             int nblk = 0;
-            RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
-            if (student) RUN(2, 0, launch_reduce_partials(T.tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s));
+            ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
+            if (student) RUN(2, 0, launch_reduce_partials(T.tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s)););
+            if (a.write_du) CK("tok_bwd g", g, (size_t)M * D * 4);
+            if (a.du_at) CK("tok_bwd du_at", T.du_at, (size_t)M * D * c->at);
+            if (student) CK("tok_bwd gate grad", gbase + c->off_gw, (size_t)(D + 1) * 4);
         }
-        if (ev_split && l == split) DYT_HIP_CHECK(hipEventRecord(ev_split, s));
+        if (ev_split && l == split) {
+            // video model: the pooling head's k / v weight gradients (side stream, part 0 of the flat buffer) must be final
+            // before the "upper gradients are final" event that the gradient sum and the early all-reduce wait for
+            if (S.pool.wpending) { DYT_HIP_CHECK(hipStreamWaitEvent(s, S.pool.ev_wj, 0)); S.pool.wpending = false; }
+            DYT_HIP_CHECK(hipEventRecord(ev_split, s));
+        }
         if (first) break;
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
             GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
             a.out_at = T.dO;
-            RUN_GEMM(EPI_STORE_AT, a);
+            ISO(8, RUN_GEMM(EPI_STORE_AT, a););
+            CK("proj_dgrad dO", T.dO, (size_t)M * D * c->at);
         }
-        RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
-            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s));
+        ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
+            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s)););
+        CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
             GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
-            RUN_GEMM(EPI_STORE_AT, a);
+            ISO(8, RUN_GEMM(EPI_STORE_AT, a););
+            CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * c->at);
         }
         {   // LN1 backward, fused with the next block's prep (AT copy of g, <g, h> for the gate gradient)
             const LayerS& Ln = S.L[l - 1];
-            RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
-                                    (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, s));
+            ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
+                                    (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, s)););
+            CK("ln_bwd g", g, (size_t)M * D * 4);
+            if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * c->at);
+            if (student) CK("ln_bwd dmask", T.dmask, (size_t)M * 4);
             prepped = true;
         }
     }
@@ -1073,13 +1199,23 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
     // (fork/join with events; graph-capturable).  Profiling mode runs serially for clean per-kernel times.
     const bool par = c->overlap && c->ov_pass && !c->prof;
     if (par && !c->side) {
+        // measurement hook (tools/probes/determinism_cumask.py): DYT_DBG_SIDE_CU_MASK = "cu" | "xcd" pins the teacher pass to
+        // the odd CU octets / the upper four XCDs (mask bit i -> XCD i % 8), the probe pins the caller's stream to the rest
+        const char* dbg_mask = getenv("DYT_DBG_SIDE_CU_MASK");
+        if (dbg_mask && (dbg_mask[0] == 'c' || dbg_mask[0] == 'x' || dbg_mask[0] == 'i')) {
+            uint32_t words[8];
+            for (int i = 0; i < 8; ++i) words[i] = dbg_mask[0] == 'c' ? 0xFF00FF00u : (dbg_mask[0] == 'x' ? 0xF0F0F0F0u : 0x00FFFFFFu);
+            DYT_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->side, 8, words));
+        } else
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
     hipStream_t s2 = par ? c->side : s;
     if (batch % c->frames != 0) { set_error("video model: batch %d is not a multiple of frames %d", batch, c->frames); return DYT_ERR_ARG; }
-    int rc = prep_adapters(c, trainable, s);
+    int rc = dbg_ck_reset(s);
+    if (rc) return rc;
+    rc = prep_adapters(c, trainable, s);
     if (rc) return rc;
     rc = prep_pool(c, trainable, s);
     if (rc) return rc;

@@ -10,6 +10,7 @@
 //   head / cls pooling                          models/vision_transformer_IN21K.py:375-380
 //   CE + KL + AdaLoss                           engine_finetune.py:52-63, models/losses.py:48-84
 //   torch.optim.AdamW                           main_image.py:285
+#include <stdlib.h>
 #include "kernels.h"
 #include "rowhelp.h"
 
@@ -1082,7 +1083,16 @@ int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
         outs.p[i] = WgOut{w.partial, w.out_w, w.sc, w.sj, w.alpha, w.out_xsum, w.alpha_x, w.out_ysum, w.alpha_y};
     }
     if (precision == 0) hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
-    else hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
+    else {
+        // measurement hook: DYT_DBG_WGRAD_LDS = extra dynamic LDS bytes per workgroup (keeps other workgroups off the CU)
+        static int extra = -1;
+        if (extra < 0) {
+            const char* e = getenv("DYT_DBG_WGRAD_LDS");
+            extra = e ? atoi(e) : 0;
+            if (extra > 0) DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, extra));
+        }
+        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks, n), dim3(256), extra, s, src, M, chunk);
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (r + 1) + 255) / 256, n), dim3(256), 0, s, outs, nchunks, r);
     LAUNCH_CHECK();
     return 0;

@@ -157,7 +157,7 @@ class DyTEngine:
         """The same step replayed from a captured hipGraph (one graph launch instead of ~450 kernel launches: the host
         cost per step drops from ~13 ms to well under 1 ms, which is what keeps 8 ranks on a 16-core host from
         becoming launch-bound).  Inputs are copied into static device buffers; the Philox seed lives on the device
-        (DYT_F_DEVICE_SEED) so every replay draws fresh noise; `seed` initialises it when the graph is built."""
+        (DYT_F_DEVICE_SEED) and is set from `seed` before every replay, exactly the value an eager step with the same `seed` uses."""
         key = (tuple(images.shape), tuple(targets.shape), float(target_ratio), float(loss_ratio), float(token_minimal),
                float(token_minimal_weight), bool(masked_dense), bool(accumulate))
         ent = self._graphs.get(key)
@@ -183,12 +183,14 @@ class DyTEngine:
             torch.cuda.synchronize(self.device)
             self.seed_device(seed)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a DataLoader pin-memory thread may call HIP meanwhile
                 self.step_fwd_bwd(x, y, **kw)
             ent = (g, x, y, out)
             self._graphs[key] = ent
-            self.seed_device(seed)
         g, x, y, out = ent
+        # the caller's per-step seed (engine_finetune.step_seed(epoch, it)) goes into the device-side seed word before EVERY replay
+        # (one tiny launch outside the graph): resumed or reordered runs draw the same noise as eager runs with the same seeds
+        self.seed_device(seed)
         if images.data_ptr() != x.data_ptr():
             x.copy_(images, non_blocking=True)
         if targets.data_ptr() != y.data_ptr():

@@ -246,6 +246,61 @@ def step_grads(sd, x, y, g1, g2, keep_masks, **kw):
     return {k: v.detach() for k, v in d.items()}, dict(zip(names, grads)), outs
 
 
+def step_grads_chunked(sd, x, y, g1, g2, keep_masks, chunk, frames=1, scale=0.1, mode="masked", token_target_ratio=0.5,
+                       token_loss_ratio=2.0, depth=DEPTH, drop_p=0.1):
+    """step_grads() for batches whose autograd graph does not fit the host (configs[4]: 16 clips x 8 frames), exact, in
+    chunks of ``chunk`` samples (clips when frames > 1).  Samples interact only through batch means (engine_finetune.py:52-63:
+    CE / KL are means over the samples, models/losses.py:69-72 the mean over ALL gate decisions), so
+      dL/dtheta = sum_chunks d/dtheta [ sum_{samples in chunk}(CE_s + CE_t + KL) / n  +  c * sum_{chunk} token_select ],
+      c = token_loss_ratio * 2 (mean(token_select) - target) / numel(token_select),
+    with the global mean taken from a first gradient-free student pass.  (No minimal-token term.)  Pinned to step_grads by
+    tests/test_oracle_golden.py::test_chunked_step_grads_equal_step_grads."""
+    names = trainable_names(sd)
+    n = y.shape[0]
+    B = x.shape[0]
+    assert B == n * frames and n % chunk == 0
+    fr = chunk * frames
+
+    def sl(c, per):   # rows of chunk c in a tensor with `per` rows per sample-frame
+        return slice(c * fr * per, (c + 1) * fr * per)
+
+    def km(p, c):
+        return None if keep_masks is None else keep_masks[p][:, sl(c, NTOK)]
+
+    kept, total = 0.0, 0
+    with torch.no_grad():
+        for c in range(n // chunk):
+            _, tok = forward(sd, x[sl(c, 1)], g1[0][:, sl(c, 1)], g2[0][:, sl(c, 1)], km(0, c), scale, False, True, mode,
+                             depth=depth, drop_p=drop_p, frames=frames)
+            kept += float(tok["token_select"].double().sum())
+            total += tok["token_select"].numel()
+    mean = kept / total
+    coef = token_loss_ratio * 2.0 * (mean - token_target_ratio) / total
+    leaf = {k: (v.detach().clone().requires_grad_(True) if k in names else v.detach()) for k, v in sd.items()}
+    grads = [torch.zeros_like(sd[k]) for k in names]
+    ce_s = ce_t = klsum = 0.0
+    outs_s, outs_t, sels = [], [], []
+    for c in range(n // chunk):
+        xs, ys = x[sl(c, 1)], y[c * chunk:(c + 1) * chunk]
+        out_s, tok = forward(leaf, xs, g1[0][:, sl(c, 1)], g2[0][:, sl(c, 1)], km(0, c), scale, False, True, mode,
+                             depth=depth, drop_p=drop_p, frames=frames)
+        out_t, _ = forward(leaf, xs, g1[1][:, sl(c, 1)], g2[1][:, sl(c, 1)], km(1, c), scale, True, True, mode,
+                           depth=depth, drop_p=drop_p, frames=frames)
+        a = F.cross_entropy(out_s, ys, reduction="sum")
+        b = F.cross_entropy(out_t, ys, reduction="sum")
+        k = F.kl_div(F.log_softmax(out_s, dim=-1), F.log_softmax(out_t.detach(), dim=-1), reduction="sum", log_target=True)
+        sur = (a + b + k) / n + coef * tok["token_select"].sum()
+        for acc, g in zip(grads, torch.autograd.grad(sur, [leaf[kk] for kk in names])):
+            acc += g
+        ce_s += float(a); ce_t += float(b); klsum += float(k)
+        outs_s.append(out_s.detach()); outs_t.append(out_t.detach()); sels.append(tok["token_select"].detach())
+    tokl = token_loss_ratio * (mean - token_target_ratio) ** 2
+    d = dict(base_loss=ce_s / n, token_loss=tokl, teacher_loss=ce_t / n, distillation_loss=klsum / n,
+             loss=ce_s / n + tokl + ce_t / n + klsum / n)
+    return ({k: torch.tensor(v) for k, v in d.items()}, dict(zip(names, grads)),
+            (torch.cat(outs_s), torch.cat(outs_t), dict(token_select=torch.cat(sels))))
+
+
 def adamw_update(p, g, m, v, step, lr, wd=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.AdamW single-tensor update (decoupled decay on every trainable tensor,
     main_image.py:285).  ``step`` is 1-based.  Returns new (p, m, v)."""

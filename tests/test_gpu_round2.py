@@ -296,6 +296,104 @@ def test_evaluate_vs_reference_golden():
         assert abs(status["keep_ratio"] - float(g["token_select"].mean())) < (1e-6 if prec == "fp32" else 2e-3)
 
 
+def test_evaluate_accuracy_vs_reference_golden_nonzero():
+    """eval_acc.npz: 12 images whose targets were chosen from the reference's own logit ranking (5 top-1 hits, 3 more inside the
+    top 5, 4 misses; every decision >= 0.08 away from a rank swap): evaluate() on the GPU, ragged batches, returns the
+    reference's acc1 = 41.67 (its evaluate(), engine_finetune.py:253-261), acc5 = 66.67 (its accuracy()) and its
+    mean-per-class accuracy -- in both arithmetic modes."""
+    from engine_finetune import evaluate
+    g = dict(np.load(os.path.join(GOLDEN, "eval_acc.npz")))
+    B, C = int(g["meta_batch"]), int(g["meta_num_classes"])
+    x, _ = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    y = torch.from_numpy(g["targets"])
+    assert 0.0 < float(g["metric_accuracy"]) < float(g["acc5"]) < 100.0
+    loader = [(x[:5], y[:5]), (x[5:9], y[5:9]), (x[9:], y[9:])]
+    for prec in ("fp32", "bf16"):
+        model, _ = D.build_model(g, prec)
+        st = evaluate(loader, model, torch.device("cuda", 0), None, None, None, types.SimpleNamespace(metric="accuracy", nb_classes=C))
+        assert abs(st["metric"] - float(g["metric_accuracy"])) < 1e-5, (prec, st)
+        assert abs(st["acc5"] - float(g["acc5"])) < 1e-5, (prec, st)
+        assert abs(st["keep_ratio"] - float(g["token_select_mean"])) < (1e-6 if prec == "fp32" else 3e-3)
+        st = evaluate(loader, model, torch.device("cuda", 0), None, None, None, types.SimpleNamespace(metric="mean_per_class_acc", nb_classes=C))
+        assert abs(st["metric"] - float(g["metric_mean_per_class_acc"])) < 1e-4, (prec, st)
+
+
+_VIDEO_REF = []
+
+
+def _video_full_size_reference():
+    """inputs + the oracle's step at 16 clips x 8 frames, 400 classes (computed once for both precisions: ~30 s of host time)"""
+    if not _VIDEO_REF:
+        clips, frames, C, r, target = 16, 8, 400, 64, 0.5
+        B = clips * frames
+        sd = synth.make_state_dict(C, r, seed=0, kind="test", gate_bias=0.85, video=True)
+        x, y = synth.make_batch(B, C, seed=171)
+        y = y[:clips].contiguous()
+        g1, g2 = synth.make_noise(B, seed=172)
+        keep = synth.make_dropout_masks(B, r, seed=173)
+        torch.set_num_threads(synth.available_cores())
+        d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads_chunked(sd, x, y, g1, g2, keep, 2, frames=frames, scale=0.1, mode="masked",
+                                                                   token_target_ratio=target)
+        _VIDEO_REF.append((sd, x, y, g1, g2, keep, d_ref, g_ref, ref_ls, ref_lt, tok["token_select"][..., 0].float()))
+    return _VIDEO_REF[0]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_video_training_step_at_train_video_sh_size(precision):
+    """BASELINE.json configs[4] at FULL size (train_video.sh:19-31: --batch_size 16 per GPU, 8 frames per clip
+    (video_datasets/video_datasets.py:28), K400 = 400 classes, r = 64, scale 0.1, token_target_ratio 0.5): one fused training
+    step of the video model on 16 clips x 8 frames = 128 frames + the 1 x 1576 attentive pool, in the reference's masked
+    training semantics (engine_finetune.py:109-203), against the oracle on the same seeded inputs / draws: student and teacher
+    logits, every gate decision, the five loss components and all 88 trainable gradients.  The oracle takes the step in
+    8 chunks of 2 clips (step_grads_chunked: exact, pinned to step_grads on CPU) so that its autograd graph fits a host."""
+    from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k
+    clips, frames, C, r, target = 16, 8, 400, 64, 0.5
+    B = clips * frames
+    sd, x, y, g1, g2, keep, d_ref, g_ref, ref_ls, ref_lt, ref_ts = _video_full_size_reference()
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+    m = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                   precision=precision, train_mode="masked", max_batch=B)
+    m.load_state_dict(sd, strict=True)
+    for n, p in m.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    m = m.cuda().train()
+    xc = x.reshape(clips, frames, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous()   # [b,c,t,h,w] as the loader yields it
+    assert torch.equal(m.fold_input(xc), x)
+    eng = m.engine(B, torch.device("cuda", 0))
+    ls = torch.empty(clips, C, device="cuda")
+    lt = torch.empty(clips, C, device="cuda")
+    ts = torch.zeros(B, 12, 196, device="cuda")
+    losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=True, g1=g1.cuda().contiguous(),
+                              g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
+                              token_select=ts).cpu()
+    ltol = 1e-3 if precision == "fp32" else 0.02            # bf16 measured 2e-3 on the 2 x 2 golden
+    assert float((ls.cpu() - ref_ls).abs().max()) < ltol, float((ls.cpu() - ref_ls).abs().max())
+    assert float((lt.cpu() - ref_lt).abs().max()) < ltol, float((lt.cpu() - ref_lt).abs().max())
+    flips = int((ts.cpu() != ref_ts).sum())
+    assert flips <= (4 if precision == "fp32" else B * 3), flips     # of B * 2352 = 301 056 decisions (fp32: ties only)
+    for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
+        ref = float(d_ref[k])
+        assert abs(float(losses[i]) - ref) < (1e-4 if precision == "fp32" else 0.02) * max(1.0, abs(ref)), (k, float(losses[i]), ref)
+    worst = {}
+    scal = []
+    for n, gr in g_ref.items():
+        got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
+        if gr.numel() == 1:
+            scal.append((float(got), float(gr)))
+            continue
+        # norm_k.bias has an exactly-zero true gradient (a constant added to every key shifts all scores equally): absolute floor
+        e = float((got - gr).norm() / max(float(gr.norm()), 1e-4 if precision == "fp32" else 1e-3))
+        kind = n.split(".", 2)[-1] if n.startswith("blocks.") else n
+        tol = _grad_tol(n, precision) if n.startswith("blocks.") or n.startswith("head") else (2e-3 if precision == "fp32" else 0.05)
+        assert e < tol, (precision, n, e)
+        worst[kind] = max(worst.get(kind, 0.0), e)
+    a, b = torch.tensor(scal, dtype=torch.float64).unbind(1)
+    e = float((a - b).norm() / (b.norm() + 1e-20))
+    assert e < _grad_tol("mlp_token_select", precision), e
+    print("video 16x8 %s worst rel-L2:" % precision, {k: "%.1e" % v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]}, "flips", flips)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

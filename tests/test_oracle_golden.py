@@ -132,6 +132,26 @@ def test_eval_and_gather_equivalence(golden_dir):
     assert abs(float(O.accuracy(lm, y, topk=(1, 5))[0]) - float(g["metric"])) < 1e-6
 
 
+def test_eval_accuracy_fixture_is_not_degenerate(golden_dir):
+    """tests/golden/eval_acc.npz (make_golden_eval_acc.py): targets chosen from the reference's own ranking so that its
+    evaluate() returns acc1 = 5/12, acc5 = 8/12 -- the oracle's forward + accuracy() and the mirror's metrics reproduce them."""
+    from util.metrics import accuracy, mean_per_class_accuracy
+    g = load(golden_dir, "eval_acc.npz")
+    B, C, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_seed"])
+    sd = state(g)
+    x, _ = synth.make_batch(B, C, seed=seed)
+    y = torch.from_numpy(g["targets"])
+    with torch.no_grad():
+        lm, _ = O.forward(sd, x, scale=float(g["meta_scale"]), training=False, mode="masked")
+    assert np.abs(lm.numpy() - g["logits"]).max() < 2e-5
+    assert 0.0 < float(g["metric_accuracy"]) < float(g["acc5"]) < 100.0
+    a1, a5 = O.accuracy(lm, y, topk=(1, 5))
+    assert abs(float(a1) - float(g["metric_accuracy"])) < 1e-6 and abs(float(a5) - float(g["acc5"])) < 1e-6
+    b1, b5 = accuracy(lm, y, topk=(1, 5))
+    assert abs(float(b1) - float(g["metric_accuracy"])) < 1e-6 and abs(float(b5) - float(g["acc5"])) < 1e-6
+    assert abs(float(mean_per_class_accuracy(lm, y, C)) - float(g["metric_mean_per_class_acc"])) < 1e-5
+
+
 def test_compact_mode_semantics(step64):
     """compact mode: same forward values, gate gradient only from kept tokens."""
     g, sd, d, grads, outs, (x, y, g1, g2, keep) = step64
@@ -205,3 +225,27 @@ def test_oracle_count_flops_variant_vs_reference(golden_dir):
         with torch.no_grad():
             logits, _ = O.forward(sd, x, scale=float(g["meta_scale"]), training=False, count_flops_tokens=int(n))
         assert np.abs(logits.numpy() - g["logits_n%d" % n]).max() < 2e-5, n
+
+
+@pytest.mark.parametrize("frames", [1, 2])
+def test_chunked_step_grads_equal_step_grads(frames):
+    """oracle.step_grads_chunked (used for the full-size configs[4] GPU test, whose autograd graph does not fit a host) is the
+    same function as the golden-pinned step_grads: 4 samples in chunks of 1 and 2 (image model) / 2 clips x 2 frames."""
+    n, C, r = (4, 10, 8) if frames == 1 else (2, 7, 8)
+    B = n * frames
+    sd = synth.make_state_dict(C, r, seed=5, kind="test", gate_bias=0.4, video=frames > 1)
+    x, y = synth.make_batch(B, C, seed=6)
+    y = y[:n].contiguous()
+    g1, g2 = synth.make_noise(B, seed=7)
+    keep = synth.make_dropout_masks(B, r, seed=8)
+    kw = dict(scale=0.5, mode="masked", token_target_ratio=0.5, frames=frames)
+    d, g, (ls, lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, **kw)
+    for chunk in ((1, 2) if frames == 1 else (1,)):
+        d2, g2_, (ls2, lt2, tok2) = O.step_grads_chunked(sd, x, y, g1, g2, keep, chunk, **kw)
+        assert float((ls2 - ls.detach()).abs().max()) < 1e-5 and float((lt2 - lt.detach()).abs().max()) < 1e-5
+        assert torch.equal(tok2["token_select"], tok["token_select"].detach())
+        for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+            assert abs(float(d2[k]) - float(d[k])) < 1e-5 * max(1.0, abs(float(d[k]))), (k, float(d2[k]), float(d[k]))
+        for k in g:
+            e = float((g2_[k] - g[k]).norm() / max(float(g[k].norm()), 1e-4))   # floor: norm_k.bias has an exactly-zero true gradient
+            assert e < (5e-4 if g[k].numel() == 1 else 5e-5), (chunk, k, e)   # fp32 summation order; the 1-element gate biases are sums of signed terms
