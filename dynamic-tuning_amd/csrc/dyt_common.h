@@ -12,12 +12,23 @@
 #define DYT_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
 
-// ln_bwd / tok_bwd wait for their whole block of independent loads with one `s_waitcnt vmcnt(0)` instead of the compiler's
-// per-use countdown.  Empirical: the step is bit-reproducible on one stream but not when the two backward
-// passes overlap; recording, from the registers, every value these two kernels had loaded showed identical inputs and a
-// low-bit different output row.  Draining the counter cut the frequency of such events at B=4 by ~4x at no measurable cost;
-// it does not remove them (other kernels show the same sensitivity), and the mechanism is not understood.
+// Full drain of the wave's vector-memory counter, ORDERED AFTER the loads that produced the listed registers.
+//
+// Why: on gfx950 a partial wait (`s_waitcnt vmcnt(N)`, N > 0 -- what the compiler emits when a value is needed while younger
+// loads are still in flight) is only safe if loads complete in issue order.  In the row kernels of the backward pass that
+// assumption does not hold when the CU is shared with another stream's LDS/MFMA-heavy workgroups: a load that hits (LN / gate
+// weights, resident in L1) completes ahead of an older load that misses (the row's statistics, its residual snapshot), the
+// counter reaches N, and the wave consumes the older load's destination register before the data has landed -- i.e. whatever
+// a previous wave left there, typically another row's value of the same quantity.  Results then differ run to run at the
+// 1e-2 level in single rows (found with CU-masked streams, per-class isolation, NaN poisoning and
+// `-mllvm -amdgpu-waitcnt-forcezero`; tools/probes/determinism_*.py).  A drain that is (i) a full `vmcnt(0)` and (ii) carries
+// one register of every load instruction of the group as an operand -- so that neither the scheduler nor a `__restrict__`
+// qualifier can move a load below it -- removes the exposure at no measurable cost (the kernels are HBM-bound).
 #define DYT_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DYT_PIN1(a) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory")
+#define DYT_PIN2(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
+#define DYT_PIN3(a, b, c) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
+#define DYT_PIN4(a, b, c, d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
 
 namespace dyt {
 
@@ -68,6 +79,23 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
 __device__ __forceinline__ float lane_f32(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+#ifdef DYT_DPP_NOPS
+// A/B build (tools/probes): every cross-lane step as ONE inline-asm block padded with s_nop 4 on both sides, so that neither the
+// scheduler nor the hazard recogniser decides the distance between a VALU write and the DPP / v_readlane read of that register
+#define DYT_DPP_ADD(out, in, ctrl)                                                                                   \
+    asm volatile("s_nop 4\n\tv_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 4" : "=v"(out) : "v"(in))
+__device__ __forceinline__ float wave_sum(float v) {
+    float a, b, c, d;
+    DYT_DPP_ADD(a, v, "quad_perm:[1,0,3,2]");
+    DYT_DPP_ADD(b, a, "quad_perm:[2,3,0,1]");
+    DYT_DPP_ADD(c, b, "row_half_mirror");
+    DYT_DPP_ADD(d, c, "row_mirror");
+    int s0, s1, s2, s3;
+    asm volatile("s_nop 4\n\tv_readlane_b32 %0, %4, 0\n\tv_readlane_b32 %1, %4, 16\n\tv_readlane_b32 %2, %4, 32\n\tv_readlane_b32 %3, %4, 48\n\ts_nop 4"
+                 : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3) : "v"(d));
+    return (__builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1)) + (__builtin_bit_cast(float, s2) + __builtin_bit_cast(float, s3));
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
     v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
@@ -75,6 +103,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0x140>(v);   // row_mirror: half row <-> half row  => every lane holds its row's sum
     return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
+#endif
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f32<0xB1>(v));
     v = fmaxf(v, dpp_f32<0x4E>(v));

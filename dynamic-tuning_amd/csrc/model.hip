@@ -884,7 +884,8 @@ __global__ void dbg_checksum_kernel(const uint32_t* __restrict__ p, size_t nword
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-struct DbgCk { unsigned long long* dev = nullptr; int n[2] = {0, 0}; int on = -1; std::vector<std::string> label[2]; };
+struct DbgCk { unsigned long long* dev = nullptr; int n[2] = {0, 0}; int on = -1; std::vector<std::string> label[2];
+               void* dump = nullptr; size_t dump_bytes = 0, dump_len = 0; };
 static DbgCk g_ck;
 constexpr int DBG_CK_MAX = 1024;
 static bool dbg_ck_on() {
@@ -914,6 +915,16 @@ static int dbg_ck(int slot, hipStream_t s, const char* what, int layer, const vo
         if (!hit) return 0;
     }
     g_ck.label[slot].push_back(buf);
+    static const char* dump = getenv("DYT_DBG_DUMP");   // "<slot>:<label>": keep a copy of that launch's output buffer
+    if (dump && dump[0] && dump[1] == ':' && dump[0] - '0' == slot && !strcmp(dump + 2, buf)) {
+        if (g_ck.dump_bytes < bytes) {
+            if (g_ck.dump) (void)hipFree(g_ck.dump);
+            DYT_HIP_CHECK(hipMalloc(&g_ck.dump, bytes));
+            g_ck.dump_bytes = bytes;
+        }
+        DYT_HIP_CHECK(hipMemcpyAsync(g_ck.dump, p, bytes, hipMemcpyDeviceToDevice, s));
+        g_ck.dump_len = bytes;
+    }
     hipLaunchKernelGGL(dbg_checksum_kernel, dim3(128), dim3(256), 0, s, static_cast<const uint32_t*>(p), bytes / 4,
                        g_ck.dev + slot * DBG_CK_MAX + g_ck.n[slot]++);
     DYT_HIP_CHECK(hipGetLastError());
@@ -929,6 +940,12 @@ extern "C" int dyt_debug_checksums(int slot, uint64_t* out, int max_n, int* n_ou
     DYT_HIP_CHECK(hipMemcpy(out, g_ck.dev + slot * DBG_CK_MAX, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     *n_out = n;
     return DYT_OK;
+}
+extern "C" int64_t dyt_debug_dump_read(void* dst_device, int64_t max_bytes) {   // -> bytes copied (device to device)
+    if (!g_ck.dump || !dst_device) return 0;
+    const size_t n = g_ck.dump_len < (size_t)max_bytes ? g_ck.dump_len : (size_t)max_bytes;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst_device, g_ck.dump, n, hipMemcpyDeviceToDevice) != hipSuccess) return -1;
+    return (int64_t)n;
 }
 extern "C" const char* dyt_debug_checksum_label(int slot, int i) {
     if (slot < 0 || slot > 1 || i < 0 || i >= (int)g_ck.label[slot].size()) return "";
@@ -975,6 +992,18 @@ static int dbg_iso_leave(int slot, hipStream_t* s, hipStream_t keep) {
         body                                                                  \
         { int _r = dbg_iso_leave(slot, &s, _iso_keep); if (_r) return _r; }   \
     } while (0)
+
+// Measurement hook: DYT_DBG_POISON = bit mask of backward transients that are filled with NaN bit patterns (0xFF bytes) on the
+// stream right before the kernel that produces them.  A consumer that reads a row before its producer's store is visible then
+// turns the final gradient into NaN instead of a 1e-6 difference.   1 dxn  2 dA2  4 dad  8 du_at  16 dO  32 dqkv  64 ddz  128 dZ  256 g_at
+static int dbg_poison(int bit, void* p, size_t bytes, hipStream_t s) {
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("DYT_DBG_POISON"); mask = e ? atoi(e) : 0; }
+    if (!(mask & bit) || !p) return 0;
+    DYT_HIP_CHECK(hipMemsetAsync(p, 0xFF, bytes, s));
+    return 0;
+}
+#define POISON(bit, ptr, bytes) do { int _r = dbg_poison((bit), (ptr), (bytes), s); if (_r) return _r; } while (0)
 
 // ev_split (optional) is recorded on `s` once the gradients of the head and of every block >= split are enqueued
 static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const float* dlogits, const float* dtoken_select,
@@ -1044,6 +1073,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {
             GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
             a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
+            POISON(64, T.ddz, (size_t)Mr * RP * c->at);
             ISO(16, RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s)););
             CK("ad_dgrad_up ddz", T.ddz, (size_t)Mr * RP * c->at);
         }
@@ -1067,11 +1097,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
                 a.row_map = (h_by_token && !tail) ? L.row_src : nullptr;
+                if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
                 CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
             }
             {
                 GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
+                if (dense) POISON(2, T.dA2, (size_t)Mr * D * c->at);
                 ISO(8, RUN_GEMM(EPI_STORE_AT, a););
                 CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * c->at);
             }
@@ -1082,7 +1114,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         const bool dad_at = P != 0 && !tail && !first;
         if (!first) {
             GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
-            if (dad_at) { a.out_at = T.dad; ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
+            if (dad_at) { a.out_at = T.dad; POISON(4, T.dad, (size_t)Mr * D * c->at); ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
             else { a.out_f32 = gin; a.accumulate = 1; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
             if (dad_at) CK("ad_dgrad_down dad", T.dad, (size_t)Mr * D * c->at);   // g <- g + ddz Wdown
         }
@@ -1100,9 +1132,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
             a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = T.tok_partial; a.M = M; a.write_du = !first;
             int nblk = 0;
+            if (a.du_at) POISON(8, T.du_at, (size_t)M * D * c->at);
             ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
             if (student) RUN(2, 0, launch_reduce_partials(T.tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s)););
             if (a.write_du) CK("tok_bwd g", g, (size_t)M * D * 4);
+            if (a.dmask) CK("tok_in dmask", T.dmask, (size_t)M * 4);          // what tok_bwd consumed (unchanged by it)
+            if (a.dA2) CK("tok_in dA2", T.dA2, (size_t)Mr * D * c->at);
+            if (a.dad) CK("tok_in dad", T.dad, (size_t)Mr * D * c->at);
             if (a.du_at) CK("tok_bwd du_at", T.du_at, (size_t)M * D * c->at);
             if (student) CK("tok_bwd gate grad", gbase + c->off_gw, (size_t)(D + 1) * 4);
         }
@@ -1117,19 +1153,23 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {
             GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
             a.out_at = T.dO;
+            POISON(16, T.dO, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("proj_dgrad dO", T.dO, (size_t)M * D * c->at);
         }
+        POISON(32, T.dqkv, (size_t)M * 3 * D * c->at);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s)););
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
             GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
+            POISON(1, T.dxn, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * c->at);
         }
         {   // LN1 backward, fused with the next block's prep (AT copy of g, <g, h> for the gate gradient)
             const LayerS& Ln = S.L[l - 1];
+            if (g_at) POISON(256, g_at, (size_t)M * D * c->at);
             ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
                                     (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, s)););
             CK("ln_bwd g", g, (size_t)M * D * 4);
@@ -1254,6 +1294,10 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
                   c->dl_s, c->dl_t, out_losses, c->dtok, stream);
     if (rc) return rc;
     float* gt = par ? c->grad2 : grad_flat;  // teacher-pass gradients
+    // measurement hook: DYT_DBG_TEACHER_NAN=1 feeds the teacher's backward pass NaN (every value it computes or stores is NaN) and
+    // leaves the two passes' gradients unsummed: any NaN in grad_flat (the student's) is a write across the passes
+    static const bool dbg_tnan = getenv("DYT_DBG_TEACHER_NAN") && atoi(getenv("DYT_DBG_TEACHER_NAN"));
+    if (dbg_tnan && par) DYT_HIP_CHECK(hipMemsetAsync(c->dl_t, 0xFF, (size_t)batch * c->cfg.num_classes * sizeof(float), s));
     if (par) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
     if (!(flags & DYT_F_ACCUM_GRAD)) DYT_HIP_CHECK(hipMemsetAsync(grad_flat, 0, (size_t)c->n_train * sizeof(float), s));
     if (par) DYT_HIP_CHECK(hipMemsetAsync(c->grad2, 0, (size_t)c->n_train * sizeof(float), s2));
@@ -1277,13 +1321,13 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
         // upper part: summed on the aux stream as soon as both passes have left block `split`
         DYT_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_half_s, 0));
         DYT_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_half_t, 0));
-        rc = launch_reduce_partials(c->grad2 + up_off, 1, 0, grad_flat + up_off, (int)up_n, 1.0f, c->aux);
+        if (!dbg_tnan) rc = launch_reduce_partials(c->grad2 + up_off, 1, 0, grad_flat + up_off, (int)up_n, 1.0f, c->aux);
         if (rc) return rc;
         DYT_HIP_CHECK(hipEventRecord(c->ev_upper, c->aux));
         // lower part: after the teacher pass has finished
         DYT_HIP_CHECK(hipEventRecord(c->ev_join, s2));
         DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-        rc = launch_reduce_partials(c->grad2, 1, 0, grad_flat, (int)up_off, 1.0f, s);  // grad_flat[lower] += grad2[lower]
+        if (!dbg_tnan) rc = launch_reduce_partials(c->grad2, 1, 0, grad_flat, (int)up_off, 1.0f, s);  // grad_flat[lower] += grad2[lower]
         if (rc) return rc;
         DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_upper, 0));   // the caller's stream owns the whole buffer on return
     }

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(const float* __restric
     xr.load(x + (size_t)row * D, lane);
     w.load(nw, lane);
     b.load(nb, lane);
+    xr.landed(); w.landed(); b.landed();   // one full drain per load group (DYT_PIN*, dyt_common.h)
     const float2 s1 = ln_stats(xr);
 #pragma unroll
     for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - s1.x) * s1.y * w.v[i] + b.v[i];
@@ -43,11 +44,13 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(const float* __restric
     Row12 o;
     w.load(kw, lane);
     b.load(kb, lane);
+    w.landed(); b.landed();
 #pragma unroll
     for (int i = 0; i < 12; ++i) o.v[i] = (xr.v[i] - s2.x) * s2.y * w.v[i] + b.v[i];
     o.store(xk + (size_t)row * D, lane);
     w.load(vw, lane);
     b.load(vb, lane);
+    w.landed(); b.landed();
 #pragma unroll
     for (int i = 0; i < 12; ++i) o.v[i] = (xr.v[i] - s2.x) * s2.y * w.v[i] + b.v[i];
     o.store(xv + (size_t)row * D, lane);
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const AT* __restrict__
     gk.load(kw, lane);
     gv.load(vw, lane);
     wf.load(nw, lane);
+    gk.landed(); gv.landed(); wf.landed();
 #pragma unroll
     for (int i = 0; i < 12; ++i) a_kx.v[i] = a_k.v[i] = a_vx.v[i] = a_v.v[i] = 0.f;
     const int r0 = blockIdx.x * POOL_ROWS_PER_BLOCK;
@@ -394,7 +398,12 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const AT* __restrict__
         dk.load_at(dxk + (size_t)row * D, lane);
         dv.load_at(dxv + (size_t)row * D, lane);
         xr.load(xf + (size_t)row * D, lane);
-        const float2 s2 = st_kv[row];
+        float2 s2 = st_kv[row];
+        float2 sf = st_f[row];
+        Row12 x0;
+        x0.load(x + (size_t)row * D, lane);
+        dk.landed(); dv.landed(); xr.landed(); x0.landed();
+        DYT_PIN4(s2.x, s2.y, sf.x, sf.y);   // the per-row statistics: the loads whose early consumption made ln_bwd irreproducible
         Row12 dy;
         float s1 = 0.f, sx = 0.f;
 #pragma unroll
@@ -411,9 +420,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const AT* __restrict__
         sx = wave_sum(sx) * (1.0f / D);
 #pragma unroll
         for (int i = 0; i < 12; ++i) dy.v[i] = s2.y * (dy.v[i] - s1 - xr.v[i] * sx);   // dL/dxf
-        Row12 x0;
-        x0.load(x + (size_t)row * D, lane);
-        ln_bwd_row(dy, x0, wf, st_f[row]);
+        ln_bwd_row(dy, x0, wf, sf);
         dy.store(g + (size_t)row * D, lane);
     }
 #pragma unroll

@@ -38,6 +38,8 @@ struct Row12 {
 #pragma unroll
         for (int i = 0; i < 3; ++i) store4(p + i * 256 + lane * 4, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
     }
+    // full vmcnt drain ordered after the three load instructions that filled this row (see DYT_PIN* in dyt_common.h)
+    __device__ __forceinline__ void landed() { DYT_PIN3(v[0], v[4], v[8]); }
     __device__ __forceinline__ float sum() const {
         float s = 0.f;
 #pragma unroll

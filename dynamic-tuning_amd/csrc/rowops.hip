@@ -18,6 +18,30 @@ namespace dyt {
 
 #define LAUNCH_CHECK() DYT_HIP_CHECK(hipGetLastError())
 
+// A/B switches of the probes (tools/probes/README.md): which of the full drains of ln_bwd / tok_bwd are compiled in
+#if defined(DYT_NOPIN_LN) || defined(DYT_NOPIN_ROWS)
+#define LN_ROWPIN(x)
+#else
+#define LN_ROWPIN(x) (x).landed()
+#endif
+#if defined(DYT_NOPIN_LN) || defined(DYT_NOPIN_SCALARS)
+#define LN_SCALPIN3(a, b, c)
+#else
+#define LN_SCALPIN3(a, b, c) DYT_PIN3(a, b, c)
+#endif
+#if defined(DYT_NOPIN_TOK) || defined(DYT_NOPIN_ROWS)
+#define TK_ROWPIN(x)
+#else
+#define TK_ROWPIN(x) (x).landed()
+#endif
+#if defined(DYT_NOPIN_TOK) || defined(DYT_NOPIN_SCALARS)
+#define TK_SCALPIN3(a, b, c)
+#define TK_SCALPIN4(a, b, c, d)
+#else
+#define TK_SCALPIN3(a, b, c) DYT_PIN3(a, b, c)
+#define TK_SCALPIN4(a, b, c, d) DYT_PIN4(a, b, c, d)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm forward / backward
 // ------------------------------------------------------------------------------------------
@@ -32,6 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     xr.load(x + (size_t)row * D, lane);
     wr.load(w, lane);
     br.load(b, lane);
+    xr.landed(); wr.landed(); br.landed();   // one full drain for the whole load group (DYT_PIN*, dyt_common.h)
     const float2 st = ln_stats(xr);
 #pragma unroll
     for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - st.x) * st.y * wr.v[i] + br.v[i];
@@ -50,16 +75,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    Row12 g, xr, wr;
+    // every load of the row is issued up front and completed by ONE full drain that names all of them (DYT_PIN*, dyt_common.h)
+    Row12 g, xr, wr, br;
     g.load_at(dy + (size_t)row * D, lane);
     xr.load_nt(x + (size_t)row * D, lane);   // residual snapshot of the forward pass: last use
     wr.load(w, lane);
-    DYT_VMEM_DRAIN();
-    ln_bwd_row(g, xr, wr, stats[row]);
+    float2 st = stats[row];
+    int r = dst_of_next ? dst_of_next[row] : row;
+    if (base) br.load(base + (size_t)row * D, lane);
+    LN_ROWPIN(g); LN_ROWPIN(xr); LN_ROWPIN(wr);
+    LN_SCALPIN3(st.x, st.y, r);
+    if (base) LN_ROWPIN(br);
+    ln_bwd_row(g, xr, wr, st);
     if (base) {
-        Row12 br;
-        br.load(base + (size_t)row * D, lane);
-        DYT_VMEM_DRAIN();
 #pragma unroll
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
@@ -67,10 +95,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     if (g_at) g.store(g_at + (size_t)row * D, lane);
     if (dmask_next) {
         float dm = 0.f;
-        const int r = dst_of_next ? dst_of_next[row] : row;
         if (h_next && r >= 0) {
             Row12 hr;
             hr.load_at(h_next + (size_t)r * D, lane);
+            LN_ROWPIN(hr);
             dm = dot12(g, hr);
         }
         if (lane == 0) dmask_next[row] = dm;
@@ -116,7 +144,9 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const float* __restric
     Row12 wr, ur;
     wr.load(w, lane);
     ur.load(u + (size_t)t * D, lane);
-    const float l = dot12(ur, wr) + bias[0];
+    float bs = bias[0];
+    wr.landed(); ur.landed(); DYT_PIN1(bs);
+    const float l = dot12(ur, wr) + bs;
     if (lane == 0) logit[t] = l;
 }
 // (2) per image: (Gumbel-)sigmoid, hard threshold, ballot/popcount compaction of the kept-token list
@@ -203,6 +233,7 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
     xr.load(u + (size_t)src * D, lane);
     wr.load(w, lane);
     br.load(bb, lane);
+    xr.landed(); wr.landed(); br.landed();
     const float2 st = ln_stats(xr);
 #pragma unroll
     for (int i = 0; i < 12; ++i) xr.v[i] = (xr.v[i] - st.x) * st.y * wr.v[i] + br.v[i];
@@ -274,6 +305,7 @@ __global__ __launch_bounds__(256) void ln_cls_kernel(const float* __restrict__ u
     xr.load(u + t * D, lane);
     wr.load(w, lane);
     br.load(bb, lane);
+    xr.landed(); wr.landed(); br.landed();
     if (u_cls) xr.store(u_cls + (size_t)b * D, lane);
     const float2 st = ln_stats(xr);
 #pragma unroll
@@ -678,18 +710,20 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     if (t >= M) return;
     Row12 gr;
     gr.load(g + (size_t)t * D, lane);
+    int r = dst_of ? dst_of[t] : t;
+    float mk = row_mask ? row_mask[t] : 1.0f;
+    gr.landed(); DYT_PIN2(r, mk);
     if (g_at) gr.store(g_at + (size_t)t * D, lane);
-    const int r = dst_of ? dst_of[t] : t;
     float dm = 0.f;
     if (r >= 0) {
         if (h) {
             Row12 hr;
             hr.load_at(h + (size_t)r * D, lane);
+            hr.landed();
             dm = dot12(gr, hr);
         }
         if (dH) {
             if (row_mask) {
-                const float mk = row_mask[t];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) gr.v[i] *= mk;
             }
@@ -723,15 +757,18 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
     float dbg = 0.f;
 #pragma unroll
     for (int i = 0; i < 12; ++i) dwg.v[i] = 0.f;
-    if (a.gate_w) wg.load(a.gate_w, lane);
-    if (a.dA2) ln2w.load(a.ln2_w, lane);
+    if (a.gate_w) { wg.load(a.gate_w, lane); TK_ROWPIN(wg); }
+    if (a.dA2) { ln2w.load(a.ln2_w, lane); TK_ROWPIN(ln2w); }
     const int t0 = blockIdx.x * TOK_PER_BLOCK;
     for (int k = wave; k < TOK_PER_BLOCK; k += 4) {
         const int t = t0 + k;
         if (t >= a.M) break;
         const int b = t / NT, n = t - b * NT;
-        Row12 du, ur;
+        // all loads of the token first, then ONE full drain that names every one of them (DYT_PIN*, dyt_common.h): the previous
+        // iteration's stores, the row loads (misses) and the per-token scalars share the counter
+        Row12 du, ur, e, dy;
         const bool need_u = a.dA2 || a.gate_w;
+        const bool gate = a.gate_w && n >= 1;
         if (need_u) ur.load_nt(a.u + (size_t)t * D, lane);   // saved u of the forward pass: last use
         if (a.write_du && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
         else if (a.write_du && n == 0) du.load(a.g_cls + (size_t)b * D, lane);
@@ -739,34 +776,42 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] = 0.f;
         }
-        Row12 e;
         if (a.dad) e.load_at(reinterpret_cast<const AT*>(a.dad) + (size_t)t * D, lane);
         int r = -1;
         if (a.dA2 && a.write_du) r = a.g_cls ? (n == 0 ? b : -1) : (a.dst_of ? a.dst_of[t] : t);
-        DYT_VMEM_DRAIN();
+        float2 st2 = make_float2(0.f, 1.f);
+        if (a.dA2 && a.write_du) st2 = a.stats2[t];
+        float ext = 0.f, sf = 0.f, dmk = 0.f, dlg = 0.f;
+        if (gate) {
+            const size_t oi = (size_t)b * a.out_stride + n - 1;
+            if (a.dtoken_select) ext = a.dtoken_select[oi];
+            else if (a.dtok) ext = a.dtok[0] + (a.maskf[t] != 0.f ? a.dtok[2] : a.dtok[1]);
+            sf = a.soft[t];
+            if (a.dmask) dmk = a.dmask[t];
+            if (a.dtoken_logits) dlg = a.dtoken_logits[oi];
+        }
+        if (need_u) TK_ROWPIN(ur);
+        TK_ROWPIN(du);
+        if (a.dad) TK_ROWPIN(e);
+        TK_SCALPIN4(r, st2.x, st2.y, ext);
+        TK_SCALPIN3(sf, dmk, dlg);
         if (a.dad) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] += e.v[i];
         }
         if (a.dA2 && a.write_du) {
             if (r >= 0) {
-                Row12 dy;
                 dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
-                DYT_VMEM_DRAIN();
-                ln_bwd_row(dy, ur, ln2w, a.stats2[t]);
+                TK_ROWPIN(dy);
+                ln_bwd_row(dy, ur, ln2w, st2);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i];
             }
         }
-        if (a.gate_w && n >= 1) {
-            const size_t oi = (size_t)b * a.out_stride + n - 1;
-            float ext = 0.f;
-            if (a.dtoken_select) ext = a.dtoken_select[oi];
-            else if (a.dtok) ext = a.dtok[0] + (a.maskf[t] != 0.f ? a.dtok[2] : a.dtok[1]);
-            const float sf = a.soft[t];
-            float dlogit = ((a.dmask ? a.dmask[t] : 0.f) + ext) * sf * (1.0f - sf);
+        if (gate) {
+            float dlogit = (dmk + ext) * sf * (1.0f - sf);
             if (a.training) dlogit /= a.tau;
-            if (a.dtoken_logits) dlogit += a.dtoken_logits[oi];
+            dlogit += dlg;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 du.v[i] = fmaf(dlogit, wg.v[i], du.v[i]);

@@ -249,10 +249,11 @@ def test_scheduling_options_do_not_change_results(precision):
 
 @pytest.mark.parametrize("overlap", [0, 4, 1])
 def test_reproducible_schedules_are_bitwise(overlap):
-    """DYT_OPT_STREAM_OVERLAP 0 (one stream) and 4 (forward passes overlapped, backward passes one after the other) give the
-    same bits on every run at every size.  The default schedule (1: both passes overlap end to end) reproduces the forward
-    bit for bit and -- since the adapter weight-gradient kernel was rewritten -- usually the gradients too at this size, but
-    not reliably (~1e-6 events remain, at B=128 in every step), so it is held to 1e-5 relative here.
+    """Every schedule gives the same bits on every run: DYT_OPT_STREAM_OVERLAP 0 (one stream), 4 (forward passes overlapped,
+    backward passes one after the other) and 1 (the default, the one bench.py measures: both passes overlap end to end).
+    Until round 3 the default schedule differed run to run at the 1e-6 level: ln_bwd consumed its per-row
+    (mean, rstd) pair under a partial `s_waitcnt vmcnt(N)` and, with the other pass's weight-gradient workgroups on the same
+    CU, occasionally before the load had landed; every row kernel now completes its load group with one full, pinned drain.
     B=16 (pre-shuffled-weight GEMMs included), fast mode, two steps each, contexts rebuilt."""
     import _lib
     B = 16
@@ -274,10 +275,38 @@ def test_reproducible_schedules_are_bitwise(overlap):
         for i in range(2):
             assert torch.equal(r[i][0], runs[0][i][0])          # losses: forward only
             assert float(r[i][1].abs().max()) > 0
-            if overlap == 1:
-                assert float((r[i][1] - runs[0][i][1]).norm() / runs[0][i][1].norm()) < 1e-5
-            else:
-                assert torch.equal(r[i][1], runs[0][i][1])
+            assert torch.equal(r[i][1], runs[0][i][1])
+
+
+@pytest.mark.parametrize("mode", ["compact", "masked"])
+def test_default_schedule_is_bitwise_at_bench_size(mode):
+    """The benchmarked configuration itself: B=128, bf16, both passes overlapped end to end (DYT_OPT_STREAM_OVERLAP = 1).
+    11 rebuilt contexts x 2 steps = 20 comparisons against the first run, gradients bit for bit (round 2: every one of them
+    differed, ~2e-6 absolute in ~1.09 M of the 1.28 M gradient elements)."""
+    import _lib
+    B = 128
+    x, y = synth.make_batch(B, 100, seed=23)
+    x, y = x.cuda(), y.cuda()
+    ref = None
+    for run in range(11):
+        m = _bench_model("bf16", mode, B, 0.85)
+        m.train()
+        eng = m.engine(B, torch.device("cuda", 0))
+        eng.set_option(_lib.OPT_STREAM_OVERLAP, 1)
+        out = []
+        for i in range(2):
+            losses = eng.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), seed=700 + i).clone()
+            torch.cuda.synchronize()
+            out.append((losses.clone(), eng.grad.clone()))
+        del m, eng
+        torch.cuda.empty_cache()
+        if ref is None:
+            ref = out
+            assert float(ref[0][1].abs().max()) > 0
+            continue
+        for i in range(2):
+            assert torch.equal(out[i][0], ref[i][0]), (run, i)
+            assert torch.equal(out[i][1], ref[i][1]), (run, i, float((out[i][1] - ref[i][1]).abs().max()))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -428,19 +428,14 @@ def _two_steps(B=4, graph=False, seed0=900):
 
 
 def _same_training(a, b):
-    """Two runs of the same three steps.  Not bit-equal by design of the comparison: with the two passes of a step on
-    concurrent streams, identical runs of the backward pass differ in isolated rows at the 1e-5 relative level (DESIGN.md
-    section 7b; the serial schedule is bitwise reproducible and is what test_scheduling_options... pins), and AdamW turns a
-    sign flip of a ~zero gradient into a 2*lr parameter difference -- so the first step is compared tightly (forward bit for
-    bit, gradient to 1e-4) and the following steps as a trajectory."""
+    """Two runs of the same three steps (default schedule: both passes overlapped end to end) are the same bits: losses,
+    the first step's gradient and the parameters after three AdamW updates.  (Rounds 1-2 could only compare a trajectory here:
+    the overlapped backward was not reproducible until the row kernels' partial vmcnt waits were replaced)"""
     flat_a, loss_a, grad_a = a
     flat_b, loss_b, grad_b = b
-    assert torch.equal(loss_a[0, :5], loss_b[0, :5])                                  # step 1 forward: bit for bit
-    assert float((grad_a - grad_b).norm() / grad_a.norm()) < 1e-4                     # step 1 gradient
-    # later steps see parameters that went through Adam's g/sqrt(v) normalisation (a ~zero gradient that flips sign moves
-    # its parameter by 2*lr): same trajectory, not the same bits
-    assert float((loss_a[:, :5] - loss_b[:, :5]).abs().max()) < 1e-2 * float(loss_a[:, 0].abs().max())
-    assert float((flat_a - flat_b).abs().max()) <= 3 * 2e-3 + 1e-6 and float((flat_a - flat_b).abs().mean()) < 2e-4
+    assert torch.equal(loss_a, loss_b), float((loss_a - loss_b).abs().max())
+    assert torch.equal(grad_a, grad_b), float((grad_a - grad_b).abs().max())
+    assert torch.equal(flat_a, flat_b), float((flat_a - flat_b).abs().max())
 
 
 def test_rccl_one_rank_path_equals_no_dist(rccl_one_rank):

@@ -9,6 +9,9 @@ if mask != "none":
     os.environ["DYT_DBG_SIDE_CU_MASK"] = mask   # cu | xcd | iso (with DYT_DBG_ISO=<class bits>, see csrc/model.hip)
 import torch
 import _lib, synth
+if os.environ.get("DYT_LIB_PATH"):   # A/B against another build of the library
+    _lib.LIB_PATH = os.environ["DYT_LIB_PATH"]
+    assert os.path.exists(_lib.LIB_PATH), _lib.LIB_PATH
 import test_gpu_round2 as T
 B = int(os.environ.get("PB", "128")); NRUN = int(os.environ.get("PRUNS", "6")); overlap = int(os.environ.get("POVERLAP", "1"))
 _lib.lib()
