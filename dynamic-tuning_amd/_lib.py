@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
-F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED = 1, 2, 4, 8, 16, 32, 64
+F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED, F_TOKENS_IN, F_TOKENS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS = 1, 2, 3, 4
 
 # enum dyt_param (include/dyt_hip.h)
@@ -104,17 +104,24 @@ SYMBOLS = {
     "dyt_seed": (_i, [_vp, _u64, _vp]),
     "dyt_grad_part": (_i, [_vp, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dyt_stream_wait_grads": (_i, [_vp, _i, _vp]),
+    "dyt_allreduce_grads": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dyt_clip_grad_norm": (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp]),
     "dyt_debug_dispatch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dyt_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dyt_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "dyt_adapter_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _u64, _i, _vp]),
+    "dyt_adapter_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _u64, _i, _vp]),
+    "dyt_mlp_gathered_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "dyt_gate_compact": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dyt_gemm_bf16_raw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_gemm_f32_raw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_wgrad_scratch_floats": (ctypes.c_int64, [_i]),
     "dyt_wgrad_raw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dyt_debug_counters": (_i, [ctypes.POINTER(ctypes.c_uint64), _i]),
+    "dyt_debug_checksums": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), _i, ctypes.POINTER(_i)]),
+    "dyt_debug_checksum_label": (ctypes.c_char_p, [_i, _i]),
+    "dyt_debug_dump_read": (ctypes.c_int64, [_vp, _i64]),
     "dyt_profile_enable": (_i, [_vp, _i]),
     "dyt_profile_read": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                               ctypes.POINTER(ctypes.c_double)]),
@@ -136,6 +143,9 @@ def lib():
         if not os.path.exists(rt):
             raise DyTError("PyTorch-ROCm's HIP runtime not found at %s" % rt)
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(rccl):   # dyt_allreduce_grads binds ncclAllReduce (a weak reference) to the RCCL torch.distributed uses
+            ctypes.CDLL(rccl, mode=ctypes.RTLD_GLOBAL)
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
@@ -161,3 +171,50 @@ def ptr(t):
 def stream_ptr():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- RCCL communicator for dyt_allreduce_grads: created natively (ncclCommInitRank), the 128-byte unique id travels over the
+# ---- already initialised torch.distributed group (plumbing only) ----------------------------------------------------------------
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * 128)]
+
+
+_rccl = None
+
+
+def rccl():
+    global _rccl
+    if _rccl is None:
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            raise DyTError("PyTorch-ROCm's librccl.so not found at %s" % path)
+        R = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        R.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+        R.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        R.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        R.ncclGetErrorString.restype = ctypes.c_char_p
+        _rccl = R
+    return _rccl
+
+
+def rccl_comm_create(device, group=None):
+    """One ncclComm_t per process over the ranks of the (initialised) torch.distributed group."""
+    import torch
+    import torch.distributed as dist
+    R = rccl()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = _NcclUniqueId()
+    if rank == 0:
+        rc = R.ncclGetUniqueId(ctypes.byref(uid))
+        if rc != 0:
+            raise DyTError("ncclGetUniqueId: %s" % R.ncclGetErrorString(rc).decode())
+    t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().tolist()), 128)
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = R.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise DyTError("ncclCommInitRank: %s" % R.ncclGetErrorString(rc).decode())
+    return comm

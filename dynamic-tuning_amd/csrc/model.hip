@@ -161,7 +161,7 @@ struct dyt_ctx {
     uint64_t* seed_dev = nullptr;   // device-side Philox seed word (DYT_F_DEVICE_SEED: captured graphs draw fresh noise per replay)
     float* clip_scratch = nullptr;  // [256] partial sums of dyt_clip_grad_norm
     // gradient availability for a chunked all-reduce (dyt_stream_wait_grads): layers >= grad_split and the head are final
-    hipEvent_t ev_half_s = nullptr, ev_half_t = nullptr, ev_upper = nullptr;
+    hipEvent_t ev_half_s = nullptr, ev_half_t = nullptr, ev_upper = nullptr, ev_comm = nullptr;
     hipStream_t aux = nullptr;       // sums the upper part of the two passes' gradient buffers while the backward goes on
     bool upper_recorded = false;
     bool cls_tail = true;      // last block: MLP/adapter on the cls rows only (only they reach the head)
@@ -395,6 +395,7 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
     if (c->ev_half_s) hipEventDestroy(c->ev_half_s);
     if (c->ev_half_t) hipEventDestroy(c->ev_half_t);
     if (c->ev_upper) hipEventDestroy(c->ev_upper);
+    if (c->ev_comm) hipEventDestroy(c->ev_comm);
     if (c->aux) hipStreamDestroy(c->aux);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -749,7 +750,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
-    if (!share0) {
+    const bool tokens_in = flags & DYT_F_TOKENS_IN, tokens_out = flags & DYT_F_TOKENS_OUT;
+    if (tokens_in) {
+        // stand-alone Block.forward (reference vision_transformer_IN21K.py:144-165 called on a token tensor, as
+        // block_flops_dict.py:36-46 does): `images` IS the residual stream [B,197,768]
+        DYT_HIP_CHECK(hipMemcpyAsync(S.xs[0], images, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else if (!share0) {
         // patch embedding: im2col + GEMM (+bias +pos_embed), cls rows
         RUN(2, 0, launch_im2col(P, images, T.xn, B, s));
         {
@@ -783,7 +789,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             }
             if (l == 0 && ev_b0_record) DYT_HIP_CHECK(hipEventRecord(ev_b0_record, s));
         }
-        const bool tail = c->cls_tail && l == depth - 1;  // only the cls rows of the last block reach the head
+        const bool tail = c->cls_tail && l == depth - 1 && !tokens_out;  // only the cls rows of the last block reach the head
         const int Mr = tail ? B : M;                       // rows the adapter / MLP of this block run on
         if (tail)   // LN2 of the cls rows + their AT copy (adapter operand); everything below works on B rows
             RUN(2, 0, launch_ln_cls(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, S.ucls_at, B, s));
@@ -848,14 +854,16 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN_GEMM(EPI_FC2, a);
         }
     }
-    if (c->frames > 1) {
+    if (tokens_out) {   // the block stack's output tokens instead of the head: `logits` receives [B,197,768]
+        DYT_HIP_CHECK(hipMemcpyAsync(logits, S.xs[depth], (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else if (c->frames > 1) {
         int rc = pool_forward(c, S, trainable, logits, B, s);
         if (rc) return rc;
     } else {
         RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
                                   S.head_stats, logits, B, c->cfg.num_classes, s));
     }
-    S.batch = B; S.flags = flags; S.valid = save; S.trainable = trainable;
+    S.batch = B; S.flags = flags; S.valid = save && !tokens_in && !tokens_out; S.trainable = trainable;   // token-level passes are forward only
     return DYT_OK;
 }
 
@@ -1356,6 +1364,41 @@ extern "C" int dyt_stream_wait_grads(dyt_ctx* c, int part, void* stream) {
     return DYT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// gradient all-reduce on RCCL, behind the ABI (reference: DistributedDataParallel's bucket all-reduce inside loss.backward(),
+// main_image.py:280-282 / misc.py:258-259).  librccl is NOT a link-time dependency: the symbol binds at load time to the RCCL that
+// the host process already has (PyTorch's, promoted to the global scope by _lib.py, or the binder's own); absent -> an error.
+// ------------------------------------------------------------------------------------------
+extern "C" int ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm,
+                             hipStream_t stream) __attribute__((weak));
+extern "C" const char* ncclGetErrorString(int result) __attribute__((weak));
+
+extern "C" int dyt_allreduce_grads(dyt_ctx* c, void* rccl_comm, float* grad_flat, void* comm_stream, void* stream) {
+    if (!c || !rccl_comm || !grad_flat) { set_error("null argument"); return DYT_ERR_ARG; }
+    if (!ncclAllReduce) { set_error("RCCL is not loaded in this process (ncclAllReduce unresolved)"); return DYT_ERR_STATE; }
+    constexpr int kNcclFloat32 = 7, kNcclSum = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream), cs = static_cast<hipStream_t>(comm_stream);
+    const int64_t up_off = (int64_t)(c->cfg.depth / 2) * c->layer_stride, up_n = c->n_train - up_off;
+    auto chk = [](int rc) {
+        if (rc != 0) { set_error("ncclAllReduce failed: %s", ncclGetErrorString ? ncclGetErrorString(rc) : "?"); return DYT_ERR_HIP; }
+        return 0;
+    };
+    if (cs && cs != s && c->upper_recorded) {
+        // part 0 (head + upper blocks): final half-way through the backward pass -> reduced on the communication stream while the
+        // frozen-backbone backward of the lower blocks is still running on `stream`; part 1 follows on `stream`
+        if (!c->ev_comm) DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+        DYT_HIP_CHECK(hipStreamWaitEvent(cs, c->ev_upper, 0));
+        int rc = chk(ncclAllReduce(grad_flat + up_off, grad_flat + up_off, (size_t)up_n, kNcclFloat32, kNcclSum, rccl_comm, cs));
+        if (rc) return rc;
+        DYT_HIP_CHECK(hipEventRecord(c->ev_comm, cs));
+        rc = chk(ncclAllReduce(grad_flat, grad_flat, (size_t)up_off, kNcclFloat32, kNcclSum, rccl_comm, s));
+        if (rc) return rc;
+        DYT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm, 0));
+        return DYT_OK;
+    }
+    return chk(ncclAllReduce(grad_flat, grad_flat, (size_t)c->n_train, kNcclFloat32, kNcclSum, rccl_comm, s));
+}
+
 extern "C" int dyt_clip_grad_norm(dyt_ctx* c, float* grad, int64_t numel, float max_norm, float pre_scale, float* norm_out,
                                   void* stream) {
     if (!c || !grad || numel < 1 || !(max_norm > 0.f)) { set_error("bad argument"); return DYT_ERR_ARG; }
@@ -1474,6 +1517,158 @@ extern "C" int dyt_attention(const float* qkv, float* out, const float* dout, fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     return precision == 0 ? attention_test<float>(qkv, out, dout, dqkv, batch, 0, s)
                           : attention_test<bf16>(qkv, out, dout, dqkv, batch, 1, s);
+}
+
+// ---- sub-module unit entries: the adapter and the gathered MLP alone, through the product's own kernels ----
+namespace dyt {
+// per image: kept-token list (ascending) and count from a {0,1} mask -- what gate_select_kernel leaves behind
+__global__ __launch_bounds__(256) void mask_to_keep_kernel(const float* __restrict__ maskf, int* __restrict__ keep_local,
+                                                           int* __restrict__ counts) {
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool keep = tid < NT && maskf[(size_t)b * NT + tid] != 0.f;
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (keep) keep_local[(size_t)b * NT + off + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
+    if (tid == 0) counts[b] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+}  // namespace dyt
+
+struct AdapterOps {   // AT copies of one adapter's weights in the layouts the GEMMs want (see prep_adapters_kernel)
+    void *x_at, *down_w, *down_wT, *up_w, *up_wT, *d_act;
+    float* down_b;
+};
+static int adapter_prepare(Scratch& sc, int P, const float* x, const float* down_w, const float* down_b, const float* up_w, int M, int r,
+                           AdapterOps* o, hipStream_t s) {
+    const size_t at = at_size(P);
+    o->x_at = P == 0 ? (void*)x : sc.get((size_t)M * D * at);
+    o->down_w = sc.get((size_t)RP * D * at); o->down_wT = sc.get((size_t)RP * D * at);
+    o->up_w = sc.get((size_t)RP * D * at); o->up_wT = sc.get((size_t)RP * D * at);
+    o->d_act = sc.get((size_t)M * RP * at);
+    o->down_b = (float*)sc.get(RP * sizeof(float));
+    if (!o->x_at || !o->down_w || !o->down_wT || !o->up_w || !o->up_wT || !o->d_act || !o->down_b) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    int rc = 0;
+    if (P != 0) rc = launch_convert(P, x, o->x_at, (int64_t)M * D, s);
+    if (!rc) rc = launch_pad_convert(P, down_w, o->down_w, r, D, RP, D, s);              // [RP,768], rows >= r zero
+    if (!rc) rc = launch_transpose_convert(P, down_w, o->down_wT, r, D, D, RP, s);       // [768,RP]
+    if (!rc) rc = launch_pad_convert(P, up_w, o->up_w, D, r, D, RP, s);                  // [768,RP], cols >= r zero
+    if (!rc) rc = launch_transpose_convert(P, up_w, o->up_wT, D, r, RP, D, s);           // [RP,768]
+    if (rc) return rc;
+    DYT_HIP_CHECK(hipMemsetAsync(o->down_b, 0, RP * sizeof(float), s));
+    DYT_HIP_CHECK(hipMemcpyAsync(o->down_b, down_b, (size_t)r * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+static int adapter_down(int P, const AdapterOps& o, int M, int r, float drop_p, const uint8_t* keep, uint64_t seed, hipStream_t s) {
+    GemmArgs a; a.A = o.x_at; a.W = o.down_w; a.M = M; a.N = RP; a.K = D; a.bias = o.down_b; a.out_at = o.d_act; a.r = r;
+    a.drop_p = drop_p; a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; a.keep = keep; a.seed = seed; a.subseq = 1;
+    return launch_gemm(P, EPI_AD_DOWN, a, s);
+}
+
+// Adapter.forward (reference models/dynamic_adapter.py:120-140): out = [residual +] scale * up(dropout_p(relu(down(x))))
+extern "C" int dyt_adapter_fwd(const float* x, const float* down_w, const float* down_b, const float* up_w, const float* up_b,
+                               const float* residual, float* out, int M, int r, float scale, float drop_p, const uint8_t* keep_mask,
+                               uint64_t seed, int precision, void* stream) {
+    if (!x || !down_w || !down_b || !up_w || !up_b || !out || M < 1 || r < 1 || r > RP || (precision != 0 && precision != 1)) {
+        set_error("bad argument");
+        return DYT_ERR_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch sc;
+    AdapterOps o;
+    int rc = adapter_prepare(sc, precision, x, down_w, down_b, up_w, M, r, &o, s);
+    if (rc) return rc;
+    float* zero = nullptr;
+    if (!residual) {
+        zero = (float*)sc.get((size_t)M * D * sizeof(float));
+        if (!zero) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+        DYT_HIP_CHECK(hipMemsetAsync(zero, 0, (size_t)M * D * sizeof(float), s));
+    }
+    rc = adapter_down(precision, o, M, r, drop_p, keep_mask, seed, s);
+    if (rc) return rc;
+    GemmArgs a; a.A = o.d_act; a.W = o.up_w; a.M = M; a.N = D; a.K = RP; a.bias = up_b; a.resid = residual ? residual : zero;
+    a.out_f32 = out; a.scale = scale;
+    rc = launch_gemm(precision, EPI_AD_UP, a, s);
+    if (rc) return rc;
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
+}
+
+// Its backward for an upstream gradient dout [M,768] (the same draws): dx [M,768] (may be NULL) and the four parameter gradients,
+// ACCUMULATED into d_down_w [r,768], d_down_b [r], d_up_w [768,r], d_up_b [768].
+extern "C" int dyt_adapter_bwd(const float* x, const float* down_w, const float* down_b, const float* up_w, const float* dout, float* dx,
+                               float* d_down_w, float* d_down_b, float* d_up_w, float* d_up_b, int M, int r, float scale, float drop_p,
+                               const uint8_t* keep_mask, uint64_t seed, int precision, void* stream) {
+    if (!x || !down_w || !down_b || !up_w || !dout || !d_down_w || !d_down_b || !d_up_w || !d_up_b || M < 1 || r < 1 || r > RP ||
+        (precision != 0 && precision != 1)) {
+        set_error("bad argument");
+        return DYT_ERR_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int P = precision;
+    const size_t at = at_size(P);
+    Scratch sc;
+    AdapterOps o;
+    int rc = adapter_prepare(sc, P, x, down_w, down_b, up_w, M, r, &o, s);
+    if (rc) return rc;
+    rc = adapter_down(P, o, M, r, drop_p, keep_mask, seed, s);   // recompute the bottleneck activations (relu / dropout pattern)
+    if (rc) return rc;
+    void* g_at = P == 0 ? (void*)dout : sc.get((size_t)M * D * at);
+    void* ddz = sc.get((size_t)M * RP * at);
+    float* p1 = (float*)sc.get((size_t)dyt_wgrad_scratch_floats(M) * sizeof(float));
+    float* p2 = (float*)sc.get((size_t)dyt_wgrad_scratch_floats(M) * sizeof(float));
+    if (!g_at || !ddz || !p1 || !p2) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    if (P != 0) { rc = launch_convert(P, dout, g_at, (int64_t)M * D, s); if (rc) return rc; }
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    {
+        GemmArgs a; a.A = g_at; a.W = o.up_wT; a.M = M; a.N = RP; a.K = D; a.aux_at = o.d_act; a.out_at = ddz; a.scale = scale; a.inv_keep = inv_keep;
+        rc = launch_gemm(P, EPI_AD_DGRAD_UP, a, s); if (rc) return rc;
+    }
+    WgradArgs w[2];
+    w[0].X = g_at; w[0].Y = o.d_act; w[0].M = M; w[0].r = r; w[0].partial = p1; w[0].out_w = d_up_w; w[0].sc = r; w[0].sj = 1;
+    w[0].alpha = scale; w[0].out_xsum = d_up_b; w[0].alpha_x = scale;
+    w[1].X = o.x_at; w[1].Y = ddz; w[1].M = M; w[1].r = r; w[1].partial = p2; w[1].out_w = d_down_w; w[1].sc = 1; w[1].sj = D;
+    w[1].alpha = 1.0f; w[1].out_xsum = nullptr; w[1].alpha_x = 0.f; w[1].out_ysum = d_down_b; w[1].alpha_y = 1.0f;
+    rc = launch_wgrad(P, w, 2, s); if (rc) return rc;
+    if (dx) {
+        GemmArgs a; a.A = ddz; a.W = o.down_wT; a.M = M; a.N = D; a.K = RP; a.out_f32 = dx; a.accumulate = 0;
+        rc = launch_gemm(P, EPI_STORE_F32, a, s); if (rc) return rc;
+    }
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
+}
+
+// The token-gathered MLP of block `layer` with the context's frozen weights (reference models/model_speed_test.py:297-305):
+// x [B*197,768] += scatter(fc2(gelu(fc1(LN2(gather(u, mask)))))) for the tokens whose mask is non-zero; u, x fp32, mask [B*197].
+extern "C" int dyt_mlp_gathered_fwd(dyt_ctx* c, int layer, const float* u, const float* mask, float* x, int batch, int32_t* total_out,
+                                    void* stream) {
+    if (!c || !u || !mask || !x || layer < 0 || layer >= c->cfg.depth || batch < 1 || batch > c->cfg.max_batch) { set_error("bad argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int P = c->prec, M = batch * NT;
+    const LayerW& W = c->W[layer];
+    Scratch sc;
+    int* keep_local = (int*)sc.get((size_t)M * 4); int* counts = (int*)sc.get((size_t)batch * 4); int* total = (int*)sc.get(16);
+    int* row_src = (int*)sc.get((size_t)M * 4); int* dst_of = (int*)sc.get((size_t)M * 4);
+    float2* st = (float2*)sc.get((size_t)M * sizeof(float2));
+    void* xn = sc.get((size_t)M * D * c->at); void* h1 = sc.get((size_t)M * DM * c->at);
+    if (!keep_local || !counts || !total || !row_src || !dst_of || !st || !xn || !h1) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    hipLaunchKernelGGL(mask_to_keep_kernel, dim3(batch), dim3(256), 0, s, mask, keep_local, counts);
+    DYT_HIP_CHECK(hipGetLastError());
+    int rc = launch_ln_gather(P, u, W.ln2_w, W.ln2_b, keep_local, counts, total, mask, xn, st, row_src, dst_of, batch, s);
+    if (rc) return rc;
+    {
+        GemmArgs a; a.A = xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = M; a.N = DM; a.K = D; a.m_dev = total; a.bias = W.fc1_b; a.out_at = h1;
+        rc = launch_gemm(P, EPI_FC1, a, s); if (rc) return rc;
+    }
+    {
+        GemmArgs a; a.A = h1; a.W = W.fc2_w; a.M = M; a.N = D; a.K = DM; a.m_dev = total; a.bias = W.fc2_b; a.out_f32 = x; a.row_map = row_src;
+        rc = launch_gemm(P, EPI_FC2, a, s); if (rc) return rc;
+    }
+    if (total_out) DYT_HIP_CHECK(hipMemcpyAsync(total_out, total, 4, hipMemcpyDeviceToDevice, s));
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
 }
 
 extern "C" int dyt_gate_compact(const float* u, const float* w, const float* b, const float* g1, const float* g2, int batch,

@@ -9,6 +9,7 @@ dyt_adamw -- with NO per-step host synchronisation: the reference's ``loss.item(
 accumulation of the five loss components, read back once per ``print_freq`` steps.
 """
 import math
+import os
 import time
 
 import torch
@@ -147,6 +148,10 @@ def allreduce_grads(engine, group=None, overlap=True):
     blocks is still running -- what DDP's bucket hooks do inside loss.backward() (misc.py:258-259)."""
     if not is_dist_avail_and_initialized():
         return 1.0
+    if engine.grad.is_cuda and group is None and os.environ.get("DYT_NATIVE_RCCL", "1") != "0" and hasattr(engine, "allreduce_native"):
+        # the collective behind the C ABI (dyt_allreduce_grads): RCCL called by the library on a communicator of its own
+        engine.allreduce_native(overlap=overlap)
+        return 1.0 / dist.get_world_size()
     if overlap and engine.grad.is_cuda:
         off, num = engine.grad_part(0)
         comm, cur = engine.comm_stream(), torch.cuda.current_stream(engine.device)

@@ -93,8 +93,8 @@ class TokenSelect(nn.Module):
 
 
 class Adapter(nn.Module):
-    """Reference models/dynamic_adapter.py:80-140 (parameter container + attributes; the arithmetic
-    runs inside VisionTransformer's fused HIP path)."""
+    """Reference models/dynamic_adapter.py:80-140.  Inside a VisionTransformer the arithmetic runs in the fused HIP path;
+    ``forward`` stand-alone calls the same adapter kernels through the C ABI (forward only)."""
 
     def __init__(self, config=None, d_model=None, bottleneck=None, dropout=0.0, init_option="bert",
                  adapter_scalar="1.0", adapter_layernorm_option="in"):
@@ -120,6 +120,23 @@ class Adapter(nn.Module):
             nn.init.zeros_(self.down_proj.bias)
             nn.init.zeros_(self.up_proj.bias)
 
-    def forward(self, x, add_residual=True, residual=None):
-        raise DyTError("Adapter is evaluated inside VisionTransformer's fused HIP path (adapter GEMMs of "
-                       "csrc/gemm.hip); call the model, not the sub-module")
+    def forward(self, x, add_residual=True, residual=None, keep_mask=None, seed=0, precision=1):
+        """Reference :120-140, stand-alone: ``up(dropout(relu(down(x)))) * scale`` (+ residual), through the product's adapter
+        kernels (C ABI dyt_adapter_fwd; bf16 MFMA by default, ``precision=0`` = the exact-fp32 kernels).  Forward only -- inside
+        a VisionTransformer the adapter runs in the fused path with its backward; ``keep_mask`` [rows, r] (uint8) injects the
+        dropout draw, otherwise Philox(``seed``) in training mode."""
+        if not x.is_cuda:
+            raise DyTError("Adapter runs on the HIP device only")
+        shape = x.shape
+        xf = x.detach().float().reshape(-1, self.n_embd).contiguous()
+        res = None
+        if add_residual:
+            res = (x if residual is None else residual).detach().float().reshape(-1, self.n_embd).contiguous()
+        out = torch.empty_like(xf)
+        drop_p = float(self.dropout) if self.training else 0.0
+        km = None if keep_mask is None else keep_mask.to(torch.uint8).reshape(xf.shape[0], self.down_size).contiguous()
+        w = [t.detach().float().contiguous() for t in (self.down_proj.weight, self.down_proj.bias, self.up_proj.weight, self.up_proj.bias)]
+        check(lib().dyt_adapter_fwd(ptr(xf), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]),
+                                    ptr(res), ptr(out), xf.shape[0], self.down_size, float(self.scale), drop_p, ptr(km),
+                                    ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), int(precision), stream_ptr()))
+        return out.reshape(shape)

@@ -13,7 +13,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from _lib import DyTError, key_to_param, is_trainable_param
+from _lib import DyTError, OPT_COUNT_FLOPS_TOKENS, key_to_param, is_trainable_param
 from runtime import DyTEngine, parse_precision
 from .dynamic_adapter import Adapter, TokenSelect, _LinearParams
 
@@ -92,8 +92,45 @@ class Block(nn.Module):
         self.count_flops = None
         self.token_select_num = None
 
-    def forward(self, x, complete_model=False):
-        raise DyTError("Block is evaluated inside VisionTransformer's fused HIP path; call the model")
+        self.precision = "bf16"     # arithmetic mode of a stand-alone call (inside a model the model's precision applies)
+        self._engine = None
+        self._engine_state = None
+
+    def _block_engine(self, batch, device):
+        """A depth-1 libdyt_hip context holding this block's parameters (stand-alone use only)."""
+        eng = self._engine
+        if eng is None or eng.device != device or batch > eng.cfg.max_batch or eng.cfg.precision != parse_precision(self.precision):
+            self._engine = None
+            eng = DyTEngine(1, self.adaptmlp.down_size, self.adaptmlp.scale, device, precision=self.precision, max_batch=batch, depth=1,
+                            slots=1, adapter_dropout=self.adaptmlp.dropout, tau=self.mlp_token_select.tau,
+                            threshold=self.mlp_token_select.threshold)
+            self._engine, self._engine_state = eng, None
+        state = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if state != self._engine_state:
+            for n, p in self.named_parameters():
+                eng.set_param("blocks.0." + n, p.data)
+            self._engine_state = state
+        return eng
+
+    def forward(self, x, complete_model=False, gumbel=None, keep_mask=None, seed=0):
+        """Reference :144-165 on a token tensor x [B,197,768] (how block_flops_dict.py:36-46 calls a bare Block), through the
+        product's kernels in a depth-1 context: returns (x_out, dict(sub_token_select [B,197,1], token_logits [B,196,1])).
+        ``count_flops`` / ``token_select_num`` select the FLOP-probe variant (:167-185).  Forward only: training a block happens
+        inside the VisionTransformer's fused step.  ``gumbel=(g1, g2)`` ([B,196] each) / ``keep_mask`` ([B*197, r]) inject the
+        training-mode draws."""
+        if not x.is_cuda:
+            raise DyTError("Block runs on the HIP device only")
+        B = x.shape[0]
+        eng = self._block_engine(B, x.device)
+        eng.set_option(OPT_COUNT_FLOPS_TOKENS, int(self.token_select_num) if (self.count_flops and self.token_select_num) else 0)
+        g1 = g2 = None
+        if self.training and gumbel is not None:
+            g1, g2 = (t.to(x.device).float().reshape(1, B, 196).contiguous() for t in gumbel)
+        km = None if keep_mask is None else keep_mask.to(x.device).to(torch.uint8).reshape(1, B * 197, -1).contiguous()
+        out, ts, tl = eng.forward_tokens(x.detach().float().contiguous(), training=self.training, complete_model=complete_model,
+                                         masked_dense=True, g1=g1, g2=g2, keep_mask=km, seed=seed)
+        sel = torch.cat([ts.new_ones(B, 1, 1), ts[:, 0].unsqueeze(-1)], dim=1)
+        return out, dict(sub_token_select=sel, token_logits=tl[:, 0].unsqueeze(-1))
 
 
 class _DyTFunction(torch.autograd.Function):

@@ -9,7 +9,8 @@ import ctypes
 
 import torch
 
-from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TRAINING, PREC_BF16, PREC_FP32,
+from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
+                  F_TRAINING, PREC_BF16, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
@@ -49,6 +50,7 @@ class DyTEngine:
         self.losses = torch.zeros(8, device=self.device, dtype=torch.float32)
         self._graphs = {}          # captured hipGraphs of the step, keyed by its static arguments
         self._comm_stream = None   # side stream of the early (upper-half) gradient all-reduce
+        self._rccl_comm = None     # ncclComm_t of dyt_allreduce_grads (created on first use)
         self.generation = [0] * int(slots)   # bumped by every saving forward into a slot (stale-backward detection)
         self.depth, self.num_classes, self.ffn_num = int(depth), int(num_classes), int(ffn_num)
 
@@ -111,6 +113,21 @@ class DyTEngine:
             check(self.L.dyt_forward(self.h, slot, ptr(images), B, flags, ptr(tr), ptr(g1), ptr(g2), ptr(keep_mask),
                                      ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(logits), ptr(ts), ptr(tl), stream_ptr()))
         return logits, ts, tl
+
+    def forward_tokens(self, tokens, training=False, complete_model=False, masked_dense=False, g1=None, g2=None, keep_mask=None, seed=0):
+        """The block stack alone on a residual-stream tensor [B,197,768] (no patch embedding, no final norm / head): what a bare
+        reference Block computes when it is called on tokens (vision_transformer_IN21K.py:144-165, block_flops_dict.py:36-46).
+        Forward only.  Returns (tokens_out [B,197,768], token_select [B,depth,196], token_logits [B,depth,196])."""
+        B = tokens.shape[0]
+        flags = ((F_TRAINING if training else 0) | (F_COMPLETE if complete_model else 0) | (F_MASKED_DENSE if masked_dense else 0) |
+                 F_GATE_ALWAYS | F_TOKENS_IN | F_TOKENS_OUT)
+        out = torch.empty(B, NT, DIM, device=self.device, dtype=torch.float32)
+        ts = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32)
+        tl = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.L.dyt_forward(self.h, 0, ptr(tokens), B, flags, ptr(self.flat), ptr(g1), ptr(g2), ptr(keep_mask),
+                                     ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(out), ptr(ts), ptr(tl), stream_ptr()))
+        return out, ts, tl
 
     def backward(self, slot, dlogits, grad, dtoken_select=None, dtok=None, dtoken_logits=None):
         with torch.cuda.device(self.device):
@@ -226,6 +243,16 @@ class DyTEngine:
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(self.device)
         return self._comm_stream
+
+    def allreduce_native(self, overlap=True):
+        """dyt_allreduce_grads: SUM of the flat gradient over the ranks on the library's own RCCL communicator (created on
+        first use over the default torch.distributed group); the upper part on the communication stream when `overlap`."""
+        if self._rccl_comm is None:
+            from _lib import rccl_comm_create
+            self._rccl_comm = rccl_comm_create(self.device)
+        cs = ctypes.c_void_p(self.comm_stream().cuda_stream) if overlap else None
+        with torch.cuda.device(self.device):
+            check(self.L.dyt_allreduce_grads(self.h, self._rccl_comm, ptr(self.grad), cs, stream_ptr()))
 
     def stream_wait_grads(self, stream, part=0):
         """Make `stream` wait on the device until the early part of the last step's gradient is final."""

@@ -51,6 +51,9 @@ extern "C" {
 #define DYT_F_DEVICE_SEED 64   /* the Philox seed is read from the context's device-side seed word (dyt_seed) instead of the
                                   `seed` argument, and dyt_step_fwd_bwd advances that word by one when it is done: a step
                                   captured into a hipGraph then draws fresh Gumbel noise / dropout masks at every replay */
+#define DYT_F_TOKENS_IN 128    /* dyt_forward: `images` is the residual stream [B,197,768] itself (no patch embedding) -- stand-alone
+                                * Block.forward on a token tensor, as block_flops_dict.py:36-46 calls it; forward only */
+#define DYT_F_TOKENS_OUT 256   /* dyt_forward: `logits` receives the block stack's output tokens [B,197,768] (no final norm / head) */
 #define DYT_F_GATE_ALWAYS 16   /* also evaluate the token dispatcher in a COMPLETE pass (the reference does,
                                   and discards it, :150-152) so token_select/token_logits are returned */
 
@@ -222,6 +225,14 @@ int dyt_seed(dyt_ctx* ctx, uint64_t seed, void* stream);
 int dyt_grad_part(const dyt_ctx* ctx, int part, int64_t* offset, int64_t* numel);
 int dyt_stream_wait_grads(dyt_ctx* ctx, int part, void* stream);
 
+/* The gradient all-reduce itself, on RCCL (replaces DistributedDataParallel's bucket all-reduce, main_image.py:280-282; the
+ * collective call sites of SURVEY.md section 2.3): SUM of grad_flat over the ranks of `rccl_comm` (an ncclComm_t the binder created
+ * with ncclCommInitRank; one process per GPU).  With a `comm_stream` different from `stream`, part 0 is reduced on comm_stream as soon
+ * as the last dyt_step_fwd_bwd has it final (overlapping the backward of the lower blocks), part 1 on `stream`, and `stream` owns the
+ * whole buffer afterwards; comm_stream = NULL: one all-reduce on `stream`.  The 1/world factor is the caller's (dyt_adamw's
+ * grad_scale).  RCCL is bound at load time from the host process (no link-time dependency): DYT_ERR_STATE when it is absent. */
+int dyt_allreduce_grads(dyt_ctx* ctx, void* rccl_comm, float* grad_flat, void* comm_stream, void* stream);
+
 /* torch.nn.utils.clip_grad_norm_ over the flat gradient (engine_finetune.py:74 -> misc.py:262-266, --clip_grad):
  * norm_out[0] (device, may be NULL) = || pre_scale * grad ||_2 ; grad *= min(1, max_norm / (norm + 1e-6)).
  * pre_scale is the factor AdamW will apply (1/world after a SUM all-reduce, 1/accum_iter). */
@@ -233,6 +244,23 @@ int dyt_clip_grad_norm(dyt_ctx* ctx, float* grad, int64_t numel, float max_norm,
  *   any pointer may be NULL. */
 int dyt_debug_dispatch(dyt_ctx* ctx, int slot, int layer, int32_t* row_src, int32_t* dst_of, int32_t* counts, int32_t* total,
                        void* stream);
+
+/* ---- sub-module entry points: they allocate scratch and synchronise; not for the hot loop ---- */
+/* Adapter.forward (models/dynamic_adapter.py:120-140, layernorm option "none"): out[M,768] = [residual +] scale *
+ * (dropout_p(relu(x down_w^T + down_b)) up_w^T + up_b).  down_w [r,768], up_w [768,r] (nn.Linear layouts), r <= 64; residual may be
+ * NULL (add_residual=False); drop_p > 0: keep_mask [M,r] (uint8) if given, else Philox(seed). */
+int dyt_adapter_fwd(const float* x, const float* down_w, const float* down_b, const float* up_w, const float* up_b,
+                    const float* residual, float* out, int M, int r, float scale, float drop_p, const uint8_t* keep_mask,
+                    uint64_t seed, int precision, void* stream);
+/* its backward for dout [M,768] with the same draws: dx [M,768] (may be NULL); the parameter gradients are ACCUMULATED */
+int dyt_adapter_bwd(const float* x, const float* down_w, const float* down_b, const float* up_w, const float* dout, float* dx,
+                    float* d_down_w, float* d_down_b, float* d_up_w, float* d_up_b, int M, int r, float scale, float drop_p,
+                    const uint8_t* keep_mask, uint64_t seed, int precision, void* stream);
+/* the token-gathered MLP of block `layer` (frozen weights of the context; models/model_speed_test.py:297-305): for the tokens with a
+ * non-zero mask, x[t] += fc2(gelu(fc1(LN2(u[t])))); u, x fp32 [batch*197,768] (x in place), mask [batch*197]; total_out[1] (device,
+ * may be NULL) = number of gathered tokens */
+int dyt_mlp_gathered_fwd(dyt_ctx* ctx, int layer, const float* u, const float* mask, float* x, int batch, int32_t* total_out,
+                         void* stream);
 
 /* ---- single-kernel entry points (unit tests; also the building blocks of the sub-module API) ---- */
 /* nn.LayerNorm(768, eps=1e-6) forward; out fp32 */
@@ -265,6 +293,12 @@ int dyt_gemm_f32_raw(const float* a, const float* w, float* c, int M, int N, int
 int64_t dyt_wgrad_scratch_floats(int M);
 int dyt_wgrad_raw(const void* X, const void* Y, int M, int r, int precision, float* partial, float* out_w, float* out_xsum,
                   float* out_ysum, void* stream);
+/* measurement hooks of tools/probes/determinism_*.py: with DYT_DBG_CKSUM=1 in the environment every backward
+ * launch is followed by an integer checksum of its output; read back per pass (slot 0 student, 1 teacher) with its label; one
+ * launch's output can be kept whole (DYT_DBG_DUMP="<slot>:<label>") and copied out.  No effect unless the variables are set. */
+int dyt_debug_checksums(int slot, uint64_t* out, int max_n, int* n_out);
+const char* dyt_debug_checksum_label(int slot, int i);
+int64_t dyt_debug_dump_read(void* dst_device, int64_t max_bytes);
 /* phase timers of the instrumented GEMM variants: cycles {prologue, main loop, epilogue} summed over
  * workgroups and the workgroup count; synchronises; optionally resets */
 int dyt_debug_counters(uint64_t* out4, int reset);

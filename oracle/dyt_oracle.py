@@ -292,7 +292,7 @@ def step_grads_chunked(sd, x, y, g1, g2, keep_masks, chunk, frames=1, scale=0.1,
         sur = (a + b + k) / n + coef * tok["token_select"].sum()
         for acc, g in zip(grads, torch.autograd.grad(sur, [leaf[kk] for kk in names])):
             acc += g
-        ce_s += float(a); ce_t += float(b); klsum += float(k)
+        ce_s += float(a.detach()); ce_t += float(b.detach()); klsum += float(k.detach())
         outs_s.append(out_s.detach()); outs_t.append(out_t.detach()); sels.append(tok["token_select"].detach())
     tokl = token_loss_ratio * (mean - token_target_ratio) ** 2
     d = dict(base_loss=ce_s / n, token_loss=tokl, teacher_loss=ce_t / n, distillation_loss=klsum / n,

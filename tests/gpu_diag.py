@@ -49,6 +49,30 @@ def D_adamw(eng, lr, wd):
     eng.adamw(eng._t_m, eng._t_v, eng._t_step, lr, wd)
 
 
+# bf16-mode bounds on the relative L2 error of a gradient per tensor kind at the goldens' tiny batches (B = 2..4: fewer rows to
+# average over than the B=16 oracle test, whose table is in test_gpu_round2.BF16_GRAD_TOL) = ~2.5 x the values measured on MI355X
+BF16_GRAD_TOL_SMALL_B = {"mlp_token_select": 0.10, "adaptmlp.down_proj": 0.40, "adaptmlp.up_proj": 0.06, "head": 0.03, "pool": 0.05}
+
+
+def grad_kind(name):
+    for k in ("mlp_token_select", "adaptmlp.down_proj", "adaptmlp.up_proj", "head"):
+        if k in name:
+            return k
+    return "pool"   # video model: query_token / attentive_blocks.*
+
+
+def report_grads(tag, prec, items):
+    """items: (name, got, ref, floor).  fp32: one line, worst tensor vs 2e-3.  bf16: one line per tensor kind vs its own bound."""
+    worst = {}
+    for n, got, ref, floor in items:
+        e = float((got - ref).norm() / max(float(ref.norm()), floor))
+        k = grad_kind(n) if prec != "fp32" else "all"
+        if e > worst.get(k, (0.0, ""))[0]:
+            worst[k] = (e, n)
+    for k, (e, n) in sorted(worst.items()):
+        report("step grads (rel L2, worst %s tensor) %s" % (k, tag), e, 2e-3 if prec == "fp32" else BF16_GRAD_TOL_SMALL_B[k], n)
+
+
 def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
@@ -222,13 +246,7 @@ def t_step_golden():
                 _, gg, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="compact",
                                         token_target_ratio=float(g["meta_target_ratio"]))
                 gref = gg
-            worst, wname = 0.0, ""
-            for n, gr in gref.items():
-                got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
-                e = float((got - gr).norm() / (gr.norm() + 1e-20))
-                if e > worst:
-                    worst, wname = e, n
-            report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.25, wname)   # bf16, B=2: 0.05-0.17 depending on the kernels' summation order (the B=16 oracle test has the per-tensor table)
+            report_grads(tag, prec, [(n, eng.trainable_view(n, gr.shape, eng.grad).cpu(), gr, 1e-20) for n, gr in gref.items()])
             # AdamW on the flat buffer
             if prec == "fp32" and mode == "masked":
                 D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
@@ -272,14 +290,14 @@ def t_video_golden():
     g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
     stride = int(g["meta_row_stride"])
     for prec in ("fp32", "bf16"):
-        ltol = 1e-3 if prec == "fp32" else 0.25
+        ltol = 1e-3 if prec == "fp32" else 8e-3      # bf16 measured: 3e-4 .. 2e-3
         model, sd = build_video_model(g, prec, "masked")
         model.eval()
         with torch.no_grad():
             logits, aux = model(xc.cuda())
         report("video eval logits %s" % prec, float(np.abs(logits.cpu().numpy() - g["eval_logits"]).max()), ltol)
         flips = int((aux["token_select"].cpu().numpy().astype(np.uint8) != g["eval_token_select"]).sum())
-        report("video eval masks %s" % prec, flips, 0 if prec == "fp32" else 400)
+        report("video eval masks %s" % prec, flips, 0 if prec == "fp32" else 30, "of %d" % aux["token_select"].numel())   # as the image model's eval fixture: ~13 of 9408
         for mode in ("masked", "compact"):
             model, sd = build_video_model(g, prec, mode)
             model.train()
@@ -295,7 +313,7 @@ def t_video_golden():
             report("step logits student %s" % tag, float(np.abs(ls.cpu().numpy() - g["logits_student"]).max()), ltol)
             report("step logits teacher %s" % tag, float(np.abs(lt.cpu().numpy() - g["logits_teacher"]).max()), ltol)
             flips = int((ts.cpu().numpy().astype(np.uint8) != g["token_select"][..., 0]).sum())
-            report("step masks %s" % tag, flips, 0 if prec == "fp32" else 400, "of %d" % ts.numel())
+            report("step masks %s" % tag, flips, 0 if prec == "fp32" else 12, "of %d" % ts.numel())
             for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
                 ref = float(g["stat_" + k])
                 report("step %s %s" % (k, tag), abs(float(losses[i]) - ref), (1e-4 if prec == "fp32" else 0.05) * max(1.0, abs(ref)))
@@ -306,18 +324,15 @@ def t_video_golden():
                 _, gg, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="compact",
                                         token_target_ratio=float(g["meta_target_ratio"]), frames=frames)
                 gref = {n: (v, None) for n, v in gg.items()}
-            worst, wname = 0.0, ""
+            items = []
             for n, (gr, st) in gref.items():
-                shape = tuple(sd[n].shape)
-                got = eng.trainable_view(n, shape, eng.grad).cpu()
+                got = eng.trainable_view(n, tuple(sd[n].shape), eng.grad).cpu()
                 if st:
                     got = got[::st]
                 # norm_k.bias has an exactly-zero true gradient (a constant added to every key of a clip shifts all
                 # scores equally; the reference's own value is 1e-9 round-off), hence the absolute floor
-                e = float((got - gr).norm() / max(float(gr.norm()), 1e-4 if prec == "fp32" else 1e-3))
-                if e > worst:
-                    worst, wname = e, n
-            report("step grads (rel L2, worst tensor) %s" % tag, worst, 2e-3 if prec == "fp32" else 0.2, wname)
+                items.append((n, got, gr, 1e-4 if prec == "fp32" else 1e-3))
+            report_grads(tag, prec, items)
             if prec == "fp32" and mode == "masked":
                 D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
                 worst = 0.0

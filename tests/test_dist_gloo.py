@@ -121,3 +121,123 @@ def test_single_process_is_a_noop():
     assert E.allreduce_grads(Eng()) == 1.0 and E.get_world_size() == 1
     t = torch.arange(4.)
     assert E.all_gather_concat(t) is t
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the loops' own collectives: train_one_epoch's end-of-epoch statistics all-reduce (reference engine_finetune.py:104,
+# misc.py:42-53) and evaluate's three ragged all_gather_concat calls (reference :245-248), world 2 on CPU.  The device step /
+# the model forward are stand-ins (there is no CPU path of the HIP library); everything between them is the product's host code.
+# ------------------------------------------------------------------------------------------------------------------
+def _eval_data(rank):
+    """rank r holds 2 + r batches of different sizes: 5 + 3 images (rank 0), 4 + 2 + 1 (rank 1); 6 classes"""
+    g = torch.Generator().manual_seed(40 + rank)
+    sizes = [5, 3] if rank == 0 else [4, 2, 1]
+    return [(torch.randn(n, 3, 8, 8, generator=g), torch.randint(0, 6, (n,), generator=g)) for n in sizes]
+
+
+class _EvalModel(torch.nn.Module):
+    """deterministic stand-in for the DyT model: logits and a {0,1} token mask derived from the pixels"""
+
+    def forward(self, x):
+        f = x.flatten(1)
+        logits = torch.stack([f[:, i::6].sum(1) for i in range(6)], dim=1)
+        ts = (f[:, : 12 * 196 % f.shape[1] or f.shape[1]].mean(1, keepdim=True) > 0).float().reshape(-1, 1, 1, 1).expand(-1, 12, 196, 1)
+        return logits, {"token_select": ts.contiguous()}
+
+
+def _loop_worker(rank, world, port, q):
+    import types
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import engine_finetune as E
+    out = {}
+    # ---- evaluate(): ragged shards -> gathered predictions / targets / masks -> one accuracy on every rank ----
+    for metric in ("accuracy", "mean_per_class_acc"):
+        st = E.evaluate(_eval_data(rank), _EvalModel(), torch.device("cpu"), None, None, None,
+                        types.SimpleNamespace(metric=metric, nb_classes=6))
+        out["eval_" + metric] = st
+    # ---- train_one_epoch(): per-rank loss statistics -> mean over the ranks at the end of the epoch ----
+    class Head(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.zeros(3, 4))
+            self.bias = torch.nn.Parameter(torch.zeros(3))
+
+    class Model(torch.nn.Module):
+        train_mode = "masked"
+
+        def __init__(self):
+            super().__init__()
+            self.head = Head()
+            self._engine = None
+
+    class CpuEngine:
+        n_train, device = 15, torch.device("cpu")
+
+        def __init__(self):
+            self.flat, self.grad = torch.zeros(15), torch.zeros(15)
+
+        def trainable_slice(self, name):
+            return (0, 12) if name == "head.weight" else (12, 3)
+
+    model = Model()
+    model._engine = CpuEngine()
+    opt = E.FusedAdamW(model, lr=1e-2)
+    calls = []
+
+    def fake_step(model, samples, targets, optimizer, criterion=None, losses_out=None, seed=0, **kw):
+        calls.append((int(seed), kw["accumulate"], kw["update"]))
+        it = len(calls)                                                    # loss components that depend on rank and iteration
+        losses_out.copy_(torch.tensor([10.0 * rank + it, 1.0 + rank, 2.0, 3.0 * (rank + 1), 0.5, 0.7 - 0.1 * rank, 0.0, 0.0]))
+        return losses_out
+    E.train_step = fake_step
+    from models.losses import AdaLoss
+    crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0)
+    args = types.SimpleNamespace(accum_iter=2, lr=1e-2, min_lr=0.0, warmup_epochs=0, epochs=4)
+    loader = [(torch.zeros(2, 3, 4, 4), torch.zeros(2, dtype=torch.int64)) for _ in range(4)]
+    stats = E.train_one_epoch(model, crit, loader, opt, torch.device("cpu"), 1, None, 0, None, None, args=args)
+    out["stats"] = stats
+    out["calls"] = calls
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loop_collectives_world2():
+    import socket
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
+    from util.metrics import accuracy, mean_per_class_accuracy
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # evaluate: what one process computes on the concatenation of both shards (rank order), on both ranks
+    data = _eval_data(0) + _eval_data(1)
+    x = torch.cat([b[0] for b in data]); y = torch.cat([b[1] for b in data])
+    logits, aux = _EvalModel()(x)
+    a1, a5 = accuracy(logits, y, topk=(1, 5))
+    for r in (0, 1):
+        st = res[r]["eval_accuracy"]
+        assert abs(st["metric"] - float(a1)) < 1e-6 and abs(st["acc5"] - float(a5)) < 1e-6, (r, st)
+        assert abs(st["keep_ratio"] - float(aux["token_select"].mean())) < 1e-6
+        assert abs(res[r]["eval_mean_per_class_acc"]["metric"] - float(mean_per_class_accuracy(logits, y, 6))) < 1e-5
+    # train_one_epoch: per-rank means over 4 iterations, then the mean over the two ranks (reference :104)
+    want = {"loss": (sum(range(1, 5)) / 4 + (10 + sum(range(1, 5)) / 4)) / 2, "base_loss": 1.5, "token_loss": 2.0,
+            "teacher_loss": 4.5, "distillation_loss": 0.5}
+    for r in (0, 1):
+        for k, v in want.items():
+            assert abs(res[r]["stats"][k] - v) < 1e-9, (r, k, res[r]["stats"][k], v)
+        assert [c[1:] for c in res[r]["calls"]] == [(False, False), (True, True), (False, False), (True, True)]   # accum_iter = 2
+        assert len({c[0] for c in res[r]["calls"]}) == 4                                                            # a fresh seed per step

@@ -450,6 +450,38 @@ def test_rccl_one_rank_path_equals_no_dist(rccl_one_rank):
     _same_training(with_dist, without)
 
 
+def test_rccl_torch_collective_path_equals_native(rccl_one_rank, monkeypatch):
+    """The two implementations of the gradient all-reduce -- dyt_allreduce_grads (RCCL called by the library on its own
+    communicator, the default) and torch.distributed.all_reduce on the same two buffer parts (DYT_NATIVE_RCCL=0) -- give the
+    same training, bit for bit."""
+    native = _two_steps()
+    monkeypatch.setenv("DYT_NATIVE_RCCL", "0")
+    via_torch = _two_steps()
+    _same_training(native, via_torch)
+
+
+def test_allreduce_grads_abi_entry(rccl_one_rank):
+    """dyt_allreduce_grads through ctypes: a communicator made with ncclCommInitRank (id exchanged over the process group), both
+    call forms (one stream / upper part on a communication stream); with one rank the SUM leaves the buffer unchanged, and a
+    NULL communicator is an argument error, not a crash."""
+    import ctypes
+    import _lib
+    m, _ = _bench_model("bf16", "compact", 2, 0.85)
+    m.train()
+    x, y = synth.make_batch(2, 100, seed=62)
+    eng = m.engine(2, torch.device("cuda", 0))
+    eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, seed=5)
+    torch.cuda.synchronize()
+    before = eng.grad.clone()
+    assert float(before.abs().max()) > 0
+    eng.allreduce_native(overlap=True)
+    eng.allreduce_native(overlap=False)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grad, before)
+    rc = _lib.lib().dyt_allreduce_grads(eng.h, None, _lib.ptr(eng.grad), None, _lib.stream_ptr())
+    assert rc != 0 and b"null" in _lib.lib().dyt_last_error()
+
+
 def test_distributed_data_parallel_wrap(rccl_one_rank):
     """main_image.py:280-282: DistributedDataParallel(model) around the mirror, .module access, forward twice + loss.backward()
     through the autograd bridge: gradients equal the reference's."""
@@ -615,3 +647,140 @@ def test_inference_speed_harness_runs():
     assert thr > 100.0
     assert 0.6 < keep < 0.8
     assert 12.0 < gmacs < 17.6   # between an all-dropped and an all-kept MLP (block_flops_dict.py)
+
+
+def test_bench_multi_rank_code_path_with_one_rank():
+    """bench.py's N > 1 code path (RCCL process group, parameter broadcast, chunked all-reduce on the comm stream, barriers,
+    max-over-ranks timing) with one rank (DYT_BENCH_FORCE_DIST=1): the one JSON line carries the driver's contract keys, the
+    BASELINE.json metric / config, a roofline measured in the same run, and the step is the full-size one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DYT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-parity-mode"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["unit"] == "images/s" and d["higher_is_better"] is True
+    assert d["config"]["parallelism"] == "dp1" and d["config"]["per_gpu_batch"] == 128 and d["config"]["global_batch"] == 128
+    assert abs(d["config"]["keep_ratio_measured"] - 0.7) < 0.02
+    assert abs(d["value"] - 128 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    assert d["value"] > 2000.0, d["value"]          # the RCCL path must not serialise the two passes (GPU_MAX_HW_QUEUES, DESIGN.md 7)
+    assert d["step_mfma_frac_executed"] < d["step_mfma_frac"]
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_adapter_submodule_forward_and_backward_vs_oracle(precision):
+    """SURVEY 8b sub-module API: Adapter.forward(x, add_residual, residual) stand-alone (reference models/dynamic_adapter.py:
+    120-140) and the C-ABI pair dyt_adapter_fwd / dyt_adapter_bwd against the oracle's adapter + torch autograd: rank 8 and 64,
+    with and without residual, eval and training (injected dropout draw)."""
+    import ctypes
+    import _lib
+    from models.dynamic_adapter import Adapter
+    tol = 2e-5 if precision == 0 else 2e-2
+    for r, scale in ((8, 1.0), (64, 0.1)):
+        M = 3 * 197
+        g = torch.Generator().manual_seed(10 + r)
+        x = torch.randn(3, 197, 768, generator=g)
+        res = torch.randn(3, 197, 768, generator=g)
+        ad = Adapter(d_model=768, bottleneck=r, dropout=0.1, adapter_scalar=str(scale), adapter_layernorm_option="none")
+        with torch.no_grad():
+            ad.up_proj.weight.normal_(0, 0.05, generator=g); ad.up_proj.bias.normal_(0, 0.05, generator=g)
+            ad.down_proj.bias.normal_(0, 0.05, generator=g)
+        sd = {"blocks.0.adaptmlp." + n: p.detach().clone() for n, p in ad.named_parameters()}
+        keep = (torch.rand(M, r, generator=g) > 0.1)
+        ad = ad.cuda()
+        for training, km in ((False, None), (True, keep)):
+            ad.train(training)
+            want = O.adapter(sd, "blocks.0.", x, scale, km.reshape(3, 197, r) if km is not None else None, 0.1)
+            got = ad(x.cuda(), add_residual=False, keep_mask=None if km is None else km.cuda(), precision=precision).cpu()
+            assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max())), (r, training, float((got - want).abs().max()))
+            got = ad(x.cuda(), add_residual=True, residual=res.cuda(), keep_mask=None if km is None else km.cuda(), precision=precision).cpu()
+            assert float((got - (want + res)).abs().max()) < tol * max(1.0, float(want.abs().max()))
+            got = ad(x.cuda(), keep_mask=None if km is None else km.cuda(), precision=precision).cpu()             # residual defaults to x
+            assert float((got - (want + x)).abs().max()) < tol * max(1.0, float(want.abs().max()))
+        # backward entry (training mode, injected draw) vs autograd through the oracle
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xg = x.clone().requires_grad_(True)
+        dout = torch.randn(3, 197, 768, generator=g) * 0.01
+        (O.adapter(leaf, "blocks.0.", xg, scale, keep.reshape(3, 197, r), 0.1) * dout).sum().backward()
+        dev = lambda t: t.detach().float().contiguous().cuda()   # noqa: E731
+        bufs = [dev(x.reshape(M, 768)), dev(sd["blocks.0.adaptmlp.down_proj.weight"]), dev(sd["blocks.0.adaptmlp.down_proj.bias"]),
+                dev(sd["blocks.0.adaptmlp.up_proj.weight"]), dev(dout.reshape(M, 768))]
+        dx = torch.zeros(M, 768, device="cuda")
+        gdw, gdb, guw, gub = (torch.zeros(r, 768, device="cuda"), torch.zeros(r, device="cuda"), torch.zeros(768, r, device="cuda"),
+                              torch.zeros(768, device="cuda"))
+        km8 = keep.to(torch.uint8).contiguous().cuda()
+        _lib.check(_lib.lib().dyt_adapter_bwd(*[_lib.ptr(b) for b in bufs], _lib.ptr(dx), _lib.ptr(gdw), _lib.ptr(gdb), _lib.ptr(guw),
+                                              _lib.ptr(gub), M, r, scale, 0.1, _lib.ptr(km8), ctypes.c_uint64(0), precision, _lib.stream_ptr()))
+        gt = 1e-4 if precision == 0 else 0.06
+        for got, ref in ((dx.cpu().reshape(3, 197, 768), xg.grad), (gdw.cpu(), leaf["blocks.0.adaptmlp.down_proj.weight"].grad),
+                         (gdb.cpu(), leaf["blocks.0.adaptmlp.down_proj.bias"].grad), (guw.cpu(), leaf["blocks.0.adaptmlp.up_proj.weight"].grad),
+                         (gub.cpu(), leaf["blocks.0.adaptmlp.up_proj.bias"].grad)):
+            e = float((got - ref).norm() / (ref.norm() + 1e-20))
+            assert e < gt, (r, precision, tuple(ref.shape), e)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_block_submodule_forward_vs_oracle(precision):
+    """A bare Block called on a token tensor, as the reference's block_flops_dict.get_block_flops does
+    (block_flops_dict.py:36-46): train / eval / complete_model and the count_flops probe (vision_transformer_IN21K.py:144-185)
+    against oracle.block; plus the C-ABI entry dyt_mlp_gathered_fwd of the same block against the oracle's gather twin."""
+    import ctypes
+    import _lib
+    from models.vision_transformer_IN21K import Block
+    B, r, scale = 3, 16, 0.5
+    sd = synth.make_state_dict(5, r, seed=3, kind="test", gate_bias=0.2)
+    blk_sd = {k[len("blocks.2."):]: v for k, v in sd.items() if k.startswith("blocks.2.")}
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar=str(scale), ffn_num=r, d_model=768)
+    blk = Block(768, 12, mlp_ratio=4., qkv_bias=True, tuning_config=tuning, layer_id=2, select=True)
+    blk.load_state_dict(blk_sd, strict=True)
+    blk.precision = precision
+    blk = blk.cuda()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, 197, 768, generator=g)
+    g1, g2 = synth.make_noise(B, seed=18, passes=1)
+    g1, g2 = g1[0][2], g2[0][2]                                   # [B,196] each
+    keep = synth.make_dropout_masks(B, r, seed=19)[0][2]            # [B*197, r]
+    osd = {"blocks.0." + k: v for k, v in blk_sd.items()}
+    ltol = 2e-4 if precision == "fp32" else 0.05
+    for training, complete in ((False, False), (True, False), (True, True)):
+        blk.train(training)
+        a = g1.reshape(B, 196, 1) if training else 0.0
+        b = g2.reshape(B, 196, 1) if training else 0.0
+        want, sel, logits = O.block(osd, 0, x, a, b, keep.reshape(B, 197, r) if training else None, scale, complete, training, "masked")
+        got, aux = blk(x.cuda(), complete_model=complete, gumbel=(g1, g2) if training else None, keep_mask=keep if training else None)
+        assert float((got.cpu() - want).abs().max()) < ltol * max(1.0, float(want.abs().max())), (training, complete)
+        assert float((aux["token_logits"].cpu() - logits).abs().max()) < ltol
+        flips = int((aux["sub_token_select"].cpu() != sel.detach()).sum())
+        assert flips <= (0 if precision == "fp32" else 6), flips
+        assert tuple(aux["sub_token_select"].shape) == (B, 197, 1) and tuple(aux["token_logits"].shape) == (B, 196, 1)
+    blk.eval()
+    blk.count_flops, blk.token_select_num = True, 57               # what get_block_flops sets with apply(setattr)
+    want, _, _ = O.block(osd, 0, x, 0.0, 0.0, None, scale, False, False, "masked", count_flops_tokens=57)
+    got, _ = blk(x.cuda())
+    assert float((got.cpu() - want).abs().max()) < ltol * max(1.0, float(want.abs().max()))
+    # the gathered MLP alone (C ABI): out = u + scatter(mlp(LN2(gather(u, mask))))
+    eng = blk._block_engine(B, torch.device("cuda", 0))
+    mask = (torch.rand(B, 197, generator=g) > 0.4).float()
+    mask[:, 0] = 1.0
+    u = x.reshape(B * 197, 768).contiguous().cuda()
+    out = u.clone()
+    total = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().dyt_mlp_gathered_fwd(eng.h, 0, _lib.ptr(u), _lib.ptr(mask.reshape(-1).contiguous().cuda()), _lib.ptr(out), B,
+                                                _lib.ptr(total), _lib.stream_ptr()))
+    assert int(total.item()) == int(mask.sum())
+    h = O.mlp(osd, "blocks.0.", O.layer_norm(x, osd["blocks.0.norm2.weight"], osd["blocks.0.norm2.bias"])) * mask.unsqueeze(-1)
+    want = (x + h).reshape(B * 197, 768)
+    assert float((out.cpu() - want).abs().max()) < ltol * max(1.0, float(want.abs().max()))
