@@ -15,10 +15,12 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
+LIB_PATH_F16 = os.path.join(_HERE, "libdyt_hip_f16.so")   # the same sources with IEEE-half operands (precision "fp16")
 
 PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP16 = 2   # host-side name only: libdyt_hip_f16.so with its 16-bit mode (DYT_PREC_BF16 = 1 inside that library)
 F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED, F_TOKENS_IN, F_TOKENS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
-OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS = 1, 2, 3, 4
+OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2 = 1, 2, 3, 4, 5
 
 # enum dyt_param (include/dyt_hip.h)
 (P_CLS, P_POS, P_PE_W, P_PE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_PROJ_W, P_PROJ_B, P_LN2_W, P_LN2_B,
@@ -88,6 +90,7 @@ _vp, _i, _i64, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.
 SYMBOLS = {
     "dyt_last_error": (ctypes.c_char_p, []),
     "dyt_version": (_i, []),
+    "dyt_operand_type": (_i, []),
     "dyt_ctx_create": (_i, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
     "dyt_ctx_destroy": (_i, [_vp]),
     "dyt_ctx_bytes": (_i, [_vp, ctypes.POINTER(_i64)]),
@@ -128,9 +131,26 @@ SYMBOLS = {
 }
 
 
-def lib():
-    """Load libdyt_hip.so (once).  Raises DyTError when it is absent -- there is no CPU path."""
-    global _lib
+_lib16 = None
+
+
+def lib(fp16=False):
+    """Load libdyt_hip.so (once; fp16=True: libdyt_hip_f16.so).  Raises DyTError when it is absent -- there is no CPU path."""
+    global _lib, _lib16
+    if fp16:
+        if _lib16 is None:
+            lib()   # HIP runtime / RCCL promoted to the global scope, error text shared
+            if not os.path.exists(LIB_PATH_F16):
+                raise DyTError("%s not found: build it with `make -C dynamic-tuning_amd/csrc`" % LIB_PATH_F16)
+            L = ctypes.CDLL(LIB_PATH_F16)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            if L.dyt_operand_type() != 1:
+                raise DyTError("%s was not built with -DDYT_FP16" % LIB_PATH_F16)
+            _lib16 = L
+        return _lib16
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise DyTError("%s not found: build it with `make -C dynamic-tuning_amd/csrc` "
@@ -155,9 +175,12 @@ def lib():
     return _lib
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise DyTError("libdyt_hip: %s (code %d)" % (lib().dyt_last_error().decode(), rc))
+        msg = (L or lib()).dyt_last_error().decode()
+        if not msg and _lib16 is not None and L is None:
+            msg = _lib16.dyt_last_error().decode()
+        raise DyTError("libdyt_hip: %s (code %d)" % (msg, rc))
 
 
 def ptr(t):

@@ -62,7 +62,6 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ src, int ld,
         if (trimg) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                 bf16x2 pv = {a[i], b[i]};
                 *reinterpret_cast<bf16x2*>(trimg + (c * 8 + i) * TLD + r0) = pv;
             }
@@ -94,7 +93,6 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, bf16* rowimg, bf
         if (trimg) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                 bf16x2 pv = {a[i], b[i]};
                 *reinterpret_cast<bf16x2*>(trimg + (c * 8 + i) * TLD + r0) = pv;
             }
@@ -102,7 +100,7 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, bf16* rowimg, bf
     }
 }
 
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) DYT_MFMA_32x32x16((a), (b), (c))
 
 // ------------------------------------------------------------------------------------------
 // forward, bf16

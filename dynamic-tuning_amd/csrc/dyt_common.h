@@ -41,9 +41,23 @@ constexpr int DM = 3072;      // MLP hidden
 constexpr int RP = 64;        // adapter bottleneck padded to one MFMA N-tile
 constexpr float LN_EPS = 1e-6f;
 
+// The 16-bit operand type of the "fast" kernels.  The library is built twice from the same sources:
+//   libdyt_hip.so      bfloat16 operands (8 exponent / 7 mantissa bits)          -- precision "bf16"
+//   libdyt_hip_f16.so  IEEE half operands (-DDYT_FP16: 5 / 10 bits; the reference's own GPU dtype, it trains under fp16 autocast,
+//                      engine_finetune.py:47) with the gradient stream scaled by 2^k wherever it is held in 16 bits -- precision "fp16"
+// `bf16` / `bf16x8` below are the names of that operand type in BOTH builds (kernel names keep "bf16" too).
+#ifdef DYT_FP16
+typedef _Float16 bf16;
+#define DYT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define DYT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#else
 typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define DYT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define DYT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -137,9 +151,9 @@ __device__ __forceinline__ float normal_cdf_fast(float x) {
     return x >= 0.f ? 1.0f - half : half;
 }
 template <class AT> __device__ __forceinline__ float gelu_fwd(float x) { return gelu_erf(x); }
-template <> __device__ __forceinline__ float gelu_fwd<__bf16>(float x) { return x * normal_cdf_fast(x); }
+template <> __device__ __forceinline__ float gelu_fwd<bf16>(float x) { return x * normal_cdf_fast(x); }
 template <class AT> __device__ __forceinline__ float gelu_bwd(float x) { return gelu_erf_grad(x); }
-template <> __device__ __forceinline__ float gelu_bwd<__bf16>(float x) {
+template <> __device__ __forceinline__ float gelu_bwd<bf16>(float x) {
     return fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), normal_cdf_fast(x));
 }
 // GELU and its derivative in one go (they share Phi(x)): h = x Phi(x), gp = Phi(x) + x pdf(x).
@@ -150,7 +164,7 @@ template <class AT> __device__ __forceinline__ void gelu_both(float x, float& h,
     h = x * phi;
     gp = phi + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
-template <> __device__ __forceinline__ void gelu_both<__bf16>(float x, float& h, float& gp) {
+template <> __device__ __forceinline__ void gelu_both<bf16>(float x, float& h, float& gp) {
     // Both outputs need pdf(x); Abramowitz-Stegun 26.2.17 builds Phi from that same pdf:
     //   Phi(a) = 1 - pdf(a) t (b1 + b2 t + ... + b5 t^4),  t = 1 / (1 + 0.2316419 a),  a >= 0   (|err| < 7.5e-8)
     // -> one v_exp, one v_rcp, 9 fma/mul; checked against scipy.erf in fp32: |Phi err| 2.8e-7, |h err| 4.2e-7,
@@ -170,7 +184,7 @@ template <> __device__ __forceinline__ void gelu_both<__bf16>(float x, float& h,
 }
 // the same for two elements at once, written on 2-vectors so that the polynomial, the products and the final
 // h / gelu' run as packed-fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32: two elements per issue slot); only the two
-// v_rcp / v_exp and the sign select stay scalar.  Bit-identical to gelu_both<__bf16> per element.
+// v_rcp / v_exp and the sign select stay scalar.  Bit-identical to gelu_both<bf16> per element.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_both_x2(f32x2 x, f32x2& h, f32x2& gp) {
     const f32x2 a = __builtin_elementwise_abs(x);

@@ -201,7 +201,7 @@ struct EpiGeluBwd {
 };
 
 struct EpiStoreF32 {
-    float* out; int ld; int accumulate;
+    float* out; int ld; int accumulate; float alpha;   // out (+)= alpha * acc
     typedef NoCtx Col; typedef Raw4<float> Pre;
     __device__ __forceinline__ Col col_init(int) const { return {}; }
     __device__ __forceinline__ Pre pre(int row, int col) const {
@@ -211,7 +211,7 @@ struct EpiStoreF32 {
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre& p) const {
         float r[4];
         p.get(r);
-        store4(out + (size_t)row * ld + col, r[0] + a[0], r[1] + a[1], r[2] + a[2], r[3] + a[3]);
+        store4(out + (size_t)row * ld + col, r[0] + alpha * a[0], r[1] + alpha * a[1], r[2] + alpha * a[2], r[3] + alpha * a[3]);
     }
 };
 
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
         static_assert(TM == 8 && TN == 4 && NDMA == 8, "interleave pattern written for the 128x64 wave tile, 8 DMA pieces");
 #define DYT_MMA(FW, FA)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)            \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[j], FA[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = DYT_MFMA_16x16x32(FW[j], FA[i], acc[i][j]);
 #define DYT_SG3R __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #define DYT_SG2R __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #define DYT_SGB /* per 8 MFMAs: M2 R M2 R M1 D M2 R M1 D */                                            \
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = DYT_MFMA_16x16x32(wf[ks][j], af[ks][i], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -778,7 +778,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_GELU_BWD:
             if (a.row_map) return run<AT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
             return run<AT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
-        case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate}, s);
+        case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
         case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
             return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
@@ -829,7 +829,7 @@ int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int
     GemmArgs a; a.A = A; a.W = W; a.M = M; a.N = N; a.K = K;
     float* c = static_cast<float*>(C);
     if (variant == 1) return run_f32(a, EpiAdUp<false>{nullptr, c + (size_t)M * N, c, 0.1f, nullptr}, s);
-    if (variant == 2) return run_f32(a, EpiStoreF32{c, N, 1}, s);
+    if (variant == 2) return run_f32(a, EpiStoreF32{c, N, 1, 1.0f}, s);
     return run_f32(a, EpiStoreAT<float>{c, N}, s);
 }
 

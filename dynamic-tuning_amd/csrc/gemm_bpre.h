@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
 
 #define DYT_P_MMA(FW, FA)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)            \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[j], FA[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = DYT_MFMA_16x16x32(FW[j], FA[i], acc[i][j]);
 #define DYT_P_M2R __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
 #define DYT_P_M2V __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); __builtin_amdgcn_sched_group_barrier(0x010, 1, 2);
 #define DYT_P_M2 __builtin_amdgcn_sched_group_barrier(0x008, 2, 2);

@@ -82,7 +82,7 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx_out, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  hipStream_t s);
+                  float gs, hipStream_t s);   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
 
 struct GateArgs {
     const float* u;          // [B*197,768] residual stream after attention
@@ -170,6 +170,7 @@ struct BwdPrepArgs {
     void* dH;               // [K,768] AT (null when dense and unmasked: g_at / g is used)
     float* dmask;           // [M] (zero-filled by the kernel for rows it does not own)
     int M;
+    float gs = 1.0f;        // factor the gradient carries wherever it is held in the 16-bit operand type (fp16 build: 2^12)
 };
 int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s);
 
@@ -197,6 +198,7 @@ struct TokBwdArgs {
     float* partial;            // [nblocks][769] dwg / dbg partials
     int M;
     int write_du;              // 0 for block 0 (du itself is not needed)
+    float gs = 1.0f, inv_gs = 1.0f;   // 16-bit gradient operands (dA2, dad in; du_at out) carry the factor gs (fp16 build)
     const void* dad = nullptr;     // [M,768] AT adapter dgrad to add to du (null: already accumulated into du)
     const float* g_cls = nullptr;  // last block: incoming gradient exists for the cls rows only ([B,768]);
                                    // du/dA2 are then read as (n == 0 ? g_cls[b] / dA2[b] : 0)
@@ -229,7 +231,7 @@ int launch_pool_q_fwd(const float* query, const float* nqw, const float* nqb, co
 int launch_pool_attn_fwd(int precision, const float* qs, const void* K, const void* V, float* P, float* o, int clips,
                          int NK, hipStream_t s);
 int launch_pool_attn_bwd(int precision, const float* qs, const void* K, const void* V, const float* P, const float* dO,
-                         void* dK, void* dV, float* dq_part, int clips, int NK, hipStream_t s);
+                         void* dK, void* dV, float* dq_part, int clips, int NK, float gs, hipStream_t s);
 int launch_pool_q_bwd(const float* dq_part, int clips, const float* qn, const float* qhat, const float* st_q, const float* Wq,
                       const float* nqw, float* gq, float* dqn, float* dWq, float* dqb, float* dnqw, float* dnqb,
                       float* dquery, hipStream_t s);
@@ -241,7 +243,7 @@ int launch_transpose_rows(int precision, const void* src, void* dst, int rows, i
                           hipStream_t s);
 int launch_pool_ln_bwd(int precision, const void* dxk, const void* dxv, const float* xf, const float2* st_kv, const float* kw,
                        const float* vw, const float* x, const float2* st_f, const float* nw, float* g, float* partial,
-                       int rows, int* nblocks_out, hipStream_t s);
+                       int rows, int* nblocks_out, float gs, hipStream_t s);
 
 inline size_t at_size(int precision) { return precision == 0 ? 4 : 2; }
 

@@ -164,6 +164,8 @@ struct dyt_ctx {
     hipEvent_t ev_half_s = nullptr, ev_half_t = nullptr, ev_upper = nullptr, ev_comm = nullptr;
     hipStream_t aux = nullptr;       // sums the upper part of the two passes' gradient buffers while the backward goes on
     bool upper_recorded = false;
+    float gs = 1.0f;           // factor the gradient carries wherever it is held in the 16-bit operand type (fp16 build: 2^12, a
+                               // fixed loss scale confined to the library: fp32 streams and every returned gradient are unscaled)
     bool cls_tail = true;      // last block: MLP/adapter on the cls rows only (only they reach the head)
     // second stream: the student and the teacher pass of a step are independent and run concurrently
     hipStream_t side = nullptr;
@@ -336,6 +338,14 @@ static void trainable_layout(dyt_ctx* c) {
 
 extern "C" const char* dyt_last_error(void) { return g_err; }
 extern "C" int dyt_version(void) { return 1; }
+// 16-bit operand type of this build: 0 = bfloat16 (libdyt_hip.so), 1 = IEEE half (libdyt_hip_f16.so)
+extern "C" int dyt_operand_type(void) {
+#ifdef DYT_FP16
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
     if (!cfg || !out) { set_error("null argument"); return DYT_ERR_ARG; }
@@ -359,6 +369,9 @@ extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
     c->frames = cfg->frames > 1 ? cfg->frames : 1;
     if (c->frames > 1) c->cls_tail = false;   // every token of the last block reaches the pooling head
     c->at = at_size(c->prec);
+#ifdef DYT_FP16
+    if (c->prec != DYT_PREC_FP32) c->gs = 4096.0f;
+#endif
     trainable_layout(c);
     layout(c, true);
     c->arena_size = c->arena_used;
@@ -549,6 +562,10 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             return DYT_OK;
         case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0 && c->frames <= 1; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
+        case DYT_OPT_GRAD_SCALE_LOG2:   // 16-bit gradient operands carry 2^value (0 = none); fp32 mode ignores it
+            if (value < 0 || value > 24) { set_error("grad scale log2 %d out of range 0..24", value); return DYT_ERR_ARG; }
+            c->gs = c->prec == DYT_PREC_FP32 ? 1.0f : (float)(1u << value);
+            return DYT_OK;
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
             c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
@@ -672,12 +689,13 @@ static int pool_backward(dyt_ctx* c, Slot& S, const float* tr, const float* dlog
     const int Mp = (M + 63) / 64 * 64;
     PoolS& Q = S.pool;
     Transients& T = S.T;
+    const float gs = P == 0 ? 1.0f : c->gs, inv_gs = 1.0f / gs;   // 16-bit gradient operands carry gs (fp16 build)
     RUN(2, 0, launch_rows_linear_bwd(dlogits, Q.y, tr + c->off_hw, Q.dy, grad + c->off_hw, grad + c->off_hb, clips, C, D, s));
     RUN(2, 0, launch_rows_linear_bwd(Q.dy, Q.o, tr + c->off_pproj_w, Q.dO, grad + c->off_pproj_w, grad + c->off_pproj_b,
                                      clips, D, D, s));
     void* dK = T.dO; void* dV = T.dxn;   // [M,768] AT transients, free until the trunk backward starts
     RUN(1, 8.0 * clips * NH * (double)NK * HD,
-        launch_pool_attn_bwd(P, Q.qs, Q.Kp, Q.Vp, Q.P, Q.dO, dK, dV, Q.dq_part, clips, NK, s));
+        launch_pool_attn_bwd(P, Q.qs, Q.Kp, Q.Vp, Q.P, Q.dO, dK, dV, Q.dq_part, clips, NK, gs, s));
     RUN(2, 0, launch_pool_q_bwd(Q.dq_part, clips, Q.qn, Q.qhat, Q.st_q, tr + c->off_pq_w, tr + c->off_pnq_w, Q.gq, Q.dqn,
                                 grad + c->off_pq_w, grad + c->off_pq_bias, grad + c->off_pnq_w, grad + c->off_pnq_b,
                                 grad + c->off_pquery, s));
@@ -688,7 +706,7 @@ static int pool_backward(dyt_ctx* c, Slot& S, const float* tr, const float* dlog
     RUN(2, 0, launch_transpose_rows(P, Q.xk, Q.xkt, M, Mp, nullptr, s));
     RUN(2, 0, launch_transpose_rows(P, dV, Q.dVt, M, Mp, T.tok_partial, s));   // + column sums of dV -> v_bias
     RUN(2, 0, launch_transpose_rows(P, Q.xv, Q.xvt, M, Mp, nullptr, s));
-    RUN(2, 0, launch_reduce_partials(T.tok_partial, Mp / 64, D, grad + c->off_pv_bias, D, 1.0f, s));
+    RUN(2, 0, launch_reduce_partials(T.tok_partial, Mp / 64, D, grad + c->off_pv_bias, D, inv_gs, s));
     hipStream_t ws = nullptr;
     if (c->overlap && !c->prof) {
         if (!Q.wstream) {
@@ -701,11 +719,11 @@ static int pool_backward(dyt_ctx* c, Slot& S, const float* tr, const float* dlog
         DYT_HIP_CHECK(hipStreamWaitEvent(ws, Q.ev_wf, 0));
     }
     {
-        GemmArgs a; a.A = Q.dKt; a.W = Q.xkt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pk_w; a.accumulate = 1;
+        GemmArgs a; a.A = Q.dKt; a.W = Q.xkt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pk_w; a.accumulate = 1; a.scale = inv_gs;
         RUN_ON(ws, 0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
     }
     {
-        GemmArgs a; a.A = Q.dVt; a.W = Q.xvt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pv_w; a.accumulate = 1;
+        GemmArgs a; a.A = Q.dVt; a.W = Q.xvt; a.M = D; a.N = D; a.K = Mp; a.out_f32 = grad + c->off_pv_w; a.accumulate = 1; a.scale = inv_gs;
         RUN_ON(ws, 0, a.flops(), launch_gemm(P, EPI_STORE_F32, a, s));
     }
     if (ws) { DYT_HIP_CHECK(hipEventRecord(Q.ev_wj, ws)); Q.wpending = true; }   // joined at the end of backward_impl
@@ -720,7 +738,7 @@ static int pool_backward(dyt_ctx* c, Slot& S, const float* tr, const float* dlog
     }
     int nblk = 0;
     RUN(2, 0, launch_pool_ln_bwd(P, T.du_at, T.dA2, Q.xf, Q.st_kv, tr + c->off_pnk_w, tr + c->off_pnv_w, S.xs[c->cfg.depth],
-                                 Q.st_f, c->norm_w, T.g, T.wg_partial, M, &nblk, s));
+                                 Q.st_f, c->norm_w, T.g, T.wg_partial, M, &nblk, gs, s));
     RUN(2, 0, launch_reduce_partials(T.wg_partial, nblk, 4 * D, grad + c->off_pnk_w, 4 * D, 1.0f, s));
     return 0;
 }
@@ -1036,6 +1054,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const float scale = c->cfg.adapter_scale;
+    const float gs = P == 0 ? 1.0f : c->gs, inv_gs = 1.0f / gs;   // 16-bit gradient operands carry gs (dyt_ctx: gs)
     float* g = T.g;
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
@@ -1069,7 +1088,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.g = gin; a.h = (student && !tail) ? L.h : nullptr; a.dst_of = (dense || tail || h_by_token) ? nullptr : L.dst_of;
             a.row_mask = nullptr;
             a.g_at = g_at; a.dH = nullptr; a.dmask = (student && !tail) ? T.dmask : nullptr;
-            a.M = Mr;
+            a.M = Mr; a.gs = gs;
             ISO(64, RUN(2, 0, launch_bwd_prep(P, a, s)););
             if (g_at) CK("bwd_prep g_at", g_at, (size_t)Mr * D * c->at);
             if (a.dmask) CK("bwd_prep dmask", T.dmask, (size_t)Mr * 4);
@@ -1089,13 +1108,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             WgradArgs w[2];
             WgradArgs& a = w[0];
             a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = T.wg_partial;
-            a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale;       // up_proj.weight [768, r]
-            a.out_xsum = gbase + c->off_ub; a.alpha_x = scale;                      // up_proj.bias
+            a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale * inv_gs;       // up_proj.weight [768, r]  (X = g_at carries gs)
+            a.out_xsum = gbase + c->off_ub; a.alpha_x = scale * inv_gs;                      // up_proj.bias
             WgradArgs& b = w[1];
             b.X = tail ? S.ucls_at : L.u_at; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = T.wg_partial2;
-            b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = 1.0f;        // down_proj.weight [r, 768]
+            b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = inv_gs;      // down_proj.weight [r, 768]  (Y = ddz carries gs)
             b.out_xsum = nullptr; b.alpha_x = 0.f;
-            b.out_ysum = gbase + c->off_db; b.alpha_y = 1.0f;                       // down_proj.bias
+            b.out_ysum = gbase + c->off_db; b.alpha_y = inv_gs;                     // down_proj.bias
             ISO(32, RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s)););
             CK("wgrad up_w", gbase + c->off_uw, (size_t)D * r * 4); CK("wgrad down_w", gbase + c->off_dw, (size_t)D * r * 4);
         }
@@ -1123,7 +1142,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         if (!first) {
             GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
             if (dad_at) { a.out_at = T.dad; POISON(4, T.dad, (size_t)Mr * D * c->at); ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
-            else { a.out_f32 = gin; a.accumulate = 1; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
+            else { a.out_f32 = gin; a.accumulate = 1; a.scale = inv_gs; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
             if (dad_at) CK("ad_dgrad_down dad", T.dad, (size_t)Mr * D * c->at);   // g <- g + ddz Wdown
         }
 
@@ -1135,6 +1154,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dmask = tail ? nullptr : T.dmask;
             a.g_cls = tail ? S.gcls : nullptr;
             a.dad = dad_at ? T.dad : nullptr;
+            a.gs = gs; a.inv_gs = inv_gs;
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
@@ -1179,7 +1199,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             const LayerS& Ln = S.L[l - 1];
             if (g_at) POISON(256, g_at, (size_t)M * D * c->at);
             ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
-                                    (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, s)););
+                                    (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, gs, s)););
             CK("ln_bwd g", g, (size_t)M * D * 4);
             if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * c->at);
             if (student) CK("ln_bwd dmask", T.dmask, (size_t)M * 4);

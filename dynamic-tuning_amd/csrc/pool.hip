@@ -163,7 +163,7 @@ template <class AT>
 __global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const float* __restrict__ qs, const AT* __restrict__ K,
                                                             const AT* __restrict__ V, const float* __restrict__ P,
                                                             const float* __restrict__ dO, AT* __restrict__ dK,
-                                                            AT* __restrict__ dV, float* __restrict__ dq_part, int NK) {
+                                                            AT* __restrict__ dV, float* __restrict__ dq_part, int NK, float gs) {
     extern __shared__ float sm[];   // p[NK], dp[NK]
     __shared__ float red[4];
     __shared__ float qred[4][64];
@@ -189,23 +189,23 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const float* __restr
         const float ds = pj * (dp[j] - spd);
         const size_t o = base + (size_t)j * D + lane;
         dq = fmaf(ds, to_f32(K[o]), dq);
-        dK[o] = from_f32<AT>(ds * qd);
-        dV[o] = from_f32<AT>(pj * dod);
+        dK[o] = from_f32<AT>(ds * qd * gs);     // 16-bit gradient operands carry gs (fp16 build; 1 otherwise: exact)
+        dV[o] = from_f32<AT>(pj * dod * gs);
     }
     qred[wave][lane] = dq;
     __syncthreads();
     if (wave == 0) dq_part[(size_t)c * D + h * HD + lane] = qred[0][lane] + qred[1][lane] + qred[2][lane] + qred[3][lane];
 }
 int launch_pool_attn_bwd(int precision, const float* qs, const void* K, const void* V, const float* P, const float* dO,
-                         void* dK, void* dV, float* dq_part, int clips, int NK, hipStream_t s) {
+                         void* dK, void* dV, float* dq_part, int clips, int NK, float gs, hipStream_t s) {
     const size_t sm = (size_t)2 * NK * sizeof(float);
     if (sm > 60 * 1024) { set_error("pool_attn: %d keys per clip exceed the LDS budget", NK); return -1; }
     if (precision == 0)
         hipLaunchKernelGGL(pool_attn_bwd_kernel<float>, dim3(clips, NH), dim3(256), sm, s, qs, (const float*)K,
-                           (const float*)V, P, dO, (float*)dK, (float*)dV, dq_part, NK);
+                           (const float*)V, P, dO, (float*)dK, (float*)dV, dq_part, NK, 1.0f);
     else
         hipLaunchKernelGGL(pool_attn_bwd_kernel<bf16>, dim3(clips, NH), dim3(256), sm, s, qs, (const bf16*)K,
-                           (const bf16*)V, P, dO, (bf16*)dK, (bf16*)dV, dq_part, NK);
+                           (const bf16*)V, P, dO, (bf16*)dK, (bf16*)dV, dq_part, NK, gs);
     LAUNCH_CHECK();
     return 0;
 }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const AT* __restrict__
                                                           const float* __restrict__ kw, const float* __restrict__ vw,
                                                           const float* __restrict__ x, const float2* __restrict__ st_f,
                                                           const float* __restrict__ nw, float* __restrict__ g,
-                                                          float* __restrict__ partial, int rows) {
+                                                          float* __restrict__ partial, int rows, float inv_gs) {
     __shared__ float red[4][4 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Row12 gk, gv, wf, a_kx, a_k, a_vx, a_v;
@@ -403,6 +403,8 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const AT* __restrict__
         Row12 x0;
         x0.load(x + (size_t)row * D, lane);
         dk.landed(); dv.landed(); xr.landed(); x0.landed();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { dk.v[i] *= inv_gs; dv.v[i] *= inv_gs; }   // the 16-bit operands carried gs
         DYT_PIN4(s2.x, s2.y, sf.x, sf.y);   // the per-row statistics: the loads whose early consumption made ln_bwd irreproducible
         Row12 dy;
         float s1 = 0.f, sx = 0.f;
@@ -439,15 +441,15 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const AT* __restrict__
 }
 int launch_pool_ln_bwd(int precision, const void* dxk, const void* dxv, const float* xf, const float2* st_kv, const float* kw,
                        const float* vw, const float* x, const float2* st_f, const float* nw, float* g, float* partial,
-                       int rows, int* nblocks_out, hipStream_t s) {
+                       int rows, int* nblocks_out, float gs, hipStream_t s) {
     const int grid = (rows + POOL_ROWS_PER_BLOCK - 1) / POOL_ROWS_PER_BLOCK;
     if (nblocks_out) *nblocks_out = grid;
     if (precision == 0)
         hipLaunchKernelGGL(pool_ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dxk, (const float*)dxv, xf,
-                           st_kv, kw, vw, x, st_f, nw, g, partial, rows);
+                           st_kv, kw, vw, x, st_f, nw, g, partial, rows, 1.0f);
     else
         hipLaunchKernelGGL(pool_ln_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dxk, (const bf16*)dxv, xf,
-                           st_kv, kw, vw, x, st_f, nw, g, partial, rows);
+                           st_kv, kw, vw, x, st_f, nw, g, partial, rows, 1.0f / gs);
     LAUNCH_CHECK();
     return 0;
 }

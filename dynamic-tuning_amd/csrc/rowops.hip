@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
                                                      const float2* __restrict__ stats, const float* __restrict__ w,
                                                      const float* __restrict__ base, float* __restrict__ dx, int rows,
                                                      AT* __restrict__ g_at, const AT* __restrict__ h_next,
-                                                     const int* __restrict__ dst_of_next, float* __restrict__ dmask_next) {
+                                                     const int* __restrict__ dst_of_next, float* __restrict__ dmask_next,
+                                                     float gs, float inv_gs) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -87,12 +88,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     LN_SCALPIN3(st.x, st.y, r);
     if (base) LN_ROWPIN(br);
     ln_bwd_row(g, xr, wr, st);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) g.v[i] *= inv_gs;   // dy carried the 16-bit gradient factor (1 in the bf16 / fp32 builds: exact)
     if (base) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
     g.store(dx + (size_t)row * D, lane);
-    if (g_at) g.store(g_at + (size_t)row * D, lane);
+    if (g_at) {
+        Row12 gsc;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) gsc.v[i] = g.v[i] * gs;
+        gsc.store(g_at + (size_t)row * D, lane);
+    }
     if (dmask_next) {
         float dm = 0.f;
         if (h_next && r >= 0) {
@@ -120,13 +128,13 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 }
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  hipStream_t s) {
+                  float gs, hipStream_t s) {
     if (precision == 0)
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx,
-                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next);
+                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next, 1.0f, 1.0f);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)dy, x, stats, w, base, dx,
-                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next);
+                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next, gs, 1.0f / gs);
     LAUNCH_CHECK();
     return 0;
 }
@@ -704,7 +712,7 @@ template <class AT>
 __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ g, const AT* __restrict__ h,
                                                        const int* __restrict__ dst_of, const float* __restrict__ row_mask,
                                                        AT* __restrict__ g_at, AT* __restrict__ dH,
-                                                       float* __restrict__ dmask, int M) {
+                                                       float* __restrict__ dmask, int M, float gs) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
@@ -713,7 +721,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     int r = dst_of ? dst_of[t] : t;
     float mk = row_mask ? row_mask[t] : 1.0f;
     gr.landed(); DYT_PIN2(r, mk);
-    if (g_at) gr.store(g_at + (size_t)t * D, lane);
+    if (g_at) {
+        Row12 gsc;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) gsc.v[i] = gr.v[i] * gs;
+        gsc.store(g_at + (size_t)t * D, lane);
+    }
     float dm = 0.f;
     if (r >= 0) {
         if (h) {
@@ -727,6 +740,8 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
 #pragma unroll
                 for (int i = 0; i < 12; ++i) gr.v[i] *= mk;
             }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) gr.v[i] *= gs;
             gr.store(dH + (size_t)r * D, lane);
         }
     }
@@ -736,10 +751,10 @@ int launch_bwd_prep(int precision, const BwdPrepArgs& a, hipStream_t s) {
     const int grid = (a.M + 3) / 4;
     if (precision == 0)
         hipLaunchKernelGGL(bwd_prep_kernel<float>, dim3(grid), dim3(256), 0, s, a.g, (const float*)a.h, a.dst_of, a.row_mask,
-                           (float*)a.g_at, (float*)a.dH, a.dmask, a.M);
+                           (float*)a.g_at, (float*)a.dH, a.dmask, a.M, 1.0f);
     else
         hipLaunchKernelGGL(bwd_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, a.g, (const bf16*)a.h, a.dst_of, a.row_mask,
-                           (bf16*)a.g_at, (bf16*)a.dH, a.dmask, a.M);
+                           (bf16*)a.g_at, (bf16*)a.dH, a.dmask, a.M, a.gs);
     LAUNCH_CHECK();
     return 0;
 }
@@ -797,7 +812,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         TK_SCALPIN3(sf, dmk, dlg);
         if (a.dad) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) du.v[i] += e.v[i];
+            for (int i = 0; i < 12; ++i) du.v[i] += e.v[i] * a.inv_gs;
         }
         if (a.dA2 && a.write_du) {
             if (r >= 0) {
@@ -805,7 +820,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
                 TK_ROWPIN(dy);
                 ln_bwd_row(dy, ur, ln2w, st2);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i];
+                for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i] * a.inv_gs;
             }
         }
         if (gate) {
@@ -821,7 +836,12 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         }
         if (a.write_du) {
             du.store(a.du + (size_t)t * D, lane);
-            if (a.du_at) du.store(reinterpret_cast<AT*>(a.du_at) + (size_t)t * D, lane);
+            if (a.du_at) {
+                Row12 dsc;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) dsc.v[i] = du.v[i] * a.gs;
+                dsc.store(reinterpret_cast<AT*>(a.du_at) + (size_t)t * D, lane);
+            }
         }
     }
     if (a.gate_w) {
@@ -894,7 +914,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
     constexpr int LDT = TS + 8;   // bf16 per LDS row (144 B: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) bf16 Xt[128 * LDT];
     __shared__ __attribute__((aligned(16))) bf16 Yt[64 * LDT];
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * 128;
     const int m0 = blockIdx.y * chunk;
@@ -946,13 +965,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
         __syncthreads();
         if (tb + TS < mend) load_step(tb + TS);  // in flight during the reads + MFMAs below
         const int lr = lane & 31, lk = lane >> 5;
-        auto sum8 = [](const bf16x8& v) {   // sum of 8 bf16 in fp32 (bf16 -> fp32 is a 16-bit shift)
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        auto sum8 = [](const bf16x8& v) {   // sum of the 8 operands in fp32
+#ifdef DYT_FP16
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += (float)v[i];
+            return t;
+#else
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // bf16 -> fp32 is a 16-bit shift
             const u32x4 u = __builtin_bit_cast(u32x4, v);
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) t += __builtin_bit_cast(float, u[i] << 16) + __builtin_bit_cast(float, u[i] & 0xffff0000u);
             return t;
+#endif
         };
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {  // four 16-token k blocks; lane = (row lr, tokens kk*16 + lk*8 .. +7)
@@ -961,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
 #pragma unroll
             for (int j = 0; j < 2; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 32 + lr) * LDT + kk * 16 + lk * 8]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[j] = DYT_MFMA_32x32x16(xf, yf[j], acc[j]);
             xs += sum8(xf);
             if (do_ysum) { ys[0] += sum8(yf[0]); ys[1] += sum8(yf[1]); }
         }

@@ -99,7 +99,7 @@ class Block(nn.Module):
     def _block_engine(self, batch, device):
         """A depth-1 libdyt_hip context holding this block's parameters (stand-alone use only)."""
         eng = self._engine
-        if eng is None or eng.device != device or batch > eng.cfg.max_batch or eng.cfg.precision != parse_precision(self.precision):
+        if eng is None or eng.device != device or batch > eng.cfg.max_batch or eng.precision != parse_precision(self.precision):
             self._engine = None
             eng = DyTEngine(1, self.adaptmlp.down_size, self.adaptmlp.scale, device, precision=self.precision, max_batch=batch, depth=1,
                             slots=1, adapter_dropout=self.adaptmlp.dropout, tau=self.mlp_token_select.tau,
@@ -219,7 +219,7 @@ class VisionTransformer(nn.Module):
         #     the kept tokens only, forward AND backward; forward values are identical, but a dropped token's gate then only
         #     sees the token-ratio loss.  Opt in explicitly.
         self.precision = parse_precision(precision if precision is not None else
-                                         _cfg_get(tuning_config, "precision") or os.environ.get("DYT_PRECISION", "bf16"))
+                                         _cfg_get(tuning_config, "precision") or os.environ.get("DYT_PRECISION", "fp16"))
         self.train_mode = train_mode or _cfg_get(tuning_config, "dyt_train_mode") or os.environ.get("DYT_TRAIN_MODE", "masked")
         assert self.train_mode in ("compact", "masked")
         self.max_batch = max_batch

@@ -10,21 +10,23 @@ import ctypes
 import torch
 
 from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
-                  F_TRAINING, PREC_BF16, PREC_FP32,
+                  F_TRAINING, PREC_BF16, PREC_FP16, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
 
 
 def parse_precision(p):
-    if p in (PREC_FP32, PREC_BF16):
+    if p in (PREC_FP32, PREC_BF16, PREC_FP16):
         return p
     p = str(p).lower()
     if p in ("fp32", "float32", "exact"):
         return PREC_FP32
     if p in ("bf16", "bfloat16", "fast"):
         return PREC_BF16
-    raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (p,))
+    if p in ("fp16", "float16", "half"):
+        return PREC_FP16
+    raise ValueError("precision must be 'fp32', 'bf16' or 'fp16', got %r" % (p,))
 
 
 class DyTEngine:
@@ -33,17 +35,19 @@ class DyTEngine:
         if torch.device(device).type != "cuda":
             raise DyTError("the DyT path runs on a HIP device only (got %s); there is no CPU path" % (device,))
         self.device = torch.device(device)
-        self.cfg = Config(int(num_classes), int(ffn_num), int(depth), parse_precision(precision), int(max_batch),
-                          int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
+        self.precision = parse_precision(precision)
+        # "fp16" = the second build of the library (IEEE-half operands) in ITS 16-bit mode
+        self.cfg = Config(int(num_classes), int(ffn_num), int(depth), PREC_BF16 if self.precision == PREC_FP16 else self.precision,
+                          int(max_batch), int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
                           int(frames))
         self.frames = max(1, int(frames))   # > 1: video model, every batch is clips * frames images
-        self.L = lib()
+        self.L = lib(fp16=self.precision == PREC_FP16)
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.L.dyt_ctx_create(ctypes.byref(self.cfg), ctypes.byref(h)))
+            self._ck(self.L.dyt_ctx_create(ctypes.byref(self.cfg), ctypes.byref(h)))
         self.h = h
         n = ctypes.c_int64()
-        check(self.L.dyt_trainable_numel(self.h, ctypes.byref(n)))
+        self._ck(self.L.dyt_trainable_numel(self.h, ctypes.byref(n)))
         self.n_train = n.value
         self.flat = torch.zeros(self.n_train, device=self.device, dtype=torch.float32)
         self.grad = torch.zeros_like(self.flat)
@@ -53,6 +57,9 @@ class DyTEngine:
         self._rccl_comm = None     # ncclComm_t of dyt_allreduce_grads (created on first use)
         self.generation = [0] * int(slots)   # bumped by every saving forward into a slot (stale-backward detection)
         self.depth, self.num_classes, self.ffn_num = int(depth), int(num_classes), int(ffn_num)
+
+    def _ck(self, rc):
+        check(rc, self.L)
 
     def __del__(self):
         try:
@@ -65,14 +72,14 @@ class DyTEngine:
     @property
     def bytes(self):
         b = ctypes.c_int64()
-        check(self.L.dyt_ctx_bytes(self.h, ctypes.byref(b)))
+        self._ck(self.L.dyt_ctx_bytes(self.h, ctypes.byref(b)))
         return b.value
 
     # ---- parameters -------------------------------------------------------------------------
     def trainable_slice(self, name):
         pid, layer = key_to_param(name)
         off, num = ctypes.c_int64(), ctypes.c_int64()
-        check(self.L.dyt_trainable_offset(self.h, pid, layer, ctypes.byref(off), ctypes.byref(num)))
+        self._ck(self.L.dyt_trainable_offset(self.h, pid, layer, ctypes.byref(off), ctypes.byref(num)))
         return off.value, num.value
 
     def trainable_view(self, name, shape, buf=None):
@@ -89,7 +96,7 @@ class DyTEngine:
             self.flat[off:off + num].copy_(t.reshape(-1))
         else:
             with torch.cuda.device(self.device):
-                check(self.L.dyt_set_frozen(self.h, pid, layer, ptr(t), stream_ptr()))
+                self._ck(self.L.dyt_set_frozen(self.h, pid, layer, ptr(t), stream_ptr()))
                 torch.cuda.current_stream().synchronize()  # `t` may be a temporary
 
     def load_state_dict(self, sd):
@@ -110,7 +117,7 @@ class DyTEngine:
         if save:
             self.generation[slot] += 1
         with torch.cuda.device(self.device):
-            check(self.L.dyt_forward(self.h, slot, ptr(images), B, flags, ptr(tr), ptr(g1), ptr(g2), ptr(keep_mask),
+            self._ck(self.L.dyt_forward(self.h, slot, ptr(images), B, flags, ptr(tr), ptr(g1), ptr(g2), ptr(keep_mask),
                                      ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(logits), ptr(ts), ptr(tl), stream_ptr()))
         return logits, ts, tl
 
@@ -125,13 +132,13 @@ class DyTEngine:
         ts = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32)
         tl = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            check(self.L.dyt_forward(self.h, 0, ptr(tokens), B, flags, ptr(self.flat), ptr(g1), ptr(g2), ptr(keep_mask),
+            self._ck(self.L.dyt_forward(self.h, 0, ptr(tokens), B, flags, ptr(self.flat), ptr(g1), ptr(g2), ptr(keep_mask),
                                      ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(out), ptr(ts), ptr(tl), stream_ptr()))
         return out, ts, tl
 
     def backward(self, slot, dlogits, grad, dtoken_select=None, dtok=None, dtoken_logits=None):
         with torch.cuda.device(self.device):
-            check(self.L.dyt_backward(self.h, slot, ptr(dlogits), ptr(dtoken_select), ptr(dtok), ptr(dtoken_logits),
+            self._ck(self.L.dyt_backward(self.h, slot, ptr(dlogits), ptr(dtoken_select), ptr(dtok), ptr(dtoken_logits),
                                       ptr(grad), stream_ptr()))
 
     def loss(self, logits_s, logits_t, targets, target_ratio, loss_ratio=2.0, token_minimal=0.0,
@@ -141,7 +148,7 @@ class DyTEngine:
         losses = torch.empty(8, device=self.device, dtype=torch.float32)
         dtok = torch.empty(3, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            check(self.L.dyt_loss(self.h, slot_student, ptr(logits_s), ptr(logits_t), ptr(targets), B, target_ratio,
+            self._ck(self.L.dyt_loss(self.h, slot_student, ptr(logits_s), ptr(logits_t), ptr(targets), B, target_ratio,
                                   loss_ratio, token_minimal, token_minimal_weight, ptr(dls), ptr(dlt), ptr(losses),
                                   ptr(dtok), stream_ptr()))
         return dls, dlt, losses, dtok
@@ -158,7 +165,7 @@ class DyTEngine:
         flags = (F_MASKED_DENSE if masked_dense else 0) | (F_ACCUM_GRAD if accumulate else 0) | (F_DEVICE_SEED if device_seed else 0)
         out = self.losses if losses is None else losses
         with torch.cuda.device(self.device):
-            check(self.L.dyt_step_fwd_bwd(self.h, ptr(images), ptr(targets), B, flags, ptr(self.flat), ptr(g1), ptr(g2),
+            self._ck(self.L.dyt_step_fwd_bwd(self.h, ptr(images), ptr(targets), B, flags, ptr(self.flat), ptr(g1), ptr(g2),
                                           ptr(keep_mask), ctypes.c_uint64(seed & (2 ** 64 - 1)), target_ratio, loss_ratio,
                                           token_minimal, token_minimal_weight, ptr(self.grad), ptr(out), ptr(logits_s),
                                           ptr(logits_t), ptr(token_select), stream_ptr()))
@@ -167,7 +174,7 @@ class DyTEngine:
     def seed_device(self, seed):
         """Set the device-side seed word that `device_seed=True` steps read (and advance)."""
         with torch.cuda.device(self.device):
-            check(self.L.dyt_seed(self.h, ctypes.c_uint64(seed & (2 ** 64 - 1)), stream_ptr()))
+            self._ck(self.L.dyt_seed(self.h, ctypes.c_uint64(seed & (2 ** 64 - 1)), stream_ptr()))
 
     def step_graph(self, images, targets, target_ratio=0.5, loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0,
                    masked_dense=False, losses=None, accumulate=False, seed=0):
@@ -225,18 +232,18 @@ class DyTEngine:
         """torch.optim.AdamW semantics over the flat buffer (main_image.py:285); the moments belong to the optimizer
         object (engine_finetune.FusedAdamW) and survive a re-created engine; `step` is the 1-based update count."""
         with torch.cuda.device(self.device):
-            check(self.L.dyt_adamw(ptr(self.flat), ptr(self.grad), ptr(exp_avg), ptr(exp_avg_sq), self.n_train,
+            self._ck(self.L.dyt_adamw(ptr(self.flat), ptr(self.grad), ptr(exp_avg), ptr(exp_avg_sq), self.n_train,
                                    int(step), lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr()))
 
     def clip_grad_norm(self, max_norm, pre_scale=1.0, norm_out=None):
         """torch.nn.utils.clip_grad_norm_ on the flat gradient (misc.py:262-266); pre_scale = the factor AdamW applies."""
         with torch.cuda.device(self.device):
-            check(self.L.dyt_clip_grad_norm(self.h, ptr(self.grad), self.n_train, float(max_norm), float(pre_scale),
+            self._ck(self.L.dyt_clip_grad_norm(self.h, ptr(self.grad), self.n_train, float(max_norm), float(pre_scale),
                                             ptr(norm_out), stream_ptr()))
 
     def grad_part(self, part):
         off, num = ctypes.c_int64(), ctypes.c_int64()
-        check(self.L.dyt_grad_part(self.h, int(part), ctypes.byref(off), ctypes.byref(num)))
+        self._ck(self.L.dyt_grad_part(self.h, int(part), ctypes.byref(off), ctypes.byref(num)))
         return off.value, num.value
 
     def comm_stream(self):
@@ -252,11 +259,11 @@ class DyTEngine:
             self._rccl_comm = rccl_comm_create(self.device)
         cs = ctypes.c_void_p(self.comm_stream().cuda_stream) if overlap else None
         with torch.cuda.device(self.device):
-            check(self.L.dyt_allreduce_grads(self.h, self._rccl_comm, ptr(self.grad), cs, stream_ptr()))
+            self._ck(self.L.dyt_allreduce_grads(self.h, self._rccl_comm, ptr(self.grad), cs, stream_ptr()))
 
     def stream_wait_grads(self, stream, part=0):
         """Make `stream` wait on the device until the early part of the last step's gradient is final."""
-        check(self.L.dyt_stream_wait_grads(self.h, int(part), ctypes.c_void_p(stream.cuda_stream)))
+        self._ck(self.L.dyt_stream_wait_grads(self.h, int(part), ctypes.c_void_p(stream.cuda_stream)))
 
     def debug_dispatch(self, slot, layer, batch):
         """Token-dispatcher index arrays of the pass held in `slot` (test hook): row_src, dst_of, counts, total."""
@@ -266,20 +273,20 @@ class DyTEngine:
         counts = torch.zeros(batch, device=self.device, dtype=torch.int32)
         total = torch.zeros(1, device=self.device, dtype=torch.int32)
         with torch.cuda.device(self.device):
-            check(self.L.dyt_debug_dispatch(self.h, int(slot), int(layer), ptr(row_src), ptr(dst_of), ptr(counts), ptr(total),
+            self._ck(self.L.dyt_debug_dispatch(self.h, int(slot), int(layer), ptr(row_src), ptr(dst_of), ptr(counts), ptr(total),
                                             stream_ptr()))
         return row_src, dst_of, counts, total
 
     def set_option(self, option, value):
         """_lib.OPT_STREAM_OVERLAP / OPT_CLS_TAIL / OPT_SHARE_BLOCK0 (scheduling only; results do not change);
         OPT_COUNT_FLOPS_TOKENS takes the token count n (0 = off) of Block.forward_count_flops."""
-        check(self.L.dyt_ctx_set_option(self.h, int(option), int(value)))
+        self._ck(self.L.dyt_ctx_set_option(self.h, int(option), int(value)))
 
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on):
-        check(self.L.dyt_profile_enable(self.h, 1 if on else 0))
+        self._ck(self.L.dyt_profile_enable(self.h, 1 if on else 0))
 
     def profile_read(self, category):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        check(self.L.dyt_profile_read(self.h, category, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        self._ck(self.L.dyt_profile_read(self.h, category, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
         return ms.value, n.value, fl.value

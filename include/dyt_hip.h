@@ -111,6 +111,9 @@ typedef struct dyt_ctx dyt_ctx;
 
 const char* dyt_last_error(void);
 int dyt_version(void);
+/* the 16-bit operand type DYT_PREC_BF16 selects in THIS build of the library: 0 bfloat16 (libdyt_hip.so), 1 IEEE half
+ * (libdyt_hip_f16.so, same sources compiled with -DDYT_FP16; the reference's own autocast dtype, engine_finetune.py:47) */
+int dyt_operand_type(void);
 
 int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out);
 int dyt_ctx_destroy(dyt_ctx* ctx);
@@ -139,6 +142,12 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           whatever the gate decides; token_select reports that forced pattern.  This one DOES change
  *                           results. */
 #define DYT_OPT_COUNT_FLOPS_TOKENS 4
+/*   DYT_OPT_GRAD_SCALE_LOG2     value k in 0..24: the gradient is multiplied by 2^k wherever the library holds it in its 16-bit
+ *                               operand type (g_at, dZ, dA2, dqkv ...) and divided again where it returns to fp32 -- a fixed loss
+ *                               scale that never leaves the library (what the reference's GradScaler does for its fp16 autocast,
+ *                               misc.py:252-272).  Default: 0 in libdyt_hip.so (bf16 has fp32's exponent range), 12 in
+ *                               libdyt_hip_f16.so.  Returned gradients are unscaled either way. */
+#define DYT_OPT_GRAD_SCALE_LOG2 5
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library

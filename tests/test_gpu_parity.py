@@ -278,8 +278,8 @@ def test_reproducible_schedules_are_bitwise(overlap):
             assert torch.equal(r[i][1], runs[0][i][1])
 
 
-@pytest.mark.parametrize("mode", ["compact", "masked"])
-def test_default_schedule_is_bitwise_at_bench_size(mode):
+@pytest.mark.parametrize("mode,precision", [("compact", "bf16"), ("masked", "bf16"), ("compact", "fp16")])
+def test_default_schedule_is_bitwise_at_bench_size(mode, precision):
     """The benchmarked configuration itself: B=128, bf16, both passes overlapped end to end (DYT_OPT_STREAM_OVERLAP = 1).
     11 rebuilt contexts x 2 steps = 20 comparisons against the first run, gradients bit for bit (round 2: every one of them
     differed, ~2e-6 absolute in ~1.09 M of the 1.28 M gradient elements)."""
@@ -289,7 +289,7 @@ def test_default_schedule_is_bitwise_at_bench_size(mode):
     x, y = x.cuda(), y.cuda()
     ref = None
     for run in range(11):
-        m = _bench_model("bf16", mode, B, 0.85)
+        m = _bench_model(precision, mode, B, 0.85)
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
         eng.set_option(_lib.OPT_STREAM_OVERLAP, 1)

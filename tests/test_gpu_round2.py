@@ -39,10 +39,14 @@ def _bench_model(precision, mode, B, gate_bias, classes=100, r=64, kind="bench",
 BF16_GRAD_TOL = {"mlp_token_select": 0.05, "adaptmlp.down_proj": 0.15, "adaptmlp.up_proj": 0.03, "head": 0.02}   # measured at B=16: 0.012 / 0.071 / 0.008 / 0.006
 
 
+# the same for the fp16 mode (IEEE-half operands, libdyt_hip_f16.so); measured at B=16: 0.001 / 0.039 / 0.001 / 0.0008
+FP16_GRAD_TOL = {"mlp_token_select": 0.01, "adaptmlp.down_proj": 0.25, "adaptmlp.up_proj": 0.005, "head": 0.003}   # VTAB shapes (r=16): down_proj up to 0.115, gate 0.003
+
+
 def _grad_tol(name, precision):
     if precision == "fp32":
         return 2e-3
-    for k, v in BF16_GRAD_TOL.items():
+    for k, v in (FP16_GRAD_TOL if precision == "fp16" else BF16_GRAD_TOL).items():
         if k in name:
             return v
     return 0.1
@@ -58,7 +62,7 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
     d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
     ref_ls, ref_lt, ref_ts = ref_ls.detach(), ref_lt.detach(), tok["token_select"].detach()
     z = ((tok["token_logits"].detach()[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0).abs()   # decision margins [12,B,196]
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "fp16", "bf16"):
         m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
@@ -68,18 +72,21 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
         losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
                                   g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
                                   token_select=ts).cpu()
-        ltol = 1e-3 if prec == "fp32" else 0.03
+        ltol = {"fp32": 1e-3, "fp16": 0.015, "bf16": 0.03}[prec]       # measured at B=16, C=100: 4e-6 / 1.6e-3 / 0.012; fp16 at B=64, C=397: 8.8e-3
         assert float((ls.cpu() - ref_ls).abs().max()) < ltol, (prec, float((ls.cpu() - ref_ls).abs().max()))
         assert float((lt.cpu() - ref_lt).abs().max()) < ltol
         flip = ts.cpu() != ref_ts[..., 0].float()
         if prec == "fp32":   # bit-exact wherever the decision is not within fp32 round-off of the threshold
             assert int((flip & (z.permute(1, 0, 2) > 2e-5)).sum()) == 0, int(flip.sum())
             assert int(flip.sum()) <= 2
+        elif prec == "fp16":
+            print("%s fp16 gate flips: %d of %d" % (label, int(flip.sum()), flip.numel()))
+            assert int(flip.sum()) <= max(6, B // 4), int(flip.sum())       # measured: 0 of 37 632 at B=16 (scale 0.1); 3 of 18 816 at the VTAB shape B=8, scale 1
         else:
             assert int(flip.sum()) <= max(8, B * 3 // 2), int(flip.sum())   # of B*2352 decisions (measured: a handful at B=16)
         for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
             ref = float(d_ref[k])
-            assert abs(float(losses[i]) - ref) < (1e-4 if prec == "fp32" else 0.02) * max(1.0, abs(ref)), (prec, k, float(losses[i]), ref)
+            assert abs(float(losses[i]) - ref) < {"fp32": 1e-4, "fp16": 3e-3, "bf16": 0.02}[prec] * max(1.0, abs(ref)), (prec, k, float(losses[i]), ref)
         worst, scalars = {}, {}
         for n, gr in g_ref.items():
             got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
@@ -338,7 +345,7 @@ def _video_full_size_reference():
     return _VIDEO_REF[0]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
 def test_video_training_step_at_train_video_sh_size(precision):
     """BASELINE.json configs[4] at FULL size (train_video.sh:19-31: --batch_size 16 per GPU, 8 frames per clip
     (video_datasets/video_datasets.py:28), K400 = 400 classes, r = 64, scale 0.1, token_target_ratio 0.5): one fused training
@@ -367,14 +374,14 @@ def test_video_training_step_at_train_video_sh_size(precision):
     losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=True, g1=g1.cuda().contiguous(),
                               g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
                               token_select=ts).cpu()
-    ltol = 1e-3 if precision == "fp32" else 0.02            # bf16 measured 2e-3 on the 2 x 2 golden
+    ltol = {"fp32": 1e-3, "fp16": 4e-3, "bf16": 0.02}[precision]            # bf16 measured 2e-3 on the 2 x 2 golden
     assert float((ls.cpu() - ref_ls).abs().max()) < ltol, float((ls.cpu() - ref_ls).abs().max())
     assert float((lt.cpu() - ref_lt).abs().max()) < ltol, float((lt.cpu() - ref_lt).abs().max())
     flips = int((ts.cpu() != ref_ts).sum())
-    assert flips <= (4 if precision == "fp32" else B * 3), flips     # of B * 2352 = 301 056 decisions (fp32: ties only)
+    assert flips <= {"fp32": 4, "fp16": B // 4, "bf16": B * 3}[precision], flips     # of B * 2352 = 301 056 decisions (fp32: ties only)
     for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
         ref = float(d_ref[k])
-        assert abs(float(losses[i]) - ref) < (1e-4 if precision == "fp32" else 0.02) * max(1.0, abs(ref)), (k, float(losses[i]), ref)
+        assert abs(float(losses[i]) - ref) < {"fp32": 1e-4, "fp16": 3e-3, "bf16": 0.02}[precision] * max(1.0, abs(ref)), (k, float(losses[i]), ref)
     worst = {}
     scal = []
     for n, gr in g_ref.items():
@@ -383,9 +390,9 @@ def test_video_training_step_at_train_video_sh_size(precision):
             scal.append((float(got), float(gr)))
             continue
         # norm_k.bias has an exactly-zero true gradient (a constant added to every key shifts all scores equally): absolute floor
-        e = float((got - gr).norm() / max(float(gr.norm()), 1e-4 if precision == "fp32" else 1e-3))
+        e = float((got - gr).norm() / max(float(gr.norm()), {"fp32": 1e-4, "fp16": 3e-4, "bf16": 1e-3}[precision]))
         kind = n.split(".", 2)[-1] if n.startswith("blocks.") else n
-        tol = _grad_tol(n, precision) if n.startswith("blocks.") or n.startswith("head") else (2e-3 if precision == "fp32" else 0.05)
+        tol = _grad_tol(n, precision) if n.startswith("blocks.") or n.startswith("head") else {"fp32": 2e-3, "fp16": 0.01, "bf16": 0.05}[precision]
         assert e < tol, (precision, n, e)
         worst[kind] = max(worst.get(kind, 0.0), e)
     a, b = torch.tensor(scal, dtype=torch.float64).unbind(1)
