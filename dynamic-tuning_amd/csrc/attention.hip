@@ -420,6 +420,215 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_bf16_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, bf16: dQ and dK / dV of one (image, head) in ONE workgroup pass
+// ------------------------------------------------------------------------------------------
+// The two kernels above each stream q, k, v, dO (and o) of every head from memory: 12 passes over a [M,768] operand per
+// backward (464 MB at B=128) at ~3 TB/s -- the attention backward is bound by that traffic and by per-head latencies, not by
+// the matrix pipe.  Here a persistent workgroup runs the dK/dV phase and the dQ phase of a head back to back on the same LDS:
+//   phase B  Q, dO staged once (row + transposed images); the wave's k / v rows in registers; delta = rowsum(dO * o) goes
+//            from registers to LDS (no trip through memory) -> dK, dV   (the code of attn_bwd_dkv_bf16_kernel)
+//   switch   every wave takes the q / dO rows of ITS query tile from the row images (phase A's B operands), then the K / V
+//            images (row + K^T) replace Q / dO: their cooperative loads were issued before phase B and landed under it
+//   phase A  dQ   (the code of attn_bwd_dq_bf16_kernel)
+// Q, dO and o are read once, k / v twice by the same workgroup within one head (second read from L2): 8 operand passes
+// instead of 12, one launch instead of two.  The heavy phase (B: four accumulators) runs with 64 prefetch registers in
+// flight, the light one (A) with the next head's 112 -- in the opposite order the kernel spills.  The arithmetic of both
+// phases is the code of the two kernels above, so the results are bit-identical to theirs (tested).
+template <bool ROWPF>
+__global__ __launch_bounds__(448) void attn_bwd_fused_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                                  const bf16* __restrict__ v, const bf16* __restrict__ o,
+                                                                  const bf16* __restrict__ dout,
+                                                                  const float* __restrict__ lse, float* __restrict__ delta,
+                                                                  bf16* __restrict__ dqkv, int nheads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // phase B images
+    bf16* Qs = reinterpret_cast<bf16*>(smem);
+    bf16* dOs = reinterpret_cast<bf16*>(smem + ROW_IMG);
+    bf16* Qt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG);
+    bf16* dOt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG + TR_IMG);
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * ROW_IMG + 2 * TR_IMG);
+    float* del_s = lse_s + NPAD;
+    // phase A images (same bytes)
+    bf16* Ks = reinterpret_cast<bf16*>(smem);
+    bf16* Vs = reinterpret_cast<bf16*>(smem + ROW_IMG);
+    bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);   // the wave's key tile (phase B) = its query tile (phase A)
+    StageRegs qs_, ds_;            // next head's Q / dO (cooperative): in flight during phase A
+    bf16x8 kfr[4], vfr[4], on[4];  // k / v / o rows of this wave's tile
+    float Ln = 0.f;
+    auto load_rows = [&](int bh) {
+        const int b = bh / NH, h = bh - b * NH;
+        const size_t hrow = ((size_t)bh * NT + qr) * HD;
+        const size_t trow = ((size_t)b * NT + qr) * D + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kfr[ks] = *reinterpret_cast<const bf16x8*>(k + hrow + ks * 16 + hi * 8);
+            vfr[ks] = *reinterpret_cast<const bf16x8*>(v + hrow + ks * 16 + hi * 8);
+            on[ks] = *reinterpret_cast<const bf16x8*>(o + trow + ks * 16 + hi * 8);
+        }
+        Ln = lse[(size_t)bh * NT + qr];
+    };
+    auto prefetch = [&](int bh) {
+        const int b = bh / NH, h = bh - b * NH;
+        stage_load(qs_, q + (size_t)bh * NT * HD, HD, tid);
+        stage_load(ds_, dout + (size_t)b * NT * D + h * HD, D, tid);
+        if (ROWPF) load_rows(bh);   // else: issued at the head's start, first used after the image stores and two barriers
+    };
+    int bh = blockIdx.x;
+    if (bh < nheads) prefetch(bh);
+    for (; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        if (!ROWPF) load_rows(bh);
+        stage_store(qs_, Qs, Qt, tid);
+        stage_store(ds_, dOs, dOt, tid);
+        const float L = Ln;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kfr[ks]; vf[ks] = vfr[ks]; }
+        __syncthreads();
+        // delta of this wave's query rows: dO rows from the image just written (the operand order of the dQ kernel's sum)
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dOs + qrow * RLD + ks * 16 + hi * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dl += (float)dv[i] * (float)on[ks][i];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (hi == 0) {
+            lse_s[qrow] = qrow < NT ? L : 0.f;
+            del_s[qrow] = qrow < NT ? dl : 0.f;
+            if (qrow < NT) delta[(size_t)bh * NT + qrow] = dl;
+        }
+        __syncthreads();
+        StageRegs kr, vr;   // this head's K / V for the phase-A images: in flight during phase B
+        stage_load(kr, k + (size_t)bh * NT * HD, HD, tid);
+        stage_load(vr, v + (size_t)bh * NT * HD, HD, tid);
+        // ---------------- phase B: dK, dV ----------------
+        {
+            const int key = qrow;
+            f32x16 aK[2], aV[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
+#pragma unroll 1
+            for (int qt = 0; qt < 7; ++qt) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(dOs + (qt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                    s = MFMA32(qa, kf[ks], s);     // S[q][key]   (rows q in registers, column key = lane)
+                    dp = MFMA32(da, vf[ks], dp);   // dP[q][key]
+                }
+                f32x16 p;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int q0 = qt * 32 + 8 * g + 4 * hi;
+                    const float4 L4 = *reinterpret_cast<const float4*>(lse_s + q0);
+                    const float4 D4 = *reinterpret_cast<const float4*>(del_s + q0);
+                    const float Ls[4] = {L4.x, L4.y, L4.z, L4.w};
+                    const float Ds[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const bool ok = (q0 + e < NT) && (key < NT);
+                        const float pv = ok ? __expf(s[r] - Ls[e]) : 0.f;
+                        p[r] = pv;
+                        s[r] = pv * (dp[r] - Ds[e]);  // dS
+                    }
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const bf16x8 pf = pack8(p, half * 8);
+                    const bf16x8 dsf = pack8(s, half * 8);
+                    const int qbase = qt * 32 + half * 16 + 4 * hi;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16x8 dot = join44(dOt + (dt * 32 + l31) * TLD + qbase);
+                        const bf16x8 qtf = join44(Qt + (dt * 32 + l31) * TLD + qbase);
+                        aV[dt] = MFMA32(dot, pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                        aK[dt] = MFMA32(qtf, dsf, aK[dt]);  // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                    }
+                }
+            }
+            if (key < NT) {
+                bf16* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = dt * 32 + 8 * g + 4 * hi;
+                        store4(op + D + d, aK[dt][4 * g], aK[dt][4 * g + 1], aK[dt][4 * g + 2], aK[dt][4 * g + 3]);
+                        store4(op + 2 * D + d, aV[dt][4 * g], aV[dt][4 * g + 1], aV[dt][4 * g + 2], aV[dt][4 * g + 3]);
+                    }
+            }
+        }
+        // ---------------- switch ----------------
+        bf16x8 qf[4], dof[4];   // q / dO rows of this wave's query tile (pad rows are zero in the images; their columns are never stored)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + qrow * RLD + ks * 16 + hi * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + qrow * RLD + ks * 16 + hi * 8);
+        }
+        __syncthreads();   // every wave is done with the Q / dO images
+        stage_store(kr, Ks, Kt, tid);
+        stage_store(vr, Vs, nullptr, tid);
+        __syncthreads();
+        if (bh + gridDim.x < nheads) prefetch(bh + gridDim.x);   // lands under phase A
+        // ---------------- phase A: dQ ----------------
+        {
+            f32x16 dq[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll 1
+            for (int kt = 0; kt < 7; ++kt) {
+                f32x16 s_, dp_;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp_[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                    const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                    s_ = MFMA32(ka, qf[ks], s_);
+                    dp_ = MFMA32(va, dof[ks], dp_);
+                }
+                bf16x8 ktf[2][2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) ktf[half][dt] = join44(Kt + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float p = key < NT ? __expf(s_[r] - L) : 0.f;
+                    s_[r] = p * (dp_[r] - dl);        // dS^T
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const bf16x8 dsf = pack8(s_, half * 8);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = MFMA32(ktf[half][dt], dsf, dq[dt]);  // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+                }
+            }
+            if (qrow < NT) {
+                bf16* op = dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        store4(op + dt * 32 + 8 * g + 4 * hi, dq[dt][4 * g] * 0.125f, dq[dt][4 * g + 1] * 0.125f,
+                               dq[dt][4 * g + 2] * 0.125f, dq[dt][4 * g + 3] * 0.125f);
+            }
+        }
+        __syncthreads();   // every wave is done with this head's images before they are overwritten
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // exact fp32 kernels on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulate, one
 // rounding per product = an fmaf chain) -- the parity mode.
 //
@@ -689,6 +898,7 @@ static bool* attr_flag(int family) {
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
                     hipStream_t s) {
     const int grid = batch * NH;
+    if (dbg_skip(2)) return 0;
     if (precision == 0) {
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);
         bool* once = attr_flag(0);
@@ -704,9 +914,13 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
     return 0;
 }
 
+static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV (0: the two separate kernels; 2: fused, row prefetch a head ahead)
+void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
+
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
                     const float* lse, float* delta, void* dqkv, int batch, hipStream_t s) {
     const int grid = batch * NH;
+    if (dbg_skip(1)) return 0;
     if (precision == 0) {
         const size_t lds1 = 2 * F_IMG;
         const size_t lds2 = 2 * F_IMG + 2 * NPAD * sizeof(float);
@@ -727,7 +941,19 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
         if (!*once) {
             if (set_lds((const void*)attn_bwd_dq_bf16_kernel, lds1)) return -2;
             if (set_lds((const void*)attn_bwd_dkv_bf16_kernel, lds2)) return -2;
+            if (set_lds((const void*)attn_bwd_fused_bf16_kernel<false>, lds2)) return -2;
+            if (set_lds((const void*)attn_bwd_fused_bf16_kernel<true>, lds2)) return -2;
             *once = true;
+        }
+        if (g_attn_bwd_fused) {
+            if (g_attn_bwd_fused == 2)
+                hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<true>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
+                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
+            else
+                hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<false>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
+                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
+            DYT_HIP_CHECK(hipGetLastError());
+            return 0;
         }
         hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds1, s, (const bf16*)q, (const bf16*)k,
                            (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);

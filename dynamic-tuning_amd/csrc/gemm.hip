@@ -143,21 +143,33 @@ struct EpiFc1 {
 // PLAIN = no row map and no row mask (teacher pass / dense rows): the per-chunk context is then just the 16 B of the residual,
 // small enough for the kernels to issue a whole pass of residual loads ahead of the staging barriers (PRE_ALL); with the
 // 32-byte {dst, mask, residual} context of the general form the loads sit right in front of their use.
+// `resid` is the residual the row is added to (x itself for the in-place form; the block's `u` when the adapter's
+// up-projection rides along as an extra k-tile of the contraction (CatArgs): x = u + (h W2^T + b2) + (d_act (s Wup)^T + s b_up)
+// is then ONE read of u and ONE write of x instead of two fp32 read-modify-write passes over [M,768]).
 template <class AT, bool PLAIN>
 struct EpiFc2 {
     const float* bias; float* x; const int* row_map; const float* row_mask; AT* h_out;
+    const float* resid; const float* bias2; float scale2;
     typedef Bias4 Col;
     struct PreG { int dst; float m; Raw4<float> r; };
     typedef typename std::conditional<PLAIN, Raw4<float>, PreG>::type Pre;
-    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
+    __device__ __forceinline__ Col col_init(int col) const {
+        Col c = load_bias4(bias, col);
+        if (bias2) {
+            const Col c2 = load_bias4(bias2, col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c.b[i] = fmaf(scale2, c2.b[i], c.b[i]);
+        }
+        return c;
+    }
     __device__ __forceinline__ Pre pre(int row, int col) const {
         if constexpr (PLAIN) {
-            return load_raw4(x + (size_t)row * D + col);
+            return load_raw4(resid + (size_t)row * D + col);
         } else {
             Pre p;
             p.dst = row_map ? row_map[row] : row;
             p.m = row_mask ? row_mask[p.dst] : 1.0f;
-            p.r = load_raw4(x + (size_t)p.dst * D + col);   // in place: this chunk is the only writer of these 4 values
+            p.r = load_raw4(resid + (size_t)p.dst * D + col);   // in place when resid == x: this chunk is the only writer of these 4 values
             return p;
         }
     }
@@ -271,6 +283,7 @@ struct EpiAdDown {
 template <bool MAPPED>   // MAPPED: rows go through row_map (cls-only tail of the last block); see EpiFc2 for why two forms
 struct EpiAdUp {
     const float* bias; const float* u; float* out; float scale; const int* row_map;
+    const float* skip_mask;   // rows with skip_mask[row] != 0 are left alone (kept tokens: their fc2 launch adds the adapter itself)
     typedef Bias4 Col;
     struct PreG { int dst; Raw4<float> r; };
     typedef typename std::conditional<MAPPED, PreG, Raw4<float>>::type Pre;
@@ -282,13 +295,14 @@ struct EpiAdUp {
             p.r = load_raw4(u + (size_t)p.dst * D + col);
             return p;
         } else {
+            if (skip_mask && skip_mask[row] != 0.f) return {make_float4(0.f, 0.f, 0.f, 0.f)};
             return load_raw4(u + (size_t)row * D + col);
         }
     }
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         float r[4];
         size_t dst = row;
-        if constexpr (MAPPED) { p.r.get(r); dst = p.dst; } else { p.get(r); }
+        if constexpr (MAPPED) { p.r.get(r); dst = p.dst; } else { if (skip_mask && skip_mask[row] != 0.f) return; p.get(r); }
         store4(out + dst * D + col, r[0] + scale * (a[0] + c.b[0]), r[1] + scale * (a[1] + c.b[1]),
                r[2] + scale * (a[2] + c.b[2]), r[3] + scale * (a[3] + c.b[3]));
     }
@@ -345,10 +359,15 @@ __device__ unsigned long long g_gemm_dbg[4];
 //   256x256, 2x4 waves, 128 KB LDS, 1 workgroup / CU  -- wide-N GEMMs: half the L2->LDS bytes per FLOP
 //   128x64,  2x2 waves                                 -- adapter bottleneck (N = 64)
 // ABL: 0 = product, 9 = the same kernel with the three phase timers (tools/gemm_bench.py)
-template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0>
+// CAT: the contraction gets ONE extra leading k-tile taken from a second operand pair -- A2 [rows, 64] (rows optionally
+// gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
+// riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
+// registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; };
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
-    const int* __restrict__ a_map, int m_begin, Epi epi) {
+    const int* __restrict__ a_map, int m_begin, Epi epi, CatArgs cat) {
     // rows [m_begin, M) are tiled by this launch (a GEMM may be covered by two launches with different tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = 64;
@@ -384,12 +403,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
         const int row = (t * NW + wave) * 8 + lrow;
         int grow = min(m0 + row, Mv - 1);
         if (a_map) grow = a_map[grow];  // gathered A rows (compacted MLP backward)
-        a_src[t] = A + (size_t)grow * K + chunk * 8;
+        a_src[t] = A + (size_t)grow * K + chunk * 8 - (CAT ? BK : 0);
     }
 #pragma unroll
     for (int t = 0; t < B_INSTR; ++t) {
         const int row = (t * NW + wave) * 8 + lrow;
-        b_src[t] = W + (size_t)(n0 + row) * K + chunk * 8;
+        b_src[t] = W + (size_t)(n0 + row) * K + chunk * 8 - (CAT ? BK : 0);
     }
     // one 1-KiB DMA piece (idx < A_INSTR: A rows, else W rows) -- issued interleaved with the MFMAs so the
     // in-order wave never sits behind a burst of LDS-DMA issues (each costs ~100+ cycles back-to-back)
@@ -418,6 +437,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
                                              16, 0, 0);
     };
 
+    // CAT: stage 0 comes from the second operand pair (one 64-wide row = one 128-B ring row)
+    auto stage_first = [&]() {
+        if constexpr (CAT) {
+#pragma unroll
+            for (int t = 0; t < A_INSTR; ++t) {
+                int grow = min(m0 + (t * NW + wave) * 8 + lrow, Mv - 1);
+                if (cat.a2_map) grow = cat.a2_map[grow];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.A2 + (size_t)grow * BK + chunk * 8),
+                                                 (__attribute__((address_space(3))) void*)(smem + (t * NW + wave) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < B_INSTR; ++t) {
+                const int row = (t * NW + wave) * 8 + lrow;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.W2 + (size_t)(n0 + row) * BK + chunk * 8),
+                                                 (__attribute__((address_space(3))) void*)(smem + A_BYTES + (t * NW + wave) * 1024), 16, 0, 0);
+            }
+        } else {
+            stage(0, 0);
+        }
+    };
+
     // ---- fragment read offsets: row = tilebase + (lane & 15), chunk = ks*4 + (lane >> 4) ----
     const int frow = lane & 15;
     const int fslot0 = ((lane >> 4)) ^ (lane & 7);
@@ -431,7 +471,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    const int nk = K / BK + (CAT ? 1 : 0);
     if (ABL == 9) t_loop0 = __builtin_readcyclecounter();
     if constexpr (!BOTH_KS) {
         // ---- big wave tiles (128x64 per wave): half-stage software pipeline.  Two fragment sets, one per
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
 #pragma unroll
             for (int j = 0; j < TN; ++j) fwB[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + fslot1 * 16);
         };
-        stage(0, 0);
+        stage_first();
         if (nk > 1) stage(1, 1);
         dma_wait_all();
         __syncthreads();
@@ -516,7 +556,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
 #undef DYT_SG2R
 #undef DYT_SGB
     } else {
-    stage(0, 0);
+    stage_first();
     for (int kt = 0; kt < nk; ++kt) {
         dma_wait_all();
         __syncthreads();  // stage kt landed (vmcnt drained before the barrier); ring slot (kt+1)&1 is free
@@ -643,14 +683,14 @@ long long gemm_kernel_launch_count(int reset) {
     return n;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi, bool CAT = false>
 static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int m_begin = 0, int m_end = -1) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     if (m_end < 0) m_end = a.M;
     if (m_end <= m_begin) return 0;
     const int grid = ((m_end - m_begin + BM - 1) / BM) * (a.N / BN);
     const size_t lds = 2 * (BM + BN) * 64 * 2;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT>;
     static bool attr_set[64] = {};   // per device: the attribute belongs to the (kernel, device) pair
     int dev = 0;
     DYT_HIP_CHECK(hipGetDevice(&dev));
@@ -659,8 +699,9 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
                                           (int)lds));
         attr_set[dev & 63] = true;
     }
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
-                       m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi);
+                       m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, cat);
     ++g_bf16_kernel_launches;
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -692,9 +733,13 @@ static int g_big_tile_min_n = 2304;
 static int g_use_bpre = 1;        // wide-N GEMMs with a pre-shuffled frozen weight: 128x256 tiles, 2 workgroups / CU (gemm_bpre.h)
 static int g_split_rows = 1;      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
 
-template <class Epi>
+template <class Epi, bool CAT = false>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
+    if constexpr (CAT) {
+        if (!a.A2 || !a.W2 || a.N % 128 != 0) { set_error("gemm_bf16: K-concatenated form needs A2, W2 and N %% 128 == 0 (N=%d)", a.N); return -1; }
+    } else {
+        if (a.A2) { set_error("gemm_bf16: this epilogue has no K-concatenated form"); return -1; }
     // Wide-N GEMMs against a frozen weight: the pre-shuffled-weight kernel (128x256 tiles, two workgroups per CU, the
     // weight never touches LDS).  In the step: 28.10 vs 28.40 ms with the 256x256 kernel; routing the N = 768 GEMMs
     // through it as well gains another 0.5 % wall time but costs 8 % serial GEMM time, so they keep the split-row scheme.
@@ -702,7 +747,8 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         GemmArgs b = a; b.W = a.Wp;
         return launch_bf16_bpre<0>(b, epi, s);
     }
-    if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
+    }
+    if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
     if (a.N % 256 == 0 && a.K >= 256 && g_split_rows) {
         // Narrow-N GEMMs (N = 768): per row, 256x256 tiles are ~1.6x cheaper than 128x128 tiles (half the L2->LDS bytes
         // per FLOP), but 99 x 3 = 297 tiles leave 41 for a second round.  The rows that fill whole rounds of 256
@@ -713,15 +759,15 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         constexpr int NCU = 256;
         const int tn = a.N / 256, t256 = ((a.M + 255) / 256) * tn, rounds = t256 / NCU, rem = t256 - rounds * NCU;
         if (rounds >= 1 || rem >= 3 * NCU / 4) {
-            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
+            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
             const int body = (rounds * NCU / tn) * 256;
-            int rc = launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s, 0, body);
+            int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s, 0, body);
             if (rc) return rc;
-            return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s, body, a.M);
+            return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT>(a, epi, s, body, a.M);
         }
     }
-    if (a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
-    if (a.N % 64 == 0) return launch_bf16_cfg<128, 64, 2, 2, 0>(a, epi, s);
+    if (a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT>(a, epi, s);
+    if constexpr (!CAT) { if (a.N % 64 == 0) return launch_bf16_cfg<128, 64, 2, 2, 0>(a, epi, s); }
     set_error("gemm_bf16: N=%d must be a multiple of 64", a.N);
     return -1;
 }
@@ -772,9 +818,21 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_FC1:
             if (a.out_at2) return run<AT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
             return run<AT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
-        case EPI_FC2:
-            if (!a.row_map && !a.row_mask) return run<AT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out}, s);
-            return run<AT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out}, s);
+        case EPI_FC2: {
+            const float* resid = a.resid ? a.resid : a.out_f32;   // null: in place
+            if (a.A2) {   // adapter up-projection as the leading k-tile of the contraction (16-bit kernels only)
+                if constexpr (sizeof(AT) == 2) {
+                    if (!a.row_map && !a.row_mask)
+                        return run_bf16<EpiFc2<AT, true>, true>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, a.bias2, a.scale}, s);
+                    return run_bf16<EpiFc2<AT, false>, true>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, a.bias2, a.scale}, s);
+                } else {
+                    set_error("gemm: the K-concatenated fc2 form exists in the 16-bit modes only");
+                    return -1;
+                }
+            }
+            if (!a.row_map && !a.row_mask) return run<AT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, nullptr, 0.f}, s);
+            return run<AT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
+        }
         case EPI_GELU_BWD:
             if (a.row_map) return run<AT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
             return run<AT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
@@ -783,8 +841,8 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_AD_DOWN:
             return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
         case EPI_AD_UP:
-            if (a.row_map) return run<AT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map}, s);
-            return run<AT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr}, s);
+            if (a.row_map) return run<AT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr}, s);
+            return run<AT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
         case EPI_EMBED: return run<AT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
@@ -805,6 +863,12 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
         case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 30: return run_bf16(a, epi, s);                               // the product dispatch (incl. the split-row scheme)
+        case 40: case 41: case 42: {   // C = A2 W2^T + A W^T, A2 [M,64] stored behind A, W2 [N,64] behind W (leading k-tile form)
+            a.A2 = static_cast<const bf16*>(A) + (size_t)M * K; a.W2 = static_cast<const bf16*>(W) + (size_t)N * K;
+            if (variant == 40) return launch_bf16_cfg<128, 128, 2, 2, 0, EpiStoreAT<bf16>, true>(a, epi, s);
+            if (variant == 41) return launch_bf16_cfg<256, 256, 2, 4, 0, EpiStoreAT<bf16>, true>(a, epi, s);
+            return run_bf16<EpiStoreAT<bf16>, true>(a, epi, s);
+        }
         case 70: case 79: {   // pre-shuffled-weight kernel (test-only: shuffles W into a cached scratch buffer first)
             static bf16* wp = nullptr; static size_t wp_elems = 0;
             const size_t need = (size_t)N * K;
@@ -828,7 +892,7 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
 int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int K, int variant, hipStream_t s) {
     GemmArgs a; a.A = A; a.W = W; a.M = M; a.N = N; a.K = K;
     float* c = static_cast<float*>(C);
-    if (variant == 1) return run_f32(a, EpiAdUp<false>{nullptr, c + (size_t)M * N, c, 0.1f, nullptr}, s);
+    if (variant == 1) return run_f32(a, EpiAdUp<false>{nullptr, c + (size_t)M * N, c, 0.1f, nullptr, nullptr}, s);
     if (variant == 2) return run_f32(a, EpiStoreF32{c, N, 1, 1.0f}, s);
     return run_f32(a, EpiStoreAT<float>{c, N}, s);
 }
@@ -844,6 +908,9 @@ int gemm_debug_counters(unsigned long long* out4, int reset) {
 }
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
+    if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;
+    if (dbg_skip(128) && a.N == D && a.K >= 256) return 0;
+    if (dbg_skip(256) && a.N >= 2304) return 0;
     return precision == 0 ? dispatch<float>(kind, a, s) : dispatch<bf16>(kind, a, s);
 }
 

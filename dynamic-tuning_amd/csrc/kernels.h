@@ -1,5 +1,6 @@
 // Host-callable kernel launchers of libdyt_hip.so (internal API between translation units).
 #pragma once
+#include <stdlib.h>
 #include "dyt_common.h"
 
 namespace dyt {
@@ -32,15 +33,18 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     const int* m_dev = nullptr;   // device-side count of valid rows (<= M), or null
     const int* a_map = nullptr;   // gather: logical A row r is read from A[a_map[r]] (null = identity)
+    // K-concatenated form (16-bit kernels, EPI_FC2): C = A2 W2^T + A W^T, A2 [rows,64] (row r read from A2[a2_map[r]]), W2 [N,64];
+    // bias2 / scale: the second pair's bias enters as scale * bias2 (W2 is expected to carry `scale` already)
+    const void* A2 = nullptr; const void* W2 = nullptr; const int* a2_map = nullptr; const float* bias2 = nullptr;
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
     void* out_at2 = nullptr;
     void* out_at3 = nullptr;
-    const float* resid = nullptr;
+    const float* resid = nullptr;     // BIAS_RESID / AD_UP residual ; FC2: residual source when not in place (null = out_f32)
     const void* aux_at = nullptr;     // z (GELU_BWD) / d_act (AD_DGRAD_UP)
     const int* row_map = nullptr;     // FC2 / AD_UP scatter, AD_DOWN mask index, GELU_BWD aux index: compact row -> token row
-    const float* row_mask = nullptr;  // FC2 masked-dense: per-token mask
+    const float* row_mask = nullptr;  // FC2 masked-dense: per-token mask ; AD_UP: rows with mask != 0 are skipped
     void* h_out = nullptr;            // FC2: save h (AT)
     const uint8_t* keep = nullptr;    // AD_DOWN injected keep mask [M, r]
     const float* pos = nullptr;       // EMBED
@@ -71,6 +75,8 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
                     const void* dout, const float* lse, float* delta, void* dqkv, int batch, hipStream_t s);
+// 16-bit modes: 1 (default) = dQ and dK/dV of a head in one persistent kernel, 0 = the two separate kernels (process-wide)
+void set_attn_bwd_fused(int on);
 
 // ------------------------------------------------------------------------------------------
 // row-wise / small kernels
@@ -246,5 +252,18 @@ int launch_pool_ln_bwd(int precision, const void* dxk, const void* dxv, const fl
                        int rows, int* nblocks_out, float gs, hipStream_t s);
 
 inline size_t at_size(int precision) { return precision == 0 ? 4 : 2; }
+
+// Measurement hook (tools/probes/marginal_cost.sh): DYT_DBG_SKIP = bit mask of kernel classes whose launches are dropped (results
+// are garbage; the step time then shows what that class costs in the overlapped schedule, where serial durations do not add up)
+//   1 attention bwd  2 attention fwd  4 adapter weight gradients  8 tok_bwd  16 ln_bwd  32 ln_fwd  64 GEMMs with K = 64 or N = 64 (adapter)
+//   128 N = 768 GEMMs (K >= 256)  256 wide GEMMs (N >= 2304)
+//   1024: the mask applies to launches enqueued by the backward pass only (the forward pass, hence the kept-token counts, stays intact)
+extern int g_dbg_in_backward;
+inline bool dbg_skip(int bit) {
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("DYT_DBG_SKIP"); mask = e ? atoi(e) : 0; }
+    if ((mask & 1024) && !g_dbg_in_backward) return false;
+    return (mask & bit) != 0;
+}
 
 }  // namespace dyt

@@ -22,6 +22,7 @@
 
 namespace dyt {
 
+int g_dbg_in_backward = 0;   // measurement hook, see dbg_skip (kernels.h)
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -38,11 +39,13 @@ void set_error(const char* fmt, ...) {
 //   down_wT [768,RP]                       dgrad through down_proj (N = 768, K = RP)
 //   up_w    [768,RP] (cols >= r zero)      forward up-projection   (N = 768, K = RP)
 //   up_wT   [RP,768]                       dgrad through up_proj   (N = RP, K = 768)
+//   up_ws   [768,RP] = scale * up_w        the up-projection as the leading k-tile of the fc2 contraction (16-bit modes)
 //   down_b  [RP] fp32
 template <class AT>
 __global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t layer_stride, int64_t off_dw, int64_t off_db,
                                      int64_t off_uw, int r, AT* __restrict__ down_w, AT* __restrict__ down_wT,
-                                     AT* __restrict__ up_w, AT* __restrict__ up_wT, float* __restrict__ down_b) {
+                                     AT* __restrict__ up_w, AT* __restrict__ up_wT, float* __restrict__ down_b,
+                                     AT* __restrict__ up_ws, float scale) {
     const int l = blockIdx.y;
     const float* base = flat + (int64_t)l * layer_stride;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -61,6 +64,7 @@ __global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t lay
         const float uw = j < r ? base[off_uw + (int64_t)c * r + j] : 0.f;
         down_wT[(size_t)l * SZ + idx] = from_f32<AT>(dw);
         up_w[(size_t)l * SZ + idx] = from_f32<AT>(uw);
+        if (up_ws) up_ws[(size_t)l * SZ + idx] = from_f32<AT>(scale * uw);
     }
     if (idx < RP) down_b[l * RP + idx] = idx < r ? base[off_db + idx] : 0.f;
 }
@@ -147,7 +151,9 @@ struct dyt_ctx {
     std::vector<LayerW> W;
     // per-step AT copies of the adapters (all layers contiguous)
     void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
+    void* ad_up_ws = nullptr;   // 16-bit modes: scale * up_w (leading k-tile of the fc2 contraction)
     float* ad_down_b;
+    bool fc2_cat = true;        // 16-bit modes: adapter up-projection rides on the fc2 GEMM where no separate h is needed
     // trainable flat layout
     int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
     // video model (frames > 1): attentive pooling head, trainable
@@ -227,6 +233,7 @@ static void layout(dyt_ctx* c, bool dry) {
     c->ad_down_wT = carve_at(c, depth * RP * D, dry);
     c->ad_up_w = carve_at(c, depth * RP * D, dry);
     c->ad_up_wT = carve_at(c, depth * RP * D, dry);
+    c->ad_up_ws = c->prec != 0 ? carve_at(c, depth * RP * D, dry) : nullptr;
     c->ad_down_b = carve<float>(c, depth * RP, dry);
     c->slots.resize(cf.slots);
     for (int s = 0; s < cf.slots; ++s) {
@@ -566,11 +573,19 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             if (value < 0 || value > 24) { set_error("grad scale log2 %d out of range 0..24", value); return DYT_ERR_ARG; }
             c->gs = c->prec == DYT_PREC_FP32 ? 1.0f : (float)(1u << value);
             return DYT_OK;
+        case DYT_OPT_FC2_CAT: c->fc2_cat = value != 0; return DYT_OK;
+        case DYT_OPT_ATTN_BWD_FUSED: set_attn_bwd_fused(value); return DYT_OK;   // process-wide
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
             c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
     }
     set_error("unknown option %d", option);
+    return DYT_ERR_ARG;
+}
+
+extern "C" int dyt_set_global_option(int option, int value) {
+    if (option == DYT_OPT_ATTN_BWD_FUSED) { set_attn_bwd_fused(value); return DYT_OK; }
+    set_error("option %d is not process-wide", option);
     return DYT_ERR_ARG;
 }
 
@@ -615,11 +630,11 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     if (c->prec == 0)
         hipLaunchKernelGGL(prep_adapters_kernel<float>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (float*)c->ad_down_w, (float*)c->ad_down_wT, (float*)c->ad_up_w,
-                           (float*)c->ad_up_wT, c->ad_down_b);
+                           (float*)c->ad_up_wT, c->ad_down_b, (float*)nullptr, 0.f);
     else
         hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (bf16*)c->ad_down_w, (bf16*)c->ad_down_wT, (bf16*)c->ad_up_w,
-                           (bf16*)c->ad_up_wT, c->ad_down_b);
+                           (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)c->ad_up_ws, c->cfg.adapter_scale);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -813,6 +828,14 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN(2, 0, launch_ln_cls(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, S.ucls_at, B, s));
         // ---- adapter branch: x_out = u + scale * up(dropout(relu(down(u)))) -- independent of the
         //      gate / gather / fc1 chain below, so it runs on the pass's side stream until fc2 needs x_out
+        // 16-bit modes: wherever the MLP output h is not needed on its own (teacher pass, cls tail, inference) the
+        // up-projection is the leading k-tile of the fc2 contraction (x_out = u + [d_act | h1] [s Wup | W2]^T + b): one read
+        // of u and one write of x_out per row instead of two fp32 read-modify-write passes, and no up-projection launch.
+        // In a compacted pass that covers the kept rows; the dropped rows get their u + adapter(u) from an
+        // up-projection launch that skips the kept ones.  Training student passes keep the two-launch form: the gate
+        // gradient needs h = mlp(x) alone (saved by the fc2 epilogue).
+        const bool need_h = save && !complete && !tail;
+        const bool cat = c->fc2_cat && P != 0 && !masked_dense && !need_h && !sb;
         FORK(sb);
         {
             GemmArgs a; a.A = tail ? S.ucls_at : L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
@@ -823,12 +846,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1); a.seed_dev = seed_dev;
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
-        {
-            GemmArgs a; a.A = L.d_act; a.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
-            a.bias = base + c->off_ub; a.resid = L.u; a.out_f32 = xo; a.scale = c->cfg.adapter_scale;
-            a.row_map = tail ? c->cls_rows : nullptr;
-            RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_UP, a, s));
-        }
+        GemmArgs up; up.A = L.d_act; up.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); up.M = Mr; up.N = D; up.K = RP;
+        up.bias = base + c->off_ub; up.resid = L.u; up.out_f32 = xo; up.scale = c->cfg.adapter_scale;
+        up.row_map = tail ? c->cls_rows : nullptr;
+        if (!cat) RUN_ON(sb, 0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
         int* counts = S.counts + (size_t)l * B;
         if (use_gate) {
             GateArgs ga;
@@ -843,6 +864,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             ga.out_stride = depth * NP;
             ga.keep_local = L.keep_local; ga.counts = counts; ga.force_first = c->count_flops_tokens;
             RUN(2, 0, launch_gate(ga, s));
+        }
+        if (cat && !dense && !tail) {   // dropped tokens: x_out = u + adapter(u) (the kept ones are written by fc2 below)
+            up.row_mask = L.maskf;
+            RUN(0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
         }
         if (tail) {
             // nothing: T.xn already holds LN2 of the cls rows
@@ -868,7 +893,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.out_f32 = xo;
             a.row_map = tail ? c->cls_rows : (dense ? nullptr : L.row_src);
             a.row_mask = (masked_dense && !tail) ? L.maskf : nullptr;   // the cls token is never gated
-            a.h_out = (save && !complete && !tail) ? L.h : nullptr;     // cls rows carry no gate gradient
+            a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
+            if (cat) {
+                a.A2 = L.d_act; a.W2 = at_off(c, c->ad_up_ws, (size_t)l * RP * D);
+                a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
+                a.bias2 = base + c->off_ub; a.scale = c->cfg.adapter_scale; a.resid = L.u;
+            }
             RUN_GEMM(EPI_FC2, a);
         }
     }
@@ -1340,10 +1370,12 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_upper, hipEventDisableTiming));
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     }
+    g_dbg_in_backward = 1;
     rc = backward_impl(c, 0, trainable, c->dl_s, nullptr, c->dtok, nullptr, grad_flat, s, par ? c->ev_half_s : nullptr, split);
-    if (rc) return rc;
+    if (rc) { g_dbg_in_backward = 0; return rc; }
     if (par && c->ov_bwd_serial) { DYT_HIP_CHECK(hipEventRecord(c->ev_fork, s)); DYT_HIP_CHECK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
     rc = backward_impl(c, 1, trainable, c->dl_t, nullptr, nullptr, nullptr, gt, s2, par ? c->ev_half_t : c->ev_upper, split);
+    g_dbg_in_backward = 0;
     if (rc) return rc;
     if (par) {
         // upper part: summed on the aux stream as soon as both passes have left block `split`

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
 int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats, int rows,
                   hipStream_t s) {
     const int grid = (rows + 3) / 4;
+    if (dbg_skip(32)) return 0;
     if (precision == 0)
         hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, b, (float*)out, stats, rows);
     else
@@ -129,6 +130,7 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
                   float gs, hipStream_t s) {
+    if (dbg_skip(16)) return 0;
     if (precision == 0)
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx,
                            rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next, 1.0f, 1.0f);
@@ -858,6 +860,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s) {
     const int grid = (a.M + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK;
     if (nblocks_out) *nblocks_out = grid;
+    if (dbg_skip(8)) return 0;
     if (precision == 0) hipLaunchKernelGGL(tok_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(tok_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, a);
     LAUNCH_CHECK();
@@ -1138,6 +1141,7 @@ int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
     // one round of the 256 CUs (B=128: 6 x 50 = 300 workgroups would leave a 44-workgroup second round; 6 x 40 does not);
     // a pair is two workgroups per CU, which hides the staging latency of the single-product launch
     const int M = a[0].M, r = a[0].r;
+    if (dbg_skip(4)) return 0;
     if (n < 1 || n > 2 || (n == 2 && (a[1].M != M || a[1].r != r || a[1].partial == a[0].partial))) {
         set_error("launch_wgrad: bad pair");
         return -1;

@@ -148,7 +148,19 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                               misc.py:252-272).  Default: 0 in libdyt_hip.so (bf16 has fp32's exponent range), 12 in
  *                               libdyt_hip_f16.so.  Returned gradients are unscaled either way. */
 #define DYT_OPT_GRAD_SCALE_LOG2 5
+/*   DYT_OPT_FC2_CAT             1 (default): in the 16-bit modes the adapter's up-projection is computed as the leading
+ *                           k-tile of the fc2 contraction (x_out = u + [d_act | h][s Wup | W2]^T + b: one pass over the
+ *                           fp32 residual stream instead of two, no up-projection launch) wherever the MLP output is not
+ *                           needed on its own: teacher pass, cls tail, inference.  0: always two launches (reference op
+ *                           order, models/vision_transformer_IN21K.py:157-163).  fp32 mode: ignored (always two launches). */
+#define DYT_OPT_FC2_CAT 6
+/*   DYT_OPT_ATTN_BWD_FUSED      1 (default): 16-bit modes run the attention backward of a head (dQ and dK/dV) in ONE persistent
+ *                           kernel (q, dO, o read once; delta never leaves the chip); 0: two kernels (bit-identical results);
+ *                           2: the fused kernel with the per-wave k / v / o rows prefetched a head ahead.  PROCESS-wide. */
+#define DYT_OPT_ATTN_BWD_FUSED 7
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
+/* the process-wide options (DYT_OPT_ATTN_BWD_FUSED) without a context: unit entries such as dyt_attention() see them too */
+int dyt_set_global_option(int option, int value);
 
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library
  * keeps its own copies in the layouts/dtypes its kernels want (incl. transposes for dgrad).

@@ -141,7 +141,12 @@ def test_full_size_properties(precision):
         assert float((lc - lt).abs().max()) > 1e-4      # dropping tokens does change the logits ...
         # eval-mode masked-dense forward through the engine (same values as the compacted forward)
         lm, ts_m, _ = m._engine.forward(x, slot=0, training=False, masked_dense=True)
-        assert torch.equal(ts_m, ac["token_select"][..., 0])
+        # fp32: the two forms compute the same values bit for bit.  16-bit modes: the compacted inference pass adds the adapter's
+        # up-projection inside the fc2 contraction (DYT_OPT_FC2_CAT), the mask-multiplied pass in a launch of its own -> fp32
+        # round-off differences in x_out, i.e. a handful of tie-level decisions out of 128 x 2352
+        flips = int((ts_m != ac["token_select"][..., 0]).sum())
+        print("compact vs masked-dense eval forward, %s: %d of %d decisions differ" % (precision, flips, ts_m.numel()))
+        assert flips <= (0 if precision == "fp32" else 150), flips
         assert float((lm - lc).abs().max()) < tol, float((lm - lc).abs().max())
         for blk in m.blocks:                               # ... keep everything: student == teacher
             blk.mlp_token_select.mlp_head.bias.fill_(100.0)

@@ -676,7 +676,7 @@ def test_bench_multi_rank_code_path_with_one_rank():
               "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["unit"] == "images/s" and d["higher_is_better"] is True
+    assert d["dtype"] == "fp16" and d["data"] == "synthetic" and d["unit"] == "images/s" and d["higher_is_better"] is True
     assert d["config"]["parallelism"] == "dp1" and d["config"]["per_gpu_batch"] == 128 and d["config"]["global_batch"] == 128
     assert abs(d["config"]["keep_ratio_measured"] - 0.7) < 0.02
     assert abs(d["value"] - 128 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]

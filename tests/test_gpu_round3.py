@@ -1,0 +1,126 @@
+"""GPU parity tests added in round 3 (pytest -m gpu), all through the C ABI:
+  * the K-concatenated fc2 GEMM (adapter up-projection as the leading k-tile, DYT_OPT_FC2_CAT): the raw kernel forms bitwise
+    against the same contraction written as ONE plain GEMM over [A2 | A], and the whole step / inference forward with the
+    option on and off."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import synth  # noqa: E402
+from test_gpu_round2 import _bench_model, _grad_tol  # noqa: E402
+
+
+@pytest.mark.parametrize("M", [128, 3152, 17690, 25216])
+def test_gemm_leading_ktile_form_is_the_concatenated_gemm(M):
+    """C = A2 W2^T + A W^T with the second pair staged as k-tile 0 (csrc/gemm.hip CatArgs; the fc2 + adapter-up GEMM of the
+    16-bit modes: models/vision_transformer_IN21K.py:157-163 + models/dynamic_adapter.py:128-137 in one accumulator chain):
+    the 128x128 kernel, the 256x256 pipelined kernel and the product dispatch (row-split, both kernels) must give the
+    bits of the plain 128x128 GEMM over the K-concatenated operands [A2 | A], [W2 | W]."""
+    from _lib import check, lib, ptr, stream_ptr
+    N, K = 768, 3072
+    g = torch.Generator(device="cuda").manual_seed(M)
+    a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    a2 = torch.randn(M, 64, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    w2 = (torch.randn(N, 64, device="cuda", generator=g) * 0.05).bfloat16()
+    abuf = torch.cat([a.reshape(-1), a2.reshape(-1)]).contiguous()      # A2 behind A, W2 behind W (the raw hook's convention)
+    wbuf = torch.cat([w.reshape(-1), w2.reshape(-1)]).contiguous()
+    acat = torch.cat([a2, a], dim=1).contiguous()
+    wcat = torch.cat([w2, w], dim=1).contiguous()
+    ref = torch.zeros(2 * M, N, device="cuda", dtype=torch.bfloat16)
+    check(lib().dyt_gemm_bf16_raw(ptr(acat), ptr(wcat), ptr(ref), M, N, K + 64, 0, stream_ptr()))
+    torch.cuda.synchronize()
+    want = a2.float() @ w2.float().t() + a.float() @ w.float().t()
+    assert float((ref[:M].float() - want).abs().max() / want.abs().max()) < 1e-2
+    assert float(ref[M:].float().abs().max()) == 0.0
+    for variant in (40, 41, 42, 41, 42):
+        c = torch.zeros(2 * M, N, device="cuda", dtype=torch.bfloat16)
+        check(lib().dyt_gemm_bf16_raw(ptr(abuf), ptr(wbuf), ptr(c), M, N, K, variant, stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref), (M, variant, int((c != ref).sum()))
+
+
+def _step(prec, mode, cat, B=6):
+    import _lib
+    x, y = synth.make_batch(B, 100, seed=71)
+    g1, g2 = synth.make_noise(B, seed=72)
+    keep = synth.make_dropout_masks(B, 64, seed=73)
+    m, _ = _bench_model(prec, mode, B, 0.85, kind="test")
+    m.train()
+    eng = m.engine(B, torch.device("cuda", 0))
+    eng.set_option(_lib.OPT_FC2_CAT, cat)
+    ls = torch.empty(B, 100, device="cuda")
+    lt = torch.empty(B, 100, device="cuda")
+    ts = torch.zeros(B, 12, 196, device="cuda")
+    losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                              g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
+                              token_select=ts).clone()
+    m.eval()
+    with torch.no_grad():
+        le, ae = m(x.cuda())                       # inference: compacted student pass, no saved activations
+        lc, _ = m(x.cuda(), complete_model=True)
+    torch.cuda.synchronize()
+    names = [n for n, p in m.named_parameters() if synth.is_trainable(n)]
+    grads = {n: eng.trainable_view(n, dict(m.named_parameters())[n].shape, eng.grad).clone().cpu() for n in names}
+    out = dict(losses=losses.cpu(), ls=ls.cpu(), lt=lt.cpu(), ts=ts.cpu(), le=le.cpu(), lc=lc.cpu(), tse=ae["token_select"].cpu(), grads=grads)
+    del m, eng
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.parametrize("precision,mode", [("fp16", "compact"), ("bf16", "compact"), ("fp16", "masked"), ("fp32", "compact")])
+def test_fc2_leading_ktile_option_does_not_change_results(precision, mode):
+    """DYT_OPT_FC2_CAT on / off: the teacher pass, the cls tail and the inference forwards compute x_out = u + adapter + mlp in one
+    GEMM instead of two launches -- same masks, logits / losses / gradients within the 16-bit modes' own round-off (the fp32 mode
+    ignores the option: bitwise)."""
+    a, b = _step(precision, mode, 1), _step(precision, mode, 0)
+    assert torch.equal(a["ts"], b["ts"])
+    if precision == "fp32":
+        for k in ("losses", "ls", "lt", "le", "lc", "tse"):
+            assert torch.equal(a[k], b[k]), k
+        for n in a["grads"]:
+            assert torch.equal(a["grads"][n], b["grads"][n]), n
+        return
+    tol = 2e-3 if precision == "fp16" else 1.5e-2
+    assert float((a["ls"] - b["ls"]).abs().max()) < tol, float((a["ls"] - b["ls"]).abs().max())
+    assert float((a["lt"] - b["lt"]).abs().max()) < tol, float((a["lt"] - b["lt"]).abs().max())
+    assert float((a["lc"] - b["lc"]).abs().max()) < tol
+    flips = int((a["tse"] != b["tse"]).sum())
+    assert flips <= (2 if precision == "fp16" else 12), flips   # of 6 x 2352 eval-mode decisions; bf16 vs the oracle: 13 of 37 632
+    if flips == 0:
+        assert float((a["le"] - b["le"]).abs().max()) < tol, float((a["le"] - b["le"]).abs().max())
+    assert float((a["losses"][:5] - b["losses"][:5]).abs().max()) < tol * 5
+    for n, ga in a["grads"].items():
+        gb = b["grads"][n]
+        if gb.numel() == 1:
+            continue
+        e = float((ga - gb).norm() / (gb.norm() + 1e-20))
+        assert e < _grad_tol(n, precision), (n, e)
+
+
+@pytest.mark.parametrize("B", [1, 3, 128])
+def test_fused_attention_backward_is_bitwise_the_two_kernel_form(B):
+    """attn_bwd_fused_bf16_kernel (dK/dV phase and dQ phase of a head in one persistent workgroup pass, csrc/attention.hip) runs
+    the arithmetic of the two separate kernels on the same operands: dq, dk, dv must be the same bits, in both 16-bit operand
+    types, at 1 / 3 / 1536 (image, head) pairs per launch (B=128 = the bench size: 6 heads per persistent workgroup).
+    Reference op: Attention.forward's autograd backward, models/vision_transformer_IN21K.py:60-70."""
+    import _lib
+    from _lib import check, ptr, stream_ptr
+    g = torch.Generator(device="cuda").manual_seed(B)
+    qkv = torch.randn(B * 197, 2304, device="cuda", generator=g) * 1.5
+    dout = torch.randn(B * 197, 768, device="cuda", generator=g)
+    for fp16 in (False, True):
+        L = _lib.lib(fp16=fp16)
+        res = []
+        for mode in (0, 1, 2, 1):
+            check(L.dyt_set_global_option(_lib.OPT_ATTN_BWD_FUSED, mode))
+            out = torch.full((B * 197, 768), float("nan"), device="cuda")
+            dqkv = torch.full((B * 197, 2304), float("nan"), device="cuda")
+            check(L.dyt_attention(ptr(qkv), ptr(out), ptr(dout), ptr(dqkv), B, 1, stream_ptr()))
+            torch.cuda.synchronize()
+            res.append(dqkv.clone())
+        check(L.dyt_set_global_option(_lib.OPT_ATTN_BWD_FUSED, 1))
+        assert torch.isfinite(res[0]).all()
+        for r in res[1:]:
+            assert torch.equal(r, res[0]), (B, fp16, int((r != res[0]).sum()))

@@ -12,7 +12,7 @@ if os.environ.get("DYT_LIB_PATH"):
 import test_gpu_round2 as T
 B = 128
 mode = os.environ.get("PMODE", "compact")
-m, _ = T._bench_model("bf16", mode, B, 0.85)
+m, _ = T._bench_model(os.environ.get("PPREC", "bf16"), mode, B, 0.85)
 m.train()
 x, y = synth.make_batch(B, 100, seed=61)
 x, y = x.cuda(), y.cuda()
@@ -22,8 +22,13 @@ if os.environ.get("DYT_NO_OVERLAP"):
     eng.set_option(_lib.OPT_STREAM_OVERLAP, 0)
 if os.environ.get("DYT_OVERLAP"):
     eng.set_option(_lib.OPT_STREAM_OVERLAP, int(os.environ["DYT_OVERLAP"]))
+for kv in filter(None, os.environ.get("DYT_OPTS", "").split(",")):   # "6=0,2=1": dyt_ctx_set_option(option, value)
+    k, v = kv.split("=")
+    eng.set_option(int(k), int(v))
 def step(i):
     eng.step_fwd_bwd(x, y, 0.7, 2.0, 0.0, 0.0, seed=900 + i, masked_dense=(mode == "masked"))
+    if os.environ.get("PNOADAM"):
+        return
     _lib.check(eng.L.dyt_adamw(_lib.ptr(eng.flat), _lib.ptr(eng.grad), _lib.ptr(mm), _lib.ptr(vv), eng.n_train, i + 1, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, _lib.stream_ptr()))
 NS = int(os.environ.get("PSTEPS", "20"))
 for i in range(min(5, NS)):
