@@ -43,7 +43,7 @@ import synth  # noqa: E402
 STEP_GFLOP_AT_07 = 126.851   # SURVEY.md section 8d / BASELINE.md section 3, compact mode, r=64, C=100
 STEP_GFLOP_SLOPE = 42.542    # d(GFLOP)/d(keep ratio)
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # TFLOP/s dense MFMA, MI355X_MICROARCH.md
-TRAFFIC_JSON = os.path.join("round2", "gemm_traffic.json")
+TRAFFIC_JSON = os.path.join("round3", "gemm_traffic.json")
 
 
 class Cfg(dict):

@@ -743,7 +743,13 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     // Wide-N GEMMs against a frozen weight: the pre-shuffled-weight kernel (128x256 tiles, two workgroups per CU, the
     // weight never touches LDS).  In the step: 28.10 vs 28.40 ms with the 256x256 kernel; routing the N = 768 GEMMs
     // through it as well gains another 0.5 % wall time but costs 8 % serial GEMM time, so they keep the split-row scheme.
-    if (a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) {
+    // K = 768, N = 768 plain-store GEMMs (proj dgrad) take this kernel as well: with only 12 k-steps the 256x256 kernel's exposed
+    // prologue / epilogue (one workgroup per CU) weighs most: 45 vs 53.5 us serial.  (DYT_BPRE_K768: 0 off, 1 = every K = 768 GEMM
+    // with a pre-shuffled weight, i.e. the proj forward too -- measured 81.7 vs 73.3 us for that one, and the row kernels that read
+    // its fp32 output right after it got slower; 2 = default: those without a residual epilogue)
+    static const int bpre_k768 = getenv("DYT_BPRE_K768") ? atoi(getenv("DYT_BPRE_K768")) : 2;
+    const bool k768 = a.K == D && (bpre_k768 == 1 || (bpre_k768 == 2 && std::is_same<Epi, EpiStoreAT<bf16>>::value));
+    if (a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && (a.N >= g_big_tile_min_n || k768) && a.M >= 2048) {
         GemmArgs b = a; b.W = a.Wp;
         return launch_bf16_bpre<0>(b, epi, s);
     }

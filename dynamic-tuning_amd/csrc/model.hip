@@ -99,6 +99,7 @@ struct LayerW {  // frozen, library-owned
     float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;
     void *qkv_w, *qkv_wT, *proj_w, *proj_wT, *fc1_w, *fc1_wT, *fc2_w, *fc2_wT;
     void *qkv_wp = nullptr, *fc1_wp = nullptr, *fc2_wTp = nullptr;   // bf16 mode: MFMA-fragment-order twins (gemm_bpre.h)
+    void *proj_wp = nullptr, *proj_wTp = nullptr;
 };
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
@@ -227,6 +228,7 @@ static void layout(dyt_ctx* c, bool dry) {
         if (c->prec != 0) {
             w.qkv_wp = carve_at(c, (size_t)3 * D * D, dry); w.fc1_wp = carve_at(c, (size_t)DM * D, dry);
             w.fc2_wTp = carve_at(c, (size_t)DM * D, dry);
+            w.proj_wp = carve_at(c, (size_t)D * D, dry); w.proj_wTp = carve_at(c, (size_t)D * D, dry);
         }
     }
     c->ad_down_w = carve_at(c, depth * RP * D, dry);
@@ -502,7 +504,12 @@ extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src
             return rc;
         }
         case DYT_P_QKV_B: return copy_f32(w->qkv_b, src, 3 * D, s);
-        case DYT_P_PROJ_W: return set_matrix(c, src, w->proj_w, w->proj_wT, D, D, s);
+        case DYT_P_PROJ_W: {
+            int rc = set_matrix(c, src, w->proj_w, w->proj_wT, D, D, s);
+            if (!rc && w->proj_wp) rc = launch_preshuffle_w(w->proj_w, w->proj_wp, D, D, s);
+            if (!rc && w->proj_wTp) rc = launch_preshuffle_w(w->proj_wT, w->proj_wTp, D, D, s);
+            return rc;
+        }
         case DYT_P_PROJ_B: return copy_f32(w->proj_b, src, D, s);
         case DYT_P_LN2_W: return copy_f32(w->ln2_w, src, D, s);
         case DYT_P_LN2_B: return copy_f32(w->ln2_b, src, D, s);
@@ -816,7 +823,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             }
             RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
             {
-                GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
+                GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
                 a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
                 RUN_GEMM(EPI_BIAS_RESID, a);
             }
@@ -1209,7 +1216,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         if (first) break;
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
-            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.M = M; a.N = D; a.K = D;
+            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.Wp = W.proj_wTp; a.M = M; a.N = D; a.K = D;
             a.out_at = T.dO;
             POISON(16, T.dO, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););

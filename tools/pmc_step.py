@@ -16,17 +16,24 @@ def family(k):
         epi = re.search(r"Epi[A-Za-z0-9]+", k)
         tile = re.search(r"ILi(\d+)ELi(\d+)E", k)
         return "gemm %s%s %s" % (m.group(1), " %sx%s" % tile.groups() if tile and m.group(1) == "nt" else "", epi.group(0) if epi else "")
-    for n in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "wgrad_bf16", "wgrad_reduce", "tok_bwd", "ln_bwd", "ln_fwd", "ln_gather", "gate_logits",
+    for n in ("attn_fwd", "attn_bwd_fused", "attn_bwd_dq", "attn_bwd_dkv", "wgrad_bf16", "wgrad_reduce", "tok_bwd", "ln_bwd", "ln_fwd", "ln_gather", "gate_logits",
               "gate_select", "bwd_prep", "reduce_partials", "head_", "loss_", "adamw", "im2col", "prep_adapters", "fillBuffer", "copyBuffer"):
         if n in k:
             return n.rstrip("_")
     return "other"
 
 
+excluded_GB = 0.0   # the context's one-time arena memset (15 GB, dyt_ctx_create) is not part of a step
+
+
 def collect(path, counters):
+    global excluded_GB
     acc = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] not in counters:
+            continue
+        if "fillBuffer" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE" and float(r["Counter_Value"]) * 1024 > 1e9:
+            excluded_GB += float(r["Counter_Value"]) * 1024 / 1e9
             continue
         d = acc.setdefault(family(r["Kernel_Name"]), {"n": 0})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -57,7 +64,8 @@ for fam, ms in dur.items():
         rows[fam]["ms_per_step_under_the_profiler"] = round(ms / steps, 3)
         rows[fam]["TB_per_s"] = round((rows[fam]["fetch_GB_per_step"] + rows[fam]["write_GB_per_step"]) / max(ms / steps, 1e-9), 2)
 out = {"steps_profiled": steps, "hbm_GB_per_step": round(tot / 1e9, 2), "kernel_ms_per_step_under_the_profiler": round(sum(dur.values()) / steps, 2),
-       "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported; KiB -> bytes; separate --pmc passes", "families": dict(sorted(rows.items(), key=lambda kv: -(kv[1]["fetch_GB_per_step"] + kv[1]["write_GB_per_step"])))}
+       "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported; KiB -> bytes; separate --pmc passes",
+       "excluded_one_time_arena_memset_GB": round(excluded_GB, 2), "families": dict(sorted(rows.items(), key=lambda kv: -(kv[1]["fetch_GB_per_step"] + kv[1]["write_GB_per_step"])))}
 json.dump(out, open(sys.argv[6], "w"), indent=1)
 mf = collect(sys.argv[4], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])
 res, tb, ta = {}, 0.0, 0.0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Whole-step counter evidence (north_star: "rocprof MFMA-utilisation and HBM GB/s against gfx950 peak"): three SEPARATE rocprofv3 --pmc
 # passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE; only --kernel-trace next to them, as MI355X_MICROARCH.md
-# prescribes) over tools/probes/ab_step.py = 4 full fine-tune steps at B=128, bf16, compact, no calibration forwards.
+# prescribes) over tools/probes/ab_step.py = 4 full fine-tune steps at B=128, compact, no calibration forwards (PPREC=fp16|bf16 selects the operand type, default bf16).
 # usage (GPU box, repo root): tools/pmc_step.sh <tag>     -> gpurun_out/<tag>_step_traffic.json, gpurun_out/<tag>_step_mfma.json
 tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
