@@ -107,6 +107,7 @@ struct LayerS {  // saved activations of one pass
     float *lse, *u, *soft, *maskf;
     void* h;
     int *keep_local, *offsets, *total, *row_src, *dst_of;
+    bool h_has_adapter = false;   // h = mlp(x) + s up(d_act) + s b_up (fc2 carried the up-projection, DYT_OPT_FC2_CAT)
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
@@ -839,10 +840,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // up-projection is the leading k-tile of the fc2 contraction (x_out = u + [d_act | h1] [s Wup | W2]^T + b): one read
         // of u and one write of x_out per row instead of two fp32 read-modify-write passes, and no up-projection launch.
         // In a compacted pass that covers the kept rows; the dropped rows get their u + adapter(u) from an
-        // up-projection launch that skips the kept ones.  Training student passes keep the two-launch form: the gate
-        // gradient needs h = mlp(x) alone (saved by the fc2 epilogue).
+        // up-projection launch that skips the kept ones.  In a training student pass the saved MLP output h then includes the
+        // adapter; the gate gradient <g, mlp(x)> is recovered in tok_bwd by subtracting <g, adapter(x)>, which the adapter's own
+        // backward operands give for 128 B per token (TokBwdArgs::cat_*).  The masked mode keeps the two-launch form.
         const bool need_h = save && !complete && !tail;
-        const bool cat = c->fc2_cat && P != 0 && !masked_dense && !need_h && !sb;
+        const bool cat = c->fc2_cat && P != 0 && !masked_dense;
+        L.h_has_adapter = cat && need_h;   // the saved "MLP output" of this block then includes the adapter: tok_bwd corrects <g, h>
         FORK(sb);
         {
             GemmArgs a; a.A = tail ? S.ucls_at : L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
@@ -872,10 +875,6 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             ga.keep_local = L.keep_local; ga.counts = counts; ga.force_first = c->count_flops_tokens;
             RUN(2, 0, launch_gate(ga, s));
         }
-        if (cat && !dense && !tail) {   // dropped tokens: x_out = u + adapter(u) (the kept ones are written by fc2 below)
-            up.row_mask = L.maskf;
-            RUN(0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
-        }
         if (tail) {
             // nothing: T.xn already holds LN2 of the cls rows
         } else if (!dense) {
@@ -894,7 +893,11 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr;
             RUN_GEMM(EPI_FC1, a);
         }
-        JOIN(sb);  // x_out now holds u + adapter(u)
+        JOIN(sb);  // x_out now holds u + adapter(u) (two-launch form) / d_act is complete
+        if (cat && !dense && !tail) {   // dropped tokens: x_out = u + adapter(u) (the kept ones are written by fc2 below)
+            up.row_mask = L.maskf;
+            RUN(0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
+        }
         {
             GemmArgs a; a.A = T.h1; a.W = W.fc2_w; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;
             a.out_f32 = xo;
@@ -1192,6 +1195,10 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.g_cls = tail ? S.gcls : nullptr;
             a.dad = dad_at ? T.dad : nullptr;
             a.gs = gs; a.inv_gs = inv_gs;
+            if (L.h_has_adapter && student && !tail) {
+                a.cat_dact = L.d_act; a.cat_ddz = T.ddz; a.cat_bup = base + c->off_ub;
+                a.cat_scale = scale; a.cat_ddz_scale = 1.0f / (inv_keep * gs);
+            }
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;

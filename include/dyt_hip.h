@@ -150,8 +150,8 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
 #define DYT_OPT_GRAD_SCALE_LOG2 5
 /*   DYT_OPT_FC2_CAT             1 (default): in the 16-bit modes the adapter's up-projection is computed as the leading
  *                           k-tile of the fc2 contraction (x_out = u + [d_act | h][s Wup | W2]^T + b: one pass over the
- *                           fp32 residual stream instead of two, no up-projection launch) wherever the MLP output is not
- *                           needed on its own: teacher pass, cls tail, inference.  0: always two launches (reference op
+ *                           fp32 residual stream instead of two, no up-projection launch) in every compacted or
+ *                           complete pass (training student pass: the gate gradient is corrected for the adapter term).  0: always two launches (reference op
  *                           order, models/vision_transformer_IN21K.py:157-163).  fp32 mode: ignored (always two launches). */
 #define DYT_OPT_FC2_CAT 6
 /*   DYT_OPT_ATTN_BWD_FUSED      1 (default): 16-bit modes run the attention backward of a head (dQ and dK/dV) in ONE persistent

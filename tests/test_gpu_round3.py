@@ -71,9 +71,10 @@ def _step(prec, mode, cat, B=6):
 
 @pytest.mark.parametrize("precision,mode", [("fp16", "compact"), ("bf16", "compact"), ("fp16", "masked"), ("fp32", "compact")])
 def test_fc2_leading_ktile_option_does_not_change_results(precision, mode):
-    """DYT_OPT_FC2_CAT on / off: the teacher pass, the cls tail and the inference forwards compute x_out = u + adapter + mlp in one
-    GEMM instead of two launches -- same masks, logits / losses / gradients within the 16-bit modes' own round-off (the fp32 mode
-    ignores the option: bitwise)."""
+    """DYT_OPT_FC2_CAT on / off: every compacted / complete pass computes x_out = u + adapter + mlp in one GEMM instead of two
+    launches (training student pass: the saved MLP output then includes the adapter and tok_bwd subtracts <g, adapter> from the
+    gate gradient) -- same training masks, logits / losses / gradients (the gate's included) within the 16-bit modes' own
+    round-off; the masked mode and the fp32 mode keep the two-launch form (fp32: bitwise)."""
     a, b = _step(precision, mode, 1), _step(precision, mode, 0)
     assert torch.equal(a["ts"], b["ts"])
     if precision == "fp32":
