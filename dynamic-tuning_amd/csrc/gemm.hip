@@ -748,7 +748,8 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     // with a pre-shuffled weight, i.e. the proj forward too -- measured 81.7 vs 73.3 us for that one, and the row kernels that read
     // its fp32 output right after it got slower; 2 = default: those without a residual epilogue)
     static const int bpre_k768 = getenv("DYT_BPRE_K768") ? atoi(getenv("DYT_BPRE_K768")) : 2;
-    const bool k768 = a.K == D && (bpre_k768 == 1 || (bpre_k768 == 2 && std::is_same<Epi, EpiStoreAT<bf16>>::value));
+    static const int bpre_maxk = getenv("DYT_BPRE_STORE_MAXK") ? atoi(getenv("DYT_BPRE_STORE_MAXK")) : D;   // measurement knob: plain-store N = 768 GEMMs up to this K
+    const bool k768 = (a.K == D && bpre_k768 == 1) || (bpre_k768 == 2 && std::is_same<Epi, EpiStoreAT<bf16>>::value && a.K <= bpre_maxk);
     if (a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && (a.N >= g_big_tile_min_n || k768) && a.M >= 2048) {
         GemmArgs b = a; b.W = a.Wp;
         return launch_bf16_bpre<0>(b, epi, s);

@@ -231,9 +231,24 @@ struct WgradArgs {
     float* out_xsum; float alpha_x;
     float* out_ysum = nullptr; float alpha_y = 0.f;   // out_ysum[j] += alpha_y * sum_m Y[m][j], j < r
 };
+// Reductions of per-chunk partials deferred to ONE batched launch (the backward pass queues the adapter weight-gradient and the
+// gate-gradient reductions of several blocks -- each with its own partial buffer -- and flushes them where the gradients have to
+// be final: 36 latency-bound launches per pass become 4).  Fixed summation order per output, as the immediate form.
+struct WgReduceDesc {
+    const float* partial; float* out_w; int sc, sj; float alpha; float* out_xsum; float alpha_x; float* out_ysum; float alpha_y;
+    int nchunks;
+};
+struct ReduceQueue {
+    static constexpr int MAX_WG = 32, MAX_TOK = 16;
+    WgReduceDesc wg[MAX_WG]; int n_wg = 0; int r = 0;
+    const float* tok_partial[MAX_TOK]; float* tok_out[MAX_TOK]; int tok_nparts[MAX_TOK]; int n_tok = 0;
+};
 int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s);
-// two products with the same M and r (separate `partial` buffers) as one launch + one reduce launch
-int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s);
+// two products with the same M and r (separate `partial` buffers) as one launch + one reduce launch (defer: queued instead)
+int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s, ReduceQueue* defer = nullptr);
+// queue out[i] += sum_p partial[p * 769 + i], i < 769 (the gate weight + bias gradient partials of tok_bwd)
+int queue_tok_reduce(ReduceQueue& q, const float* partial, int nparts, float* out);
+int flush_reductions(ReduceQueue& q, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // video model: attentive pooling head (pool.hip)
 // ------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ struct LayerW {  // frozen, library-owned
     float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;
     void *qkv_w, *qkv_wT, *proj_w, *proj_wT, *fc1_w, *fc1_wT, *fc2_w, *fc2_wT;
     void *qkv_wp = nullptr, *fc1_wp = nullptr, *fc2_wTp = nullptr;   // bf16 mode: MFMA-fragment-order twins (gemm_bpre.h)
-    void *proj_wp = nullptr, *proj_wTp = nullptr;
+    void *proj_wp = nullptr, *proj_wTp = nullptr, *qkv_wTp = nullptr, *fc1_wTp = nullptr;
 };
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
@@ -129,6 +129,7 @@ struct Slot {
     hipEvent_t ev_f = nullptr, ev_j = nullptr;
     bool no_branch = false;              // this pass runs without its adapter side stream (see dyt_step_fwd_bwd)
     std::vector<LayerS> L;
+    std::vector<float*> wg_part, wg_part2, tok_part;   // per-layer partial buffers: their reductions are batched (ReduceQueue)
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
     int* counts = nullptr;   // [depth*B]
     void* ucls_at = nullptr; // last block: AT(u[cls rows]) [B,768] (adapter-down operand, kept for its wgrad)
@@ -230,6 +231,7 @@ static void layout(dyt_ctx* c, bool dry) {
             w.qkv_wp = carve_at(c, (size_t)3 * D * D, dry); w.fc1_wp = carve_at(c, (size_t)DM * D, dry);
             w.fc2_wTp = carve_at(c, (size_t)DM * D, dry);
             w.proj_wp = carve_at(c, (size_t)D * D, dry); w.proj_wTp = carve_at(c, (size_t)D * D, dry);
+            w.qkv_wTp = carve_at(c, (size_t)3 * D * D, dry); w.fc1_wTp = carve_at(c, (size_t)DM * D, dry);
         }
     }
     c->ad_down_w = carve_at(c, depth * RP * D, dry);
@@ -305,6 +307,13 @@ static void layout(dyt_ctx* c, bool dry) {
         T.tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
         T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
         T.wg_partial2 = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
+        Slot& S = c->slots[sl];
+        S.wg_part.resize(depth); S.wg_part2.resize(depth); S.tok_part.resize(depth);
+        for (size_t l = 0; l < depth; ++l) {
+            S.wg_part[l] = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
+            S.wg_part2[l] = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
+            S.tok_part[l] = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
+        }
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
     c->cls_rows = carve<int>(c, B, dry);
@@ -502,6 +511,7 @@ extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src
         case DYT_P_QKV_W: {
             int rc = set_matrix(c, src, w->qkv_w, w->qkv_wT, 3 * D, D, s);
             if (!rc && w->qkv_wp) rc = launch_preshuffle_w(w->qkv_w, w->qkv_wp, 3 * D, D, s);
+            if (!rc && w->qkv_wTp) rc = launch_preshuffle_w(w->qkv_wT, w->qkv_wTp, D, 3 * D, s);
             return rc;
         }
         case DYT_P_QKV_B: return copy_f32(w->qkv_b, src, 3 * D, s);
@@ -517,6 +527,7 @@ extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src
         case DYT_P_FC1_W: {
             int rc = set_matrix(c, src, w->fc1_w, w->fc1_wT, DM, D, s);
             if (!rc && w->fc1_wp) rc = launch_preshuffle_w(w->fc1_w, w->fc1_wp, DM, D, s);
+            if (!rc && w->fc1_wTp) rc = launch_preshuffle_w(w->fc1_wT, w->fc1_wTp, D, DM, s);
             return rc;
         }
         case DYT_P_FC1_B: return copy_f32(w->fc1_b, src, DM, s);
@@ -1110,6 +1121,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         { const int l = depth; CK("head_bwd g", cls_tail ? S.gcls : g, (size_t)(cls_tail ? B : M) * D * 4); CK("head_bwd dW", grad + c->off_hw, (size_t)c->cfg.num_classes * D * 4); }
     }
 
+    ReduceQueue rq;   // adapter weight-gradient / gate-gradient reductions: queued per block, flushed where the gradients must be final
     bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
     for (int l = depth - 1; l >= 0; --l) {
         const LayerW& W = c->W[l];
@@ -1147,15 +1159,15 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {   // both weight gradients (+ the two bias gradients as ones columns / rows) in one launch
             WgradArgs w[2];
             WgradArgs& a = w[0];
-            a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = T.wg_partial;
+            a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = S.wg_part[l];
             a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale * inv_gs;       // up_proj.weight [768, r]  (X = g_at carries gs)
             a.out_xsum = gbase + c->off_ub; a.alpha_x = scale * inv_gs;                      // up_proj.bias
             WgradArgs& b = w[1];
-            b.X = tail ? S.ucls_at : L.u_at; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = T.wg_partial2;
+            b.X = tail ? S.ucls_at : L.u_at; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = S.wg_part2[l];
             b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = inv_gs;      // down_proj.weight [r, 768]  (Y = ddz carries gs)
             b.out_xsum = nullptr; b.alpha_x = 0.f;
             b.out_ysum = gbase + c->off_db; b.alpha_y = inv_gs;                     // down_proj.bias
-            ISO(32, RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s)););
+            ISO(32, RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s, sb ? nullptr : &rq)););
             CK("wgrad up_w", gbase + c->off_uw, (size_t)D * r * 4); CK("wgrad down_w", gbase + c->off_dw, (size_t)D * r * 4);
         }
         // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
@@ -1169,7 +1181,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
             }
             {
-                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
+                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
                 if (dense) POISON(2, T.dA2, (size_t)Mr * D * c->at);
                 ISO(8, RUN_GEMM(EPI_STORE_AT, a););
                 CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * c->at);
@@ -1202,11 +1214,11 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
-            a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = T.tok_partial; a.M = M; a.write_du = !first;
+            a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = S.tok_part[l]; a.M = M; a.write_du = !first;
             int nblk = 0;
             if (a.du_at) POISON(8, T.du_at, (size_t)M * D * c->at);
-            ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s));
-            if (student) RUN(2, 0, launch_reduce_partials(T.tok_partial, nblk, D + 1, gbase + c->off_gw, D + 1, 1.0f, s)););
+            ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s)););
+            if (student && !dbg_skip(8)) { int _r = queue_tok_reduce(rq, S.tok_part[l], nblk, gbase + c->off_gw); if (_r) return _r; }
             if (a.write_du) CK("tok_bwd g", g, (size_t)M * D * 4);
             if (a.dmask) CK("tok_in dmask", T.dmask, (size_t)M * 4);          // what tok_bwd consumed (unchanged by it)
             if (a.dA2) CK("tok_in dA2", T.dA2, (size_t)Mr * D * c->at);
@@ -1214,6 +1226,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             if (a.du_at) CK("tok_bwd du_at", T.du_at, (size_t)M * D * c->at);
             if (student) CK("tok_bwd gate grad", gbase + c->off_gw, (size_t)(D + 1) * 4);
         }
+        if (l == split || first || dbg_ck_on()) RUN(2, 0, flush_reductions(rq, s));   // the gradients of blocks >= l are final after this
         if (ev_split && l == split) {
             // video model: the pooling head's k / v weight gradients (side stream, part 0 of the flat buffer) must be final
             // before the "upper gradients are final" event that the gradient sum and the early all-reduce wait for
@@ -1234,7 +1247,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s)););
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
-            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
+            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
             POISON(1, T.dxn, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * c->at);

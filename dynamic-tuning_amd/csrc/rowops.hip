@@ -909,6 +909,36 @@ int launch_reduce_partials(const float* partial, int nparts, int stride, float* 
     return 0;
 }
 
+// the same for several (partial, out) pairs in one launch: blockIdx.y selects the pair
+struct TokReduceBatch { const float* partial[ReduceQueue::MAX_TOK]; float* out[ReduceQueue::MAX_TOK]; int nparts[ReduceQueue::MAX_TOK]; };
+__global__ __launch_bounds__(256) void reduce_partials_batch_kernel(TokReduceBatch b, int stride, int n) {
+    __shared__ float red[8][32];
+    const float* __restrict__ partial = b.partial[blockIdx.y];
+    const int nparts = b.nparts[blockIdx.y];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    float acc = 0.f;
+    if (i < n) {
+        const int per = (nparts + 7) / 8;
+        const int p0 = grp * per, p1 = min(nparts, p0 + per);
+#pragma unroll 4
+        for (int p = p0; p < p1; ++p) acc += partial[(size_t)p * stride + i];
+    }
+    red[grp][o] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][o];
+        b.out[blockIdx.y][i] += t;
+    }
+}
+int queue_tok_reduce(ReduceQueue& q, const float* partial, int nparts, float* out) {
+    if (q.n_tok >= ReduceQueue::MAX_TOK) { set_error("reduce queue full"); return -1; }
+    q.tok_partial[q.n_tok] = partial; q.tok_out[q.n_tok] = out; q.tok_nparts[q.n_tok] = nparts; ++q.n_tok;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // adapter weight gradients:  C[c][j] = sum_m X[m][c] Y[m][j]   (+ column sums of X in j = 64)
 // ------------------------------------------------------------------------------------------
@@ -1149,8 +1179,40 @@ __global__ void wgrad_reduce_kernel(WgOutPair outs, int nchunks, int r) {
     else if (o.out_xsum) o.out_xsum[c] += o.alpha_x * acc;
 }
 
+// the reduce of several products (each with its own partial buffer and chunk count) in one launch: blockIdx.y selects the product
+struct WgReduceBatch { WgReduceDesc e[ReduceQueue::MAX_WG]; };
+__global__ void wgrad_reduce_batch_kernel(WgReduceBatch b, int r) {
+    const WgReduceDesc& o = b.e[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (D + 1) * (r + 1)) return;
+    const int c = idx / (r + 1), j = idx - c * (r + 1);
+    const int col = j < r ? j : 64;
+    if (c == D && j == r) return;
+    float acc = 0.f;
+    for (int p = 0; p < o.nchunks; ++p) acc += o.partial[((size_t)p * WG_ROWS + c) * WG_J + col];
+    if (c == D) { if (o.out_ysum) o.out_ysum[j] += o.alpha_y * acc; }
+    else if (j < r) o.out_w[(size_t)c * o.sc + (size_t)j * o.sj] += o.alpha * acc;
+    else if (o.out_xsum) o.out_xsum[c] += o.alpha_x * acc;
+}
+int flush_reductions(ReduceQueue& q, hipStream_t s) {
+    if (q.n_wg > 0) {
+        WgReduceBatch b;
+        for (int i = 0; i < q.n_wg; ++i) b.e[i] = q.wg[i];
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(((D + 1) * (q.r + 1) + 255) / 256, q.n_wg), dim3(256), 0, s, b, q.r);
+        q.n_wg = 0;
+    }
+    if (q.n_tok > 0) {
+        TokReduceBatch b;
+        for (int i = 0; i < q.n_tok; ++i) { b.partial[i] = q.tok_partial[i]; b.out[i] = q.tok_out[i]; b.nparts[i] = q.tok_nparts[i]; }
+        hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3((D + 1 + 31) / 32, q.n_tok), dim3(256), 0, s, b, D + 1, D + 1);
+        q.n_tok = 0;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // one or two products (same M and r; separate partial buffers) in one launch + one reduce launch
-int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
+int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s, ReduceQueue* defer) {
     // tokens per workgroup: at least WG_CHUNK, and large enough that the (channel blocks x chunks) grid of ONE product is
     // one round of the 256 CUs (B=128: 6 x 50 = 300 workgroups would leave a 44-workgroup second round; 6 x 40 does not);
     // a pair is two workgroups per CU, which hides the staging latency of the single-product launch
@@ -1182,10 +1244,20 @@ int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s) {
         }
         hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks, n), dim3(256), extra, s, src, M, chunk);
     }
+    if (defer) {
+        if (defer->n_wg + n > ReduceQueue::MAX_WG || (defer->n_wg > 0 && defer->r != r)) { set_error("reduce queue full / mixed ranks"); return -1; }
+        defer->r = r;
+        for (int i = 0; i < n; ++i) {
+            const WgOut& o = outs.p[i];
+            defer->wg[defer->n_wg++] = WgReduceDesc{o.partial, o.out_w, o.sc, o.sj, o.alpha, o.out_xsum, o.alpha_x, o.out_ysum, o.alpha_y, nchunks};
+        }
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(((D + 1) * (r + 1) + 255) / 256, n), dim3(256), 0, s, outs, nchunks, r);
     LAUNCH_CHECK();
     return 0;
 }
-int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) { return launch_wgrad(precision, &a, 1, s); }
+int launch_wgrad(int precision, const WgradArgs& a, hipStream_t s) { return launch_wgrad(precision, &a, 1, s, nullptr); }
 
 }  // namespace dyt

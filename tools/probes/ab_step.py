@@ -5,9 +5,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_
 import torch
 import _lib, synth
 if os.environ.get("DYT_LIB_PATH"):
-    _lib.LIB_PATH = os.environ["DYT_LIB_PATH"]
+    if os.environ.get("PPREC") == "fp16":
+        _lib.LIB_PATH_F16 = os.environ["DYT_LIB_PATH"]   # an IEEE-half build (libdyt_hip_f16.so twin)
+    else:
+        _lib.LIB_PATH = os.environ["DYT_LIB_PATH"]
     L = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
-    probe = ctypes.CDLL(_lib.LIB_PATH)
+    probe = ctypes.CDLL(os.environ["DYT_LIB_PATH"])
     _lib.SYMBOLS = {k: v for k, v in _lib.SYMBOLS.items() if hasattr(probe, k)}
 import test_gpu_round2 as T
 B = 128
