@@ -150,13 +150,24 @@ template <class AT, bool PLAIN>
 struct EpiFc2 {
     const float* bias; float* x; const int* row_map; const float* row_mask; AT* h_out;
     const float* resid; const float* bias2; float scale2;
-    typedef Bias4 Col;
+    // b: what is added to the accumulator for x (fc2 bias + s * up-projection bias); hb: the same for the saved MLP output h_out
+    // (fc2 bias only: with the up-projection riding on the contraction h_out = mlp(x) + s up_nobias(d_act), and tok_bwd takes
+    // <g, s up_nobias(d_act)> back out of the gate gradient -- without the bias term it needs no 768-wide dot for that)
+    struct ColH { float b[4]; float hb[4]; };
+    typedef typename std::conditional<PLAIN, Bias4, ColH>::type Col;
     struct PreG { int dst; float m; Raw4<float> r; };
     typedef typename std::conditional<PLAIN, Raw4<float>, PreG>::type Pre;
     __device__ __forceinline__ Col col_init(int col) const {
-        Col c = load_bias4(bias, col);
+        Col c;
+        const Bias4 c1 = load_bias4(bias, col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c.b[i] = c1.b[i];
+        if constexpr (!PLAIN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c.hb[i] = c1.b[i];
+        }
         if (bias2) {
-            const Col c2 = load_bias4(bias2, col);
+            const Bias4 c2 = load_bias4(bias2, col);
 #pragma unroll
             for (int i = 0; i < 4; ++i) c.b[i] = fmaf(scale2, c2.b[i], c.b[i]);
         }
@@ -175,12 +186,13 @@ struct EpiFc2 {
     }
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         const float h0 = a[0] + c.b[0], h1 = a[1] + c.b[1], h2 = a[2] + c.b[2], h3 = a[3] + c.b[3];
-        if (h_out) store4_nt(h_out + (size_t)row * D + col, h0, h1, h2, h3);   // read again only by the backward pass
         float r[4];
         if constexpr (PLAIN) {
+            if (h_out) store4_nt(h_out + (size_t)row * D + col, h0, h1, h2, h3);   // read again only by the backward pass
             p.get(r);
             store4(x + (size_t)row * D + col, r[0] + h0, r[1] + h1, r[2] + h2, r[3] + h3);
         } else {
+            if (h_out) store4_nt(h_out + (size_t)row * D + col, a[0] + c.hb[0], a[1] + c.hb[1], a[2] + c.hb[2], a[3] + c.hb[3]);
             p.r.get(r);
             store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);
         }

@@ -208,13 +208,13 @@ struct TokBwdArgs {
     const void* dad = nullptr;     // [M,768] AT adapter dgrad to add to du (null: already accumulated into du)
     const float* g_cls = nullptr;  // last block: incoming gradient exists for the cls rows only ([B,768]);
                                    // du/dA2 are then read as (n == 0 ? g_cls[b] / dA2[b] : 0)
-    // The saved MLP output of a kept token includes the adapter (h' = mlp(x) + s up(d_act) + s b_up: the fc2 GEMM carried the
-    // up-projection as its leading k-tile), so dmask = <g, h'> is too large by <g, s up(d_act) + s b_up>.  With ddz = the
-    // up-projection dgrad (g s W_up masked by relu' / dropout, times inv_keep and gs) that is <d_act, ddz> / (inv_keep gs) +
-    // s <g, b_up>: subtracted here, per kept token.  cat_dact == null: h is the MLP output alone.
+    // The saved MLP output of a kept token includes the adapter's weight term (h' = mlp(x) + s d_act W_up^T: the fc2 GEMM carried
+    // the up-projection as its leading k-tile; the fc2 epilogue leaves s b_up out of what it saves), so dmask = <g, h'> is too
+    // large by <g, s d_act W_up^T>.  With ddz = the up-projection dgrad (g s W_up masked by relu' / dropout, times inv_keep and
+    // gs) that is <d_act, ddz> / (inv_keep gs): subtracted here, per kept token.  cat_dact == null: h is the MLP output alone.
     const void* cat_dact = nullptr;   // [M, 64] AT (token-indexed)
     const void* cat_ddz = nullptr;    // [M, 64] AT
-    const float* cat_bup = nullptr;   // [768]
+    const float* cat_bup = nullptr;   // unused (kept for ABI stability of the struct)
     float cat_scale = 0.f, cat_ddz_scale = 0.f;   // s ; 1 / (inv_keep * gs)
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);

@@ -786,9 +786,9 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         Row12 du, ur, e, dy;
         const bool need_u = a.dA2 || a.gate_w;
         const bool gate = a.gate_w && n >= 1;
-        const bool cat = gate && a.cat_dact && a.dmask;      // the saved MLP output includes the adapter (see TokBwdArgs): needs g
+        const bool cat = gate && a.cat_dact && a.dmask;      // the saved MLP output includes the adapter's weight term (see TokBwdArgs)
         if (need_u) ur.load_nt(a.u + (size_t)t * D, lane);   // saved u of the forward pass: last use
-        if ((a.write_du || cat) && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
+        if (a.write_du && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
         else if (a.write_du && n == 0) du.load(a.g_cls + (size_t)b * D, lane);
         else {
 #pragma unroll
@@ -801,7 +801,6 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         if (a.dA2 && a.write_du) st2 = a.stats2[t];
         float ext = 0.f, sf = 0.f, dmk = 0.f, dlg = 0.f;
         float cd = 0.f, cz = 0.f;   // this lane's column of the token's d_act / ddz rows (saved h includes the adapter, see TokBwdArgs)
-        Row12 bup;
         if (gate) {
             const size_t oi = (size_t)b * a.out_stride + n - 1;
             if (a.dtoken_select) ext = a.dtoken_select[oi];
@@ -812,7 +811,6 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
             if (cat) {
                 cd = to_f32(reinterpret_cast<const AT*>(a.cat_dact)[(size_t)t * RP + lane]);
                 cz = to_f32(reinterpret_cast<const AT*>(a.cat_ddz)[(size_t)t * RP + lane]);
-                bup.load(a.cat_bup, lane);
             }
         }
         if (need_u) TK_ROWPIN(ur);
@@ -821,10 +819,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         TK_SCALPIN4(r, st2.x, st2.y, ext);
         TK_SCALPIN3(sf, dmk, dlg);
         if (cat) {
-            TK_ROWPIN(bup);
             DYT_PIN2(cd, cz);
-            // du still holds g here (the adapter dgrad is added below); dropped tokens have dmask = 0 and no saved h
-            if (a.maskf[t] != 0.f) dmk -= wave_sum(cd * cz) * a.cat_ddz_scale + a.cat_scale * dot12(du, bup);
+            if (a.maskf[t] != 0.f) dmk -= wave_sum(cd * cz) * a.cat_ddz_scale;   // dropped tokens have dmask = 0 and no saved h
         }
         if (a.dad) {
 #pragma unroll
