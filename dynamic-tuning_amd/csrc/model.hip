@@ -1327,9 +1327,9 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
         // measurement hook (tools/probes/determinism_cumask.py): DYT_DBG_SIDE_CU_MASK = "cu" | "xcd" pins the teacher pass to
         // the odd CU octets / the upper four XCDs (mask bit i -> XCD i % 8), the probe pins the caller's stream to the rest
         const char* dbg_mask = getenv("DYT_DBG_SIDE_CU_MASK");
-        if (dbg_mask && (dbg_mask[0] == 'c' || dbg_mask[0] == 'x' || dbg_mask[0] == 'i')) {
+        if (dbg_mask && (dbg_mask[0] == 'c' || dbg_mask[0] == 'x' || dbg_mask[0] == 'i' || dbg_mask[0] == 'a')) {
             uint32_t words[8];
-            for (int i = 0; i < 8; ++i) words[i] = dbg_mask[0] == 'c' ? 0xFF00FF00u : (dbg_mask[0] == 'x' ? 0xF0F0F0F0u : 0x00FFFFFFu);
+            for (int i = 0; i < 8; ++i) words[i] = dbg_mask[0] == 'c' ? 0xFF00FF00u : (dbg_mask[0] == 'x' ? 0xF0F0F0F0u : (dbg_mask[0] == 'a' ? 0xF8F8F8F8u : 0x00FFFFFFu));   // a: five XCDs for the (heavier) teacher pass
             DYT_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->side, 8, words));
         } else
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));

@@ -2,6 +2,8 @@
 import os, sys, time, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+if os.environ.get("PMASK", "none") != "none":   # the two passes on complementary CU sets: cu = alternating CU octets of every XCD, xcd = XCDs 0-3 / 4-7
+    os.environ["DYT_DBG_SIDE_CU_MASK"] = os.environ["PMASK"]
 import torch
 import _lib, synth
 if os.environ.get("DYT_LIB_PATH"):
@@ -28,6 +30,14 @@ if os.environ.get("DYT_OVERLAP"):
 for kv in filter(None, os.environ.get("DYT_OPTS", "").split(",")):   # "6=0,2=1": dyt_ctx_set_option(option, value)
     k, v = kv.split("=")
     eng.set_option(int(k), int(v))
+_mask_stream = None
+if os.environ.get("PMASK", "none") != "none":
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    words = (ctypes.c_uint32 * 8)(*([{"cu": 0x00FF00FF, "xcd": 0x0F0F0F0F, "a53": 0x07070707}[os.environ["PMASK"]]] * 8))
+    h = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words) == 0
+    _mask_stream = torch.cuda.ExternalStream(h.value)
+    torch.cuda.set_stream(_mask_stream)
 def step(i):
     eng.step_fwd_bwd(x, y, 0.7, 2.0, 0.0, 0.0, seed=900 + i, masked_dense=(mode == "masked"))
     if os.environ.get("PNOADAM"):
