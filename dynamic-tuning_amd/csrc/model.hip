@@ -834,7 +834,13 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 RUN_GEMM(EPI_QKV, a);
             }
             RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
-            {
+            if (c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate) {
+                // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
+                // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
+                GemmArgs a; a.A = L.attn_o; a.a_map = c->cls_rows; a.W = W.proj_w; a.M = B; a.N = D; a.K = D; a.bias = W.proj_b;
+                a.resid = x; a.out_f32 = L.u; a.scale = 1.0f; a.row_map = c->cls_rows;
+                RUN_GEMM(EPI_AD_UP, a);
+            } else {
                 GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
                 a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
                 RUN_GEMM(EPI_BIAS_RESID, a);

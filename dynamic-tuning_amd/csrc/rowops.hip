@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         // all loads of the token first, then ONE full drain that names every one of them (DYT_PIN*, dyt_common.h): the previous
         // iteration's stores, the row loads (misses) and the per-token scalars share the counter
         Row12 du, ur, e, dy;
-        const bool need_u = a.dA2 || a.gate_w;
+        const bool need_u = (a.dA2 && (!a.g_cls || n == 0)) || a.gate_w;   // cls-only tail without a gate: only the cls rows have an LN2 backward
         const bool gate = a.gate_w && n >= 1;
         const bool cat = gate && a.cat_dact && a.dmask;      // the saved MLP output includes the adapter's weight term (see TokBwdArgs)
         if (need_u) ur.load_nt(a.u + (size_t)t * D, lane);   // saved u of the forward pass: last use

@@ -1,2 +1,6 @@
+python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|^E  |^FAILED" | head
 export PPREC=fp16
-for m in none xcd a53 none xcd a53; do echo -n "mask=$m "; PMASK=$m PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1; done
+for i in 1 2; do
+echo -n "prev "; DYT_LIB_PATH=$(pwd)/tools/probes/_ab/prev_f16.so PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1
+echo -n "new  "; PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1
+done
