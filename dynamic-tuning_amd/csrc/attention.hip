@@ -439,7 +439,10 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16_kernel(const bf16* __
                                                                   const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                                   const bf16* __restrict__ dout,
                                                                   const float* __restrict__ lse, float* __restrict__ delta,
-                                                                  bf16* __restrict__ dqkv, int nheads) {
+                                                                  bf16* __restrict__ dqkv, int nheads, int nq) {
+    // nq: query tiles (of 32 rows) that can carry a non-zero dO -- 7, or 1 when only the cls rows have an upstream gradient
+    // (last block, cls-only tail): rows with dO = 0 have dP = delta = 0, hence dS = 0 and no contribution to dK / dV / dQ, so
+    // phase B walks nq query tiles and only the first nq waves run phase A (the others store their zero dQ rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // phase B images
     bf16* Qs = reinterpret_cast<bf16*>(smem);
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16_kernel(const bf16* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
 #pragma unroll 1
-            for (int qt = 0; qt < 7; ++qt) {
+            for (int qt = 0; qt < nq; ++qt) {
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16_kernel(const bf16* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 #pragma unroll 1
-            for (int kt = 0; kt < 7; ++kt) {
+            for (int kt = 0; kt < (wave < nq ? 7 : 0); ++kt) {
                 f32x16 s_, dp_;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp_[r] = 0.f; }
@@ -918,7 +921,7 @@ static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV 
 void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
 
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
-                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s) {
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles) {
     const int grid = batch * NH;
     if (dbg_skip(1)) return 0;
     if (precision == 0) {
@@ -948,10 +951,10 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
         if (g_attn_bwd_fused) {
             if (g_attn_bwd_fused == 2)
                 hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<true>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
-                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
+                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, q_tiles);
             else
                 hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<false>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
-                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
+                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, q_tiles);
             DYT_HIP_CHECK(hipGetLastError());
             return 0;
         }
