@@ -375,7 +375,7 @@ __device__ unsigned long long g_gemm_dbg[4];
 // gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
-struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; };
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; };   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
@@ -662,7 +662,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
                 for (int u = 0; u < BATCH; ++u) {
                     const int row = m0 + p * PROWS + rl0 + (it0 + u) * RSTEP;
                     if (row < Mv) {
-                        const float v[4] = {c4[u][0], c4[u][1], c4[u][2], c4[u][3]};
+                        const float os = cat.out_scale;   // 1.0 (exact) except in the split fp32 form of a gradient GEMM
+                        const float v[4] = {c4[u][0] * os, c4[u][1] * os, c4[u][2] * os, c4[u][3] * os};
                         epi.apply(row, col, v, cc, pr[PRE_ALL ? it0 + u : u]);
                     }
                 }
@@ -711,7 +712,7 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
                                           (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, cat);
     ++g_bf16_kernel_launches;
@@ -820,23 +821,24 @@ static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     return launch_f32_cfg<128, 64>(a, epi, s);
 }
 
-template <class AT, class Epi>
+// SPLIT: fp32 epilogue functors on the 16-bit MFMA kernels (the fp32 operands arrive as K-concatenated 16-bit hi / lo parts)
+template <class AT, bool SPLIT, class Epi>
 static int run(const GemmArgs& a, const Epi& epi, hipStream_t s) {
-    if constexpr (sizeof(AT) == 2) return run_bf16(a, epi, s);
+    if constexpr (sizeof(AT) == 2 || SPLIT) return run_bf16(a, epi, s);
     else return run_f32(a, epi, s);
 }
 
-template <class AT>
+template <class AT, bool SPLIT = false>
 static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
     switch (kind) {
-        case EPI_BIAS_F32: return run<AT>(a, EpiBiasF32{a.bias, a.out_f32, a.N}, s);
+        case EPI_BIAS_F32: return run<AT, SPLIT>(a, EpiBiasF32{a.bias, a.out_f32, a.N}, s);
         case EPI_QKV:
-            return run<AT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
+            return run<AT, SPLIT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
         case EPI_BIAS_RESID:
-            return run<AT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
+            return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1:
-            if (a.out_at2) return run<AT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
-            return run<AT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
+            if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
+            return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
         case EPI_FC2: {
             const float* resid = a.resid ? a.resid : a.out_f32;   // null: in place
             if (a.A2) {   // adapter up-projection as the leading k-tile of the contraction (16-bit kernels only)
@@ -849,23 +851,23 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
                     return -1;
                 }
             }
-            if (!a.row_map && !a.row_mask) return run<AT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, nullptr, 0.f}, s);
-            return run<AT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
+            if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, nullptr, 0.f}, s);
+            return run<AT, SPLIT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
         }
         case EPI_GELU_BWD:
-            if (a.row_map) return run<AT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
-            return run<AT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
-        case EPI_STORE_F32: return run<AT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
-        case EPI_STORE_AT: return run<AT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
+            if (a.row_map) return run<AT, SPLIT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
+            return run<AT, SPLIT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
+        case EPI_STORE_F32: return run<AT, SPLIT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
+        case EPI_STORE_AT: return run<AT, SPLIT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
-            return run<AT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
+            return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
         case EPI_AD_UP:
-            if (a.row_map) return run<AT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr}, s);
-            return run<AT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask}, s);
+            if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr}, s);
+            return run<AT, SPLIT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask}, s);
         case EPI_AD_DGRAD_UP:
-            return run<AT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
-        case EPI_EMBED: return run<AT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
-        case EPI_BIAS_AT: return run<AT>(a, EpiBiasAT<AT>{a.bias, (AT*)a.out_at, a.N}, s);
+            return run<AT, SPLIT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
+        case EPI_EMBED: return run<AT, SPLIT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
+        case EPI_BIAS_AT: return run<AT, SPLIT>(a, EpiBiasAT<AT>{a.bias, (AT*)a.out_at, a.N}, s);
     }
     set_error("gemm: unknown epilogue %d", (int)kind);
     return -1;
@@ -926,7 +928,54 @@ int gemm_debug_counters(unsigned long long* out4, int reset) {
     return 0;
 }
 
+// ---- fp32 operands as 16-bit hi / lo parts ----
+// A [M,K] fp32 (rows optionally gathered) -> out [M, 3K] = [hi | hi | lo]; one thread = 8 consecutive k of a row
+__global__ __launch_bounds__(256) void split3_a_kernel(const float* __restrict__ A, const int* __restrict__ a_map,
+                                                       const int* __restrict__ m_dev, bf16* __restrict__ out, int M, int K, float scale) {
+    const int kc = K / 8;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(idx / kc), c = (int)(idx - (size_t)row * kc);
+    const int Mv = m_dev ? min(*m_dev, M) : M;
+    if (row >= Mv) return;
+    const float* src = A + (size_t)(a_map ? a_map[row] : row) * K + c * 8;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src) * scale, x1 = *reinterpret_cast<const f32x4*>(src + 4) * scale;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (bf16)x0[i]; lo[i] = (bf16)(x0[i] - (float)hi[i]);
+        hi[4 + i] = (bf16)x1[i]; lo[4 + i] = (bf16)(x1[i] - (float)hi[4 + i]);
+    }
+    bf16* dst = out + (size_t)row * 3 * K + c * 8;
+    *reinterpret_cast<bf16x8*>(dst) = hi;
+    *reinterpret_cast<bf16x8*>(dst + K) = hi;
+    *reinterpret_cast<bf16x8*>(dst + 2 * K) = lo;
+}
+// W [N,K] fp32 -> [N, 3K] = [hi | lo | hi]
+__global__ __launch_bounds__(256) void split3_w_kernel(const float* __restrict__ W, bf16* __restrict__ out, int N, int K) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)N * K) return;
+    const size_t row = idx / K; const int k = (int)(idx - row * K);
+    const float w = W[idx];
+    const bf16 hi = (bf16)w, lo = (bf16)(w - (float)hi);
+    bf16* dst = out + row * 3 * K;
+    dst[k] = hi; dst[K + k] = lo; dst[2 * K + k] = hi;
+}
+int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(split3_w_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, W, static_cast<bf16*>(W3), N, K);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
+    if (precision == 0 && a.W3 && a.a3) {
+        if (a.K % 8 != 0 || a.A2) { set_error("gemm split form: K=%d %% 8", a.K); return -1; }
+        const size_t tasks = (size_t)a.M * (a.K / 8);
+        hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
+                           a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
+        GemmArgs b = a;
+        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_map = nullptr; b.Wp = nullptr; b.W3 = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        return dispatch<float, true>(kind, b, s);
+    }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;
     if (dbg_skip(128) && a.N == D && a.K >= 256) return 0;
     if (dbg_skip(256) && a.N >= 2304) return 0;

@@ -36,6 +36,13 @@ struct GemmArgs {
     // K-concatenated form (16-bit kernels, EPI_FC2): C = A2 W2^T + A W^T, A2 [rows,64] (row r read from A2[a2_map[r]]), W2 [N,64];
     // bias2 / scale: the second pair's bias enters as scale * bias2 (W2 is expected to carry `scale` already)
     const void* A2 = nullptr; const void* W2 = nullptr; const int* a2_map = nullptr; const float* bias2 = nullptr;
+    // fp32 mode, "split" form: W3 = the fp32 weight as [N, 3K] 16-bit operands [hi | lo | hi] (launch_split3_w); the fp32 A is split
+    // on the fly into a3 [M, 3K] = [hi | hi | lo] and the GEMM runs as ONE 16-bit MFMA contraction over 3K (hi*hi + hi*lo + lo*hi)
+    // with the fp32 epilogue: the accuracy of the exact-fp32 MFMA kernel at ~2.7x its speed (tools/probes/split_precision_probe.py)
+    const void* W3 = nullptr; void* a3 = nullptr;
+    float a3_scale = 1.f;   // power of two the fp32 A is multiplied by before it is split (gradients: keeps the lo part out of the fp16
+                            // subnormals); the accumulators are multiplied by out_scale = 1 / a3_scale before the epilogue functor
+    float out_scale = 1.f;
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -59,6 +66,8 @@ struct GemmArgs {
 };
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
+// fp32 W [N,K] -> [N, 3K] 16-bit operands [hi | lo | hi] with hi = rn16(w), lo = rn16(w - hi)
+int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s);
 // bf16 W [N,K] row-major -> fragment order for the pre-shuffled-weight kernel (N % 16 == 0, K % 32 == 0)
 int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s);
 int gemm_debug_counters(unsigned long long* out4, int reset);

@@ -100,6 +100,8 @@ struct LayerW {  // frozen, library-owned
     void *qkv_w, *qkv_wT, *proj_w, *proj_wT, *fc1_w, *fc1_wT, *fc2_w, *fc2_wT;
     void *qkv_wp = nullptr, *fc1_wp = nullptr, *fc2_wTp = nullptr;   // bf16 mode: MFMA-fragment-order twins (gemm_bpre.h)
     void *proj_wp = nullptr, *proj_wTp = nullptr, *qkv_wTp = nullptr, *fc1_wTp = nullptr;
+    // fp32 mode: [N, 3K] 16-bit hi / lo / hi parts of the eight matrices (DYT_OPT_F32_SPLIT16, launch_split3_w)
+    void *qkv_w3 = nullptr, *qkv_wT3 = nullptr, *proj_w3 = nullptr, *proj_wT3 = nullptr, *fc1_w3 = nullptr, *fc1_wT3 = nullptr, *fc2_w3 = nullptr, *fc2_wT3 = nullptr;
 };
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
@@ -111,6 +113,7 @@ struct LayerS {  // saved activations of one pass
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
+    void* a3 = nullptr;   // fp32 mode: [M, 3 * 3072] 16-bit scratch for the split A operand of a GEMM
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
@@ -156,6 +159,8 @@ struct dyt_ctx {
     void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
     void* ad_up_ws = nullptr;   // 16-bit modes: scale * up_w (leading k-tile of the fc2 contraction)
     float* ad_down_b;
+    bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
+    void* pe_w3 = nullptr;
     bool fc2_cat = true;        // 16-bit modes: adapter up-projection rides on the fc2 GEMM where no separate h is needed
     // trainable flat layout
     int64_t layer_stride, off_dw, off_db, off_uw, off_ub, off_gw, off_gb, off_hw, off_hb, n_train;
@@ -216,6 +221,7 @@ static void layout(dyt_ctx* c, bool dry) {
     c->norm_w = carve<float>(c, D, dry);
     c->norm_b = carve<float>(c, D, dry);
     c->pe_w = carve_at(c, (size_t)D * D, dry);
+    if (c->prec == 0) c->pe_w3 = carve<uint16_t>(c, (size_t)3 * D * D, dry);
     c->W.resize(depth);
     for (size_t l = 0; l < depth; ++l) {
         LayerW& w = c->W[l];
@@ -232,6 +238,11 @@ static void layout(dyt_ctx* c, bool dry) {
             w.fc2_wTp = carve_at(c, (size_t)DM * D, dry);
             w.proj_wp = carve_at(c, (size_t)D * D, dry); w.proj_wTp = carve_at(c, (size_t)D * D, dry);
             w.qkv_wTp = carve_at(c, (size_t)3 * D * D, dry); w.fc1_wTp = carve_at(c, (size_t)DM * D, dry);
+        } else {
+            w.qkv_w3 = carve<uint16_t>(c, (size_t)3 * 3 * D * D, dry); w.qkv_wT3 = carve<uint16_t>(c, (size_t)3 * 3 * D * D, dry);
+            w.proj_w3 = carve<uint16_t>(c, (size_t)3 * D * D, dry); w.proj_wT3 = carve<uint16_t>(c, (size_t)3 * D * D, dry);
+            w.fc1_w3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry); w.fc1_wT3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
+            w.fc2_w3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry); w.fc2_wT3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
         }
     }
     c->ad_down_w = carve_at(c, depth * RP * D, dry);
@@ -297,6 +308,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.ddz = carve_at(c, M * RP, dry);
         T.du_at = carve_at(c, M * D, dry);
         T.dad = c->prec != DYT_PREC_FP32 ? carve_at(c, M * D, dry) : nullptr;
+        T.a3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
         T.dO = carve_at(c, M * D, dry);
         T.dqkv = carve_at(c, M * 3 * D, dry);
         T.dA2 = carve_at(c, M * D, dry);
@@ -490,12 +502,34 @@ static int set_matrix(dyt_ctx* c, const float* src, void* w, void* wT, int N, in
     if (wT) rc = launch_transpose_convert(c->prec, src, wT, N, K, K, N, s);
     return rc;
 }
+// fp32 mode: refresh the 16-bit hi / lo / hi parts of one layer's (layer < 0: the patch embedding's) frozen matrices
+static int refresh_split(dyt_ctx* c, int layer, hipStream_t s) {
+    if (c->prec != 0) return 0;
+    if (layer < 0) return launch_split3_w((const float*)c->pe_w, c->pe_w3, D, D, s);
+    LayerW& w = c->W[layer];
+    int rc = launch_split3_w((const float*)w.qkv_w, w.qkv_w3, 3 * D, D, s);
+    if (!rc) rc = launch_split3_w((const float*)w.qkv_wT, w.qkv_wT3, D, 3 * D, s);
+    if (!rc) rc = launch_split3_w((const float*)w.proj_w, w.proj_w3, D, D, s);
+    if (!rc) rc = launch_split3_w((const float*)w.proj_wT, w.proj_wT3, D, D, s);
+    if (!rc) rc = launch_split3_w((const float*)w.fc1_w, w.fc1_w3, DM, D, s);
+    if (!rc) rc = launch_split3_w((const float*)w.fc1_wT, w.fc1_wT3, D, DM, s);
+    if (!rc) rc = launch_split3_w((const float*)w.fc2_w, w.fc2_w3, D, DM, s);
+    if (!rc) rc = launch_split3_w((const float*)w.fc2_wT, w.fc2_wT3, DM, D, s);
+    return rc;
+}
 static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
     DYT_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
+static int set_frozen_impl(dyt_ctx* c, int param, int layer, const float* src, void* stream);
 extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src, void* stream) {
+    int rc = set_frozen_impl(c, param, layer, src, stream);
+    if (!rc && c->split16 && (param == DYT_P_PE_W || param == DYT_P_QKV_W || param == DYT_P_PROJ_W || param == DYT_P_FC1_W || param == DYT_P_FC2_W))
+        rc = refresh_split(c, param == DYT_P_PE_W ? -1 : layer, static_cast<hipStream_t>(stream));
+    return rc;
+}
+static int set_frozen_impl(dyt_ctx* c, int param, int layer, const float* src, void* stream) {
     if (!c || !src) { set_error("null argument"); return DYT_ERR_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool per_layer = param >= DYT_P_LN1_W && param <= DYT_P_FC2_B;
@@ -593,6 +627,19 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             c->gs = c->prec == DYT_PREC_FP32 ? 1.0f : (float)(1u << value);
             return DYT_OK;
         case DYT_OPT_FC2_CAT: c->fc2_cat = value != 0; return DYT_OK;
+        case DYT_OPT_F32_SPLIT16: {   // fp32 mode only: the frozen-weight GEMMs as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
+            if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
+            c->split16 = value != 0;
+            for (auto& S : c->slots) S.valid = false;
+            if (c->split16) {   // parts of the weights uploaded so far (later dyt_set_frozen calls refresh theirs)
+                DYT_HIP_CHECK(hipDeviceSynchronize());   // uploads may be in flight on the caller's streams
+                int rc = refresh_split(c, -1, nullptr);
+                for (int l = 0; l < c->cfg.depth && !rc; ++l) rc = refresh_split(c, l, nullptr);
+                if (rc) return rc;
+                DYT_HIP_CHECK(hipDeviceSynchronize());
+            }
+            return DYT_OK;
+        }
         case DYT_OPT_ATTN_BWD_FUSED: set_attn_bwd_fused(value); return DYT_OK;   // process-wide
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
@@ -685,6 +732,9 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
     } while (0)
 
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
+#define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
+// gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
+#define SPLIT_G(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; (a).a3_scale = 4096.0f; } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // video model: attentive pooling head (video_models/video_vision_transformer_IN21K.py:463-483)
@@ -812,7 +862,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         RUN(2, 0, launch_im2col(P, images, T.xn, B, s));
         {
             GemmArgs a; a.A = T.xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
-            a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0];
+            a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0]; SPLIT(a, c->pe_w3);
             RUN_GEMM(EPI_EMBED, a);
         }
         RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
@@ -830,7 +880,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s));
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
-                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v;
+                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3);
                 RUN_GEMM(EPI_QKV, a);
             }
             RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
@@ -838,11 +888,11 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
                 GemmArgs a; a.A = L.attn_o; a.a_map = c->cls_rows; a.W = W.proj_w; a.M = B; a.N = D; a.K = D; a.bias = W.proj_b;
-                a.resid = x; a.out_f32 = L.u; a.scale = 1.0f; a.row_map = c->cls_rows;
+                a.resid = x; a.out_f32 = L.u; a.scale = 1.0f; a.row_map = c->cls_rows; SPLIT(a, W.proj_w3);
                 RUN_GEMM(EPI_AD_UP, a);
             } else {
                 GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
-                a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at;
+                a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at; SPLIT(a, W.proj_w3);
                 RUN_GEMM(EPI_BIAS_RESID, a);
             }
             if (l == 0 && ev_b0_record) DYT_HIP_CHECK(hipEventRecord(ev_b0_record, s));
@@ -907,7 +957,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const int* kdev = (dense || tail) ? nullptr : L.total;
         {
             GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
-            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr;
+            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT(a, W.fc1_w3);
             RUN_GEMM(EPI_FC1, a);
         }
         JOIN(sb);  // x_out now holds u + adapter(u) (two-launch form) / d_act is complete
@@ -921,6 +971,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.row_map = tail ? c->cls_rows : (dense ? nullptr : L.row_src);
             a.row_mask = (masked_dense && !tail) ? L.maskf : nullptr;   // the cls token is never gated
             a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
+            SPLIT(a, W.fc2_w3);
             if (cat) {
                 a.A2 = L.d_act; a.W2 = at_off(c, c->ad_up_ws, (size_t)l * RP * D);
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
@@ -1181,13 +1232,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             {
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
-                a.row_map = (h_by_token && !tail) ? L.row_src : nullptr;
+                a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3);
                 if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
                 CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
             }
             {
-                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2;
+                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2; SPLIT_G(a, W.fc1_wT3);
                 if (dense) POISON(2, T.dA2, (size_t)Mr * D * c->at);
                 ISO(8, RUN_GEMM(EPI_STORE_AT, a););
                 CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * c->at);
@@ -1243,7 +1294,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
             GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.Wp = W.proj_wTp; a.M = M; a.N = D; a.K = D;
-            a.out_at = T.dO;
+            a.out_at = T.dO; SPLIT_G(a, W.proj_wT3);
             POISON(16, T.dO, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("proj_dgrad dO", T.dO, (size_t)M * D * c->at);
@@ -1253,7 +1304,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7)););   // teacher tail: du, hence dO, is zero off the cls rows
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
-            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn;
+            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3);
             POISON(1, T.dxn, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * c->at);

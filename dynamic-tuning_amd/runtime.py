@@ -10,14 +10,14 @@ import ctypes
 import torch
 
 from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
-                  F_TRAINING, PREC_BF16, PREC_FP16, PREC_FP32,
+                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
 
 
 def parse_precision(p):
-    if p in (PREC_FP32, PREC_BF16, PREC_FP16):
+    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3):
         return p
     p = str(p).lower()
     if p in ("fp32", "float32", "exact"):
@@ -26,7 +26,9 @@ def parse_precision(p):
         return PREC_BF16
     if p in ("fp16", "float16", "half"):
         return PREC_FP16
-    raise ValueError("precision must be 'fp32', 'bf16' or 'fp16', got %r" % (p,))
+    if p in ("fp16x3", "split", "fp32-split"):
+        return PREC_FP16X3
+    raise ValueError("precision must be 'fp32', 'fp16x3', 'bf16' or 'fp16', got %r" % (p,))
 
 
 class DyTEngine:
@@ -37,15 +39,20 @@ class DyTEngine:
         self.device = torch.device(device)
         self.precision = parse_precision(precision)
         # "fp16" = the second build of the library (IEEE-half operands) in ITS 16-bit mode
-        self.cfg = Config(int(num_classes), int(ffn_num), int(depth), PREC_BF16 if self.precision == PREC_FP16 else self.precision,
+        # "fp16x3" = that library's fp32 mode with the frozen-weight GEMMs as three IEEE-half products (DYT_OPT_F32_SPLIT16)
+        lib_prec = {PREC_FP16: PREC_BF16, PREC_FP16X3: PREC_FP32}.get(self.precision, self.precision)
+        self.cfg = Config(int(num_classes), int(ffn_num), int(depth), lib_prec,
                           int(max_batch), int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
                           int(frames))
         self.frames = max(1, int(frames))   # > 1: video model, every batch is clips * frames images
-        self.L = lib(fp16=self.precision == PREC_FP16)
+        self.L = lib(fp16=self.precision in (PREC_FP16, PREC_FP16X3))
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             self._ck(self.L.dyt_ctx_create(ctypes.byref(self.cfg), ctypes.byref(h)))
         self.h = h
+        if self.precision == PREC_FP16X3:
+            with torch.cuda.device(self.device):
+                self._ck(self.L.dyt_ctx_set_option(self.h, OPT_F32_SPLIT16, 1))
         n = ctypes.c_int64()
         self._ck(self.L.dyt_trainable_numel(self.h, ctypes.byref(n)))
         self.n_train = n.value

@@ -125,3 +125,42 @@ def test_fused_attention_backward_is_bitwise_the_two_kernel_form(B):
         assert torch.isfinite(res[0]).all()
         for r in res[1:]:
             assert torch.equal(r, res[0]), (B, fp16, int((r != res[0]).sum()))
+
+
+@pytest.mark.parametrize("mode", ["masked", "compact"])
+def test_split_fp16x3_mode_meets_the_fp32_parity_bars(mode):
+    """precision "fp16x3" (DYT_OPT_F32_SPLIT16: the fp32 mode with every frozen-weight GEMM computed on the 16-bit matrix cores as
+    hi*hi + hi*lo + lo*hi of IEEE-half parts, fp32 accumulate and epilogues; attention / LayerNorm / adapters exact fp32) against
+    the CPU oracle at BASELINE configs[0] size (B=16): the bars of the exact-fp32 mode -- logits within 1e-3 (north_star), gate
+    decisions bit-exact outside fp32 round-off of the threshold, losses 1e-4, all 74 gradients 2e-3 relative."""
+    from oracle import dyt_oracle as O
+    B, C, r, target = 16, 100, 64, 0.5
+    x, y = synth.make_batch(B, C, seed=31)
+    g1, g2 = synth.make_noise(B, seed=32)
+    keep = synth.make_dropout_masks(B, r, seed=33)
+    sd = synth.make_state_dict(C, r, seed=0, kind="test", gate_bias=0.85)
+    d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
+    ref_ts = tok["token_select"].detach()
+    z = ((tok["token_logits"].detach()[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0).abs()   # decision margins [12,B,196]
+    m, _ = _bench_model("fp16x3", mode, B, 0.85, classes=C, r=r, kind="test")
+    m.train()
+    eng = m.engine(B, torch.device("cuda", 0))
+    ls = torch.empty(B, C, device="cuda"); lt = torch.empty(B, C, device="cuda"); ts = torch.zeros(B, 12, 196, device="cuda")
+    losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                              g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+    es, et = float((ls.cpu() - ref_ls.detach()).abs().max()), float((lt.cpu() - ref_lt.detach()).abs().max())
+    flip = ts.cpu() != ref_ts[..., 0].float()
+    print("fp16x3/%s: logits %.2e / %.2e, gate flips %d of %d" % (mode, es, et, int(flip.sum()), flip.numel()))
+    assert es < 1e-3 and et < 1e-3, (es, et)
+    assert int((flip & (z.permute(1, 0, 2) > 2e-5)).sum()) == 0 and int(flip.sum()) <= 2, int(flip.sum())
+    for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
+        assert abs(float(losses[i]) - float(d_ref[k])) < 1e-4 * max(1.0, abs(float(d_ref[k]))), (k, float(losses[i]), float(d_ref[k]))
+    worst = 0.0
+    for n, gr in g_ref.items():
+        if gr.numel() == 1:
+            continue
+        got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
+        e = float((got - gr).norm() / (gr.norm() + 1e-20))
+        worst = max(worst, e)
+        assert e < 2e-3, (n, e)
+    print("fp16x3/%s worst gradient rel-L2 %.2e" % (mode, worst))

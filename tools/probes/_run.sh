@@ -1,13 +1,8 @@
-set -x
+python -m pytest tests/test_gpu_round3.py -x -q -s 2>&1 | grep -E "passed|failed|^E  |fp16x3|Error" | head -20
+python -m pytest tests/test_gpu_parity.py -x -q -k "gemm or linear or golden" 2>&1 | grep -E "passed|failed|^E  " | head
+for p in fp16x3 fp32; do echo -n "$p "; PPREC=$p PSTEPS=6 PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1; done
 export PPREC=fp16
-python bench.py > gpurun_out/r3_head_bench.log 2>&1; grep '^{' gpurun_out/r3_head_bench.log > gpurun_out/r3_final_bench.json; cut -c1-330 gpurun_out/r3_final_bench.json
-python bench.py --precision bf16 --no-cpu-baseline --no-parity-mode 2>&1 | grep '^{' > gpurun_out/r3_final_bf16_bench.json
-python bench.py --mode masked --no-cpu-baseline --no-parity-mode 2>&1 | grep '^{' > gpurun_out/r3_final_masked_bench.json
-python bench.py --video-frames 8 --classes 400 --no-cpu-baseline --no-parity-mode 2>&1 | grep '^{' > gpurun_out/r3_final_video_bench.json
-tools/rocprof_bench.sh r3_final_ovl -- --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode > /dev/null
-tools/rocprof_bench.sh r3_final_serial DYT_NO_OVERLAP=1 -- --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode > /dev/null
-tools/pmc_step.sh r3_final
-tools/pmc_bench.sh r3_final > /dev/null
-EXTRA_ENV="PPREC=fp16" bash tools/probes/shape_times.sh r3_final_serial > /dev/null
-tools/probes/marginal_cost.sh > gpurun_out/r3_final_marginal_cost.txt 2>&1; (echo serial; DYT_NO_OVERLAP=1 tools/probes/marginal_cost.sh) >> gpurun_out/r3_final_marginal_cost.txt 2>&1
-python dynamic-tuning_amd/speed.py 2>&1 | tail -2
+for i in 1 2; do
+echo -n "prev "; DYT_LIB_PATH=$(pwd)/tools/probes/_ab/prev_f16.so PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1
+echo -n "new  "; PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1
+done
