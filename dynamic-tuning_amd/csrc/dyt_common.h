@@ -75,6 +75,15 @@ __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float
     bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
     *reinterpret_cast<bf16x4*>(p) = v;
 }
+// 4 consecutive fp32 values as 16-bit hi / hi / lo parts of the split operand layout [row][3K] (hi = rn16(x), lo = rn16(x - hi));
+// dst = &row[col], the three copies are K elements apart
+__device__ __forceinline__ void store4_split3(bf16* dst, int K, float a, float b, float c, float d) {
+    const bf16x4 hi = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+    const bf16x4 lo = {(bf16)(a - (float)hi[0]), (bf16)(b - (float)hi[1]), (bf16)(c - (float)hi[2]), (bf16)(d - (float)hi[3])};
+    *reinterpret_cast<bf16x4*>(dst) = hi;
+    *reinterpret_cast<bf16x4*>(dst + K) = hi;
+    *reinterpret_cast<bf16x4*>(dst + 2 * K) = lo;
+}
 __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
     float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;

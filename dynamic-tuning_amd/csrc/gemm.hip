@@ -113,6 +113,7 @@ struct EpiBiasResid {
 template <class AT, bool HAS_GP>
 struct EpiFc1 {
     const float* bias; AT* h; AT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
+    bf16* h3;   // split fp32 form: h goes out as the 16-bit hi / hi / lo operand of the fc2 GEMM ([rows, 3 ld]) instead of as fp32
     typedef Bias4 Col; typedef NoCtx Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int, int) const { return {}; }
@@ -135,6 +136,9 @@ struct EpiFc1 {
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + c.b[i]);
+        }
+        if constexpr (sizeof(AT) == 4) {
+            if (h3) { store4_split3(h3 + (size_t)row * 3 * ld + col, ld, hv[0], hv[1], hv[2], hv[3]); return; }
         }
         store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
@@ -205,6 +209,7 @@ template <class AT, bool MAPPED>
 struct EpiGeluBwd {
     const AT* gp; AT* out; int ld;   // gp = gelu'(z) saved by the fc1 epilogue
     const int* row_map;
+    bf16* out3; float s3;   // split fp32 form: dZ * s3 goes out as the split operand of the fc1 dgrad GEMM instead of as fp32
     typedef NoCtx Col; typedef Raw4<AT> Pre;
     __device__ __forceinline__ Col col_init(int) const { return {}; }
     __device__ __forceinline__ Pre pre(int row, int col) const {   // gelu'(z) is read exactly once: streaming load
@@ -220,6 +225,9 @@ struct EpiGeluBwd {
     __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col&, const Pre& p) const {
         float g[4];
         p.get(g);
+        if constexpr (sizeof(AT) == 4) {
+            if (out3) { store4_split3(out3 + (size_t)row * 3 * ld + col, ld, a[0] * g[0] * s3, a[1] * g[1] * s3, a[2] * g[2] * s3, a[3] * g[3] * s3); return; }
+        }
         store4(out + (size_t)row * ld + col, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
     }
 };
@@ -837,8 +845,8 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS_RESID:
             return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1:
-            if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N}, s);
-            return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N}, s);
+            if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3}, s);
+            return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3}, s);
         case EPI_FC2: {
             const float* resid = a.resid ? a.resid : a.out_f32;   // null: in place
             if (a.A2) {   // adapter up-projection as the leading k-tile of the contraction (16-bit kernels only)
@@ -855,8 +863,8 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             return run<AT, SPLIT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
         }
         case EPI_GELU_BWD:
-            if (a.row_map) return run<AT, SPLIT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map}, s);
-            return run<AT, SPLIT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr}, s);
+            if (a.row_map) return run<AT, SPLIT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map, (bf16*)a.out3, a.out3_scale}, s);
+            return run<AT, SPLIT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr, (bf16*)a.out3, a.out3_scale}, s);
         case EPI_STORE_F32: return run<AT, SPLIT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
         case EPI_STORE_AT: return run<AT, SPLIT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
@@ -970,6 +978,7 @@ int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
     if (precision == 0 && a.W3 && a.a3) {
         if (a.K % 8 != 0 || a.A2) { set_error("gemm split form: K=%d %% 8", a.K); return -1; }
         const size_t tasks = (size_t)a.M * (a.K / 8);
+        if (!a.a3_ready)
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
                            a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
         GemmArgs b = a;

@@ -43,6 +43,9 @@ struct GemmArgs {
     float a3_scale = 1.f;   // power of two the fp32 A is multiplied by before it is split (gradients: keeps the lo part out of the fp16
                             // subnormals); the accumulators are multiplied by out_scale = 1 / a3_scale before the epilogue functor
     float out_scale = 1.f;
+    bool a3_ready = false;   // a3 already holds the split A (written by the producing kernel): no pre-pass
+    // FC1 / GELU_BWD in the split form: the result also (instead of out_at) goes out as the split A operand of the NEXT GEMM
+    void* out3 = nullptr; float out3_scale = 1.f;
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -93,7 +96,7 @@ void set_attn_bwd_fused(int on);
 // ------------------------------------------------------------------------------------------
 // LayerNorm over 768 channels, one wave per row; stats[row] = {mean, rstd}
 int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats,
-                  int rows, hipStream_t s);
+                  int rows, hipStream_t s, void* out3 = nullptr);   // out3 (fp32 mode): the rows as split 16-bit operand [rows, 3*768] instead of out
 int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s);
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
@@ -125,7 +128,7 @@ int launch_gate(const GateArgs& a, hipStream_t s);
 // also computes the row offsets (prefix of counts) itself and publishes total[0] = sum(counts)
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
-                     int* row_src, int* dst_of, int batch, hipStream_t s);
+                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3 = nullptr);
 
 // the index half of launch_ln_gather alone (dense forward that is followed by a compacted backward): row_src, dst_of, total
 int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,

@@ -114,6 +114,7 @@ struct LayerS {  // saved activations of one pass
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
     void* a3 = nullptr;   // fp32 mode: [M, 3 * 3072] 16-bit scratch for the split A operand of a GEMM
+    void *xn3 = nullptr, *h3 = nullptr;   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
@@ -309,6 +310,8 @@ static void layout(dyt_ctx* c, bool dry) {
         T.du_at = carve_at(c, M * D, dry);
         T.dad = c->prec != DYT_PREC_FP32 ? carve_at(c, M * D, dry) : nullptr;
         T.a3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
+        T.xn3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
+        T.h3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
         T.dO = carve_at(c, M * D, dry);
         T.dqkv = carve_at(c, M * 3 * D, dry);
         T.dA2 = carve_at(c, M * D, dry);
@@ -734,6 +737,8 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 #define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
+// the producing kernel already wrote the split operand into `buf`
+#define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
 #define SPLIT_G(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; (a).a3_scale = 4096.0f; } } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -877,10 +882,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
         if (!(share0 && l == 0)) {
-            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s));
+            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr));
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
-                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3);
+                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3); SPLIT_READY(a, T.xn3);
                 RUN_GEMM(EPI_QKV, a);
             }
             RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
@@ -946,9 +951,9 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             // nothing: T.xn already holds LN2 of the cls rows
         } else if (!dense) {
             RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.total, L.maskf, T.xn, L.st2,
-                                       L.row_src, L.dst_of, B, s));
+                                       L.row_src, L.dst_of, B, s, c->split16 ? T.xn3 : nullptr));
         } else {
-            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s));
+            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s, c->split16 ? T.xn3 : nullptr));
             // reference-style (masked) student pass: the MLP runs on every token, but its backward only has rows for the
             // kept ones (dH = mask * g) and is compacted -- it needs the dispatcher's index arrays too
             if (masked_dense && save) RUN(2, 0, launch_gather_index(L.keep_local, counts, L.total, L.maskf, L.row_src, L.dst_of, B, s));
@@ -958,6 +963,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         {
             GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT(a, W.fc1_w3);
+            if (!tail) SPLIT_READY(a, T.xn3);   // (the cls tail's LN2 rows come from ln_cls in fp32: pre-pass)
+            if (c->split16) a.out3 = T.h3;
             RUN_GEMM(EPI_FC1, a);
         }
         JOIN(sb);  // x_out now holds u + adapter(u) (two-launch form) / d_act is complete
@@ -971,7 +978,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.row_map = tail ? c->cls_rows : (dense ? nullptr : L.row_src);
             a.row_mask = (masked_dense && !tail) ? L.maskf : nullptr;   // the cls token is never gated
             a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
-            SPLIT(a, W.fc2_w3);
+            SPLIT(a, W.fc2_w3); SPLIT_READY(a, T.h3);
             if (cat) {
                 a.A2 = L.d_act; a.W2 = at_off(c, c->ad_up_ws, (size_t)l * RP * D);
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
@@ -1233,12 +1240,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
                 a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3);
+                if (c->split16) { a.out3 = T.h3; a.out3_scale = 4096.0f; }   // dZ as the split operand of the fc1 dgrad
                 if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
                 CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
             }
             {
-                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2; SPLIT_G(a, W.fc1_wT3);
+                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2; SPLIT_G(a, W.fc1_wT3); SPLIT_READY(a, T.h3);
                 if (dense) POISON(2, T.dA2, (size_t)Mr * D * c->at);
                 ISO(8, RUN_GEMM(EPI_STORE_AT, a););
                 CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * c->at);

@@ -1,9 +1,3 @@
-time python bench.py > gpurun_out/b.log 2>&1; grep '^{' gpurun_out/b.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(d['value'], d['ms_per_step'], d['dtype'])
-for k in ('parity_mode','exact_mode','other_fast_mode'):
-    m=d.get(k); print(k, m and (m['dtype'], m['value'], m['ms_per_step'], (m.get('roofline') or {}).get('frac'), (m.get('roofline') or {}).get('achieved')))
-print(d.get('cpu_baseline'))
-"
-tail -3 gpurun_out/b.log | cut -c1-200
+python -m pytest tests/test_gpu_round3.py -x -q -s -k split 2>&1 | grep -E "passed|failed|^E  |fp16x3|Error" | head -20
+for p in fp16x3 fp32; do echo -n "$p "; PPREC=$p PSTEPS=6 PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1; done
+python -m pytest tests/test_gpu_parity.py -x -q -k "golden or scheduling or full_size or batch_of_one" 2>&1 | grep -E "passed|failed|^E  " | head
