@@ -1,3 +1,9 @@
-python -m pytest tests/test_gpu_round3.py -x -q -s -k split 2>&1 | grep -E "passed|failed|^E  |fp16x3|Error" | head -20
-for p in fp16x3 fp32; do echo -n "$p "; PPREC=$p PSTEPS=6 PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1; done
-python -m pytest tests/test_gpu_parity.py -x -q -k "golden or scheduling or full_size or batch_of_one" 2>&1 | grep -E "passed|failed|^E  " | head
+python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|^E  |^FAILED" | head
+python bench.py > gpurun_out/r3_head_bench.log 2>&1; grep '^{' gpurun_out/r3_head_bench.log > gpurun_out/r3_final_bench.json
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r3_final_bench.json'))
+print(d['value'], d['ms_per_step'], d['dtype'], d['roofline']['frac'], d['roofline']['gemm_ms_per_step'])
+for k in ('parity_mode','exact_mode','other_fast_mode'):
+    m=d.get(k); print(k, m and (m['dtype'], m['value'], m['ms_per_step'], (m.get('roofline') or {}).get('frac'), (m.get('roofline') or {}).get('achieved')))
+PY
