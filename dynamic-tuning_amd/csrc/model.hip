@@ -160,6 +160,7 @@ struct dyt_ctx {
     void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
     void* ad_up_ws = nullptr;   // 16-bit modes: scale * up_w (leading k-tile of the fc2 contraction)
     float* ad_down_b;
+    float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
     void* pe_w3 = nullptr;
     bool fc2_cat = true;        // 16-bit modes: adapter up-projection rides on the fc2 GEMM where no separate h is needed
@@ -633,6 +634,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_F32_SPLIT16: {   // fp32 mode only: the frozen-weight GEMMs as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
             if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
             c->split16 = value != 0;
+            if (const char* e = getenv("DYT_SPLIT_GS_LOG2")) c->split_gs = (float)(1u << atoi(e));   // measurement knob
             for (auto& S : c->slots) S.valid = false;
             if (c->split16) {   // parts of the weights uploaded so far (later dyt_set_frozen calls refresh theirs)
                 DYT_HIP_CHECK(hipDeviceSynchronize());   // uploads may be in flight on the caller's streams
@@ -739,7 +741,7 @@ static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return 
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
-#define SPLIT_G(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; (a).a3_scale = 4096.0f; } } while (0)
+#define SPLIT_G(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; (a).a3_scale = c->split_gs; } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // video model: attentive pooling head (video_models/video_vision_transformer_IN21K.py:463-483)
@@ -1240,7 +1242,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
                 a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3);
-                if (c->split16) { a.out3 = T.h3; a.out3_scale = 4096.0f; }   // dZ as the split operand of the fc1 dgrad
+                if (c->split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; }   // dZ as the split operand of the fc1 dgrad
                 if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
                 CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
