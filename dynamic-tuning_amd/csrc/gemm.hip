@@ -735,7 +735,7 @@ static int launch_bf16_bpre(const GemmArgs& a, const Epi& epi, hipStream_t s, in
     if (a.K % 256 != 0 || a.N % 256 != 0) { set_error("gemm_bpre: K=%d and N=%d must be multiples of 256", a.K, a.N); return -1; }
     const int grid = ((m_end - m_begin + 127) / 128) * (a.N / 256);
     hipLaunchKernelGGL((gemm_bf16_bpre_kernel<Epi, ABL>), dim3(grid), dim3(256), 0, s, static_cast<const bf16*>(a.A),
-                       static_cast<const bf16*>(a.W), m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi);
+                       static_cast<const bf16*>(a.W), m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, a.out_scale);
     ++g_bf16_kernel_launches;
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -982,7 +982,7 @@ int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
                            a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
         GemmArgs b = a;
-        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_map = nullptr; b.Wp = nullptr; b.W3 = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_map = nullptr; b.Wp = a.W3p; b.W3 = nullptr; b.W3p = nullptr; b.out_scale = 1.0f / a.a3_scale;
         return dispatch<float, true>(kind, b, s);
     }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;

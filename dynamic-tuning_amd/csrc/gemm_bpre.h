@@ -29,7 +29,7 @@ __global__ void preshuffle_w_kernel(const bf16* __restrict__ W, bf16* __restrict
 template <class Epi, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Wp, int M,
                                                                 int N, int K, const int* __restrict__ m_dev,
-                                                                const int* __restrict__ a_map, int m_begin, Epi epi) {
+                                                                const int* __restrict__ a_map, int m_begin, Epi epi, float out_scale) {
     constexpr int BM = 128, BN = 256, BK = 64, NW = 4, NTHR = 256, SLOTS = 4;
     constexpr int SLOT = BM * BK * 2;            // 16 KB: the activation tile of one K stage
     // One LDS OBJECT per ring slot, and the K loop unrolled over the ring: the compiler's wait-count pass makes every
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
                 for (int u = 0; u < BATCH; ++u) {
                     const int row = m0 + p * PROWS + rl0 + (it0 + u) * RSTEP;
                     if (row < Mv) {
-                        const float v[4] = {c4[u][0], c4[u][1], c4[u][2], c4[u][3]};
+                        const float v[4] = {c4[u][0] * out_scale, c4[u][1] * out_scale, c4[u][2] * out_scale, c4[u][3] * out_scale};   // 1.0 except in the split fp32 form of a gradient GEMM
                         epi.apply(row, col, v, cc, pr[PRE_ALL ? it0 + u : u]);
                     }
                 }
