@@ -1,7 +1,10 @@
 """GPU parity tests added in round 3 (pytest -m gpu), all through the C ABI:
   * the K-concatenated fc2 GEMM (adapter up-projection as the leading k-tile, DYT_OPT_FC2_CAT): the raw kernel forms bitwise
     against the same contraction written as ONE plain GEMM over [A2 | A], and the whole step / inference forward with the
-    option on and off."""
+    option on and off;
+  * the fused attention backward kernel, bit for bit against the two-kernel form;
+  * precision "fp16x3" (DYT_OPT_F32_SPLIT16: frozen-weight GEMMs as three IEEE-half products) against the oracle at the
+    parity bars of the exact-fp32 mode."""
 import pytest
 import torch
 
