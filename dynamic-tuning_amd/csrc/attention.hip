@@ -753,7 +753,8 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_f32_kernel(const float* __res
                                                               const float* __restrict__ v, const float* __restrict__ o,
                                                               const float* __restrict__ dout,
                                                               const float* __restrict__ lse, float* __restrict__ delta,
-                                                              float* __restrict__ dqkv) {
+                                                              float* __restrict__ dqkv, bf16* __restrict__ dqkv3, float s3) {
+    // dqkv3 (fp32 split form): the result times s3 goes out as the 16-bit hi / hi / lo operand of the qkv dgrad GEMM ([M, 3 * 2304])
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
     float* Vs = reinterpret_cast<float*>(smem + F_IMG);
@@ -799,7 +800,16 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_f32_kernel(const float* __res
             dq[1] = MFMA32F(kp[32], s[r], dq[1]);
         }
     }
-    if (qrow < NT) {
+    if (qrow < NT && dqkv3) {
+        bf16* op3 = dqkv3 + ((size_t)b * NT + qrow) * (9 * D) + h * HD;
+        const float sc = 0.125f * s3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4_split3(op3 + dt * 32 + 8 * g + 4 * hi, 3 * D, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc, dq[dt][4 * g + 2] * sc,
+                              dq[dt][4 * g + 3] * sc);
+    } else if (qrow < NT) {
         float* op = dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -816,7 +826,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __re
                                                                const float* __restrict__ dout,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
-                                                               float* __restrict__ dqkv) {
+                                                               float* __restrict__ dqkv, bf16* __restrict__ dqkv3, float s3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Qs = reinterpret_cast<float*>(smem);
     float* dOs = reinterpret_cast<float*>(smem + F_IMG);
@@ -872,7 +882,17 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __re
             aK[1] = MFMA32F(qp[32], s[r], aK[1]);
         }
     }
-    if (key < NT) {
+    if (key < NT && dqkv3) {
+        bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (9 * D) + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hi;
+                store4_split3(op3 + D + d, 3 * D, aK[dt][4 * g] * s3, aK[dt][4 * g + 1] * s3, aK[dt][4 * g + 2] * s3, aK[dt][4 * g + 3] * s3);
+                store4_split3(op3 + 2 * D + d, 3 * D, aV[dt][4 * g] * s3, aV[dt][4 * g + 1] * s3, aV[dt][4 * g + 2] * s3, aV[dt][4 * g + 3] * s3);
+            }
+    } else if (key < NT) {
         float* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -921,7 +941,7 @@ static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV 
 void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
 
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
-                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles) {
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3) {
     const int grid = batch * NH;
     if (dbg_skip(1)) return 0;
     if (precision == 0) {
@@ -934,9 +954,9 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
             *once = true;
         }
         hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3(grid), dim3(448), lds1, s, (const float*)q, (const float*)k,
-                           (const float*)v, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv);
+                           (const float*)v, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3);
         hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3(grid), dim3(448), lds2, s, (const float*)q, (const float*)k,
-                           (const float*)v, (const float*)dout, lse, delta, (float*)dqkv);
+                           (const float*)v, (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3);
     } else {
         const size_t lds1 = 2 * ROW_IMG + TR_IMG;
         const size_t lds2 = 2 * ROW_IMG + 2 * TR_IMG + 2 * NPAD * sizeof(float);

@@ -115,7 +115,7 @@ struct LayerS {  // saved activations of one pass
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
     void* a3 = nullptr;   // fp32 mode: [M, 3 * 3072] 16-bit scratch for the split A operand of a GEMM
-    void *xn3 = nullptr, *h3 = nullptr;   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
+    void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
@@ -316,6 +316,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.a3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
         T.xn3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
         T.h3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
+        T.dqkv3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 9 * D, dry) : nullptr;
         T.dO = carve_at(c, M * D, dry);
         T.dqkv = carve_at(c, M * 3 * D, dry);
         T.dA2 = carve_at(c, M * D, dry);
@@ -1318,10 +1319,11 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         }
         POISON(32, T.dqkv, (size_t)M * 3 * D * c->at);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
-            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7)););   // teacher tail: du, hence dO, is zero off the cls rows
+            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
+                            c->split16 ? T.dqkv3 : nullptr, c->split_gs)););   // teacher tail: du, hence dO, is zero off the cls rows
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
-            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3);
+            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3);
             POISON(1, T.dxn, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * c->at);
