@@ -276,6 +276,8 @@ struct EpiAdDown {
     const uint8_t* keep; int r; float inv_keep; float drop_p; uint64_t seed, subseq;
     const int* row_map;  // token row of compact row `row` (mask / RNG are indexed by token), or null
     const uint64_t* seed_dev;   // overrides `seed` when set (captured graphs draw fresh noise per replay)
+    AT* out_s; float s_out;     // optional second copy s_out * result: the A2 operand of the fc2 + up-projection contraction (the adapter
+                                // scale goes on the O(1) activations, not on the possibly tiny up-projection weights: fp16 subnormals)
     typedef Bias4 Col;
     struct Pre { int trow; };
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
@@ -297,6 +299,7 @@ struct EpiAdDown {
             }
         }
         store4(out + (size_t)row * RP + col, v[0], v[1], v[2], v[3]);
+        if (out_s) store4(out_s + (size_t)row * RP + col, v[0] * s_out, v[1] * s_out, v[2] * s_out, v[3] * s_out);
     }
 };
 
@@ -868,7 +871,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_STORE_F32: return run<AT, SPLIT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
         case EPI_STORE_AT: return run<AT, SPLIT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
-            return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev}, s);
+            return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (AT*)a.out_at2, a.scale}, s);
         case EPI_AD_UP:
             if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr}, s);
             return run<AT, SPLIT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask}, s);

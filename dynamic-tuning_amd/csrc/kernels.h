@@ -34,7 +34,7 @@ struct GemmArgs {
     const int* m_dev = nullptr;   // device-side count of valid rows (<= M), or null
     const int* a_map = nullptr;   // gather: logical A row r is read from A[a_map[r]] (null = identity)
     // K-concatenated form (16-bit kernels, EPI_FC2): C = A2 W2^T + A W^T, A2 [rows,64] (row r read from A2[a2_map[r]]), W2 [N,64];
-    // bias2 / scale: the second pair's bias enters as scale * bias2 (W2 is expected to carry `scale` already)
+    // bias2 / scale: the second pair's bias enters as scale * bias2 (A2 is expected to carry `scale` already)
     const void* A2 = nullptr; const void* W2 = nullptr; const int* a2_map = nullptr; const float* bias2 = nullptr;
     // fp32 mode, "split" form: W3 = the fp32 weight as [N, 3K] 16-bit operands [hi | lo | hi] (launch_split3_w); the fp32 A is split
     // on the fly into a3 [M, 3K] = [hi | hi | lo] and the GEMM runs as ONE 16-bit MFMA contraction over 3K (hi*hi + hi*lo + lo*hi)

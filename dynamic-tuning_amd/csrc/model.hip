@@ -39,7 +39,6 @@ void set_error(const char* fmt, ...) {
 //   down_wT [768,RP]                       dgrad through down_proj (N = 768, K = RP)
 //   up_w    [768,RP] (cols >= r zero)      forward up-projection   (N = 768, K = RP)
 //   up_wT   [RP,768]                       dgrad through up_proj   (N = RP, K = 768)
-//   up_ws   [768,RP] = scale * up_w        the up-projection as the leading k-tile of the fc2 contraction (16-bit modes)
 //   down_b  [RP] fp32
 template <class AT>
 __global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t layer_stride, int64_t off_dw, int64_t off_db,
@@ -114,6 +113,7 @@ struct LayerS {  // saved activations of one pass
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
+    void* dact_s = nullptr;   // 16-bit modes: adapter_scale * d_act, the A2 operand of the fc2 + up-projection contraction
     void* a3 = nullptr;   // fp32 mode: [M, 3 * 3072] 16-bit scratch for the split A operand of a GEMM
     void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
@@ -159,7 +159,6 @@ struct dyt_ctx {
     std::vector<LayerW> W;
     // per-step AT copies of the adapters (all layers contiguous)
     void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
-    void* ad_up_ws = nullptr;   // 16-bit modes: scale * up_w (leading k-tile of the fc2 contraction)
     float* ad_down_b;
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
@@ -254,7 +253,6 @@ static void layout(dyt_ctx* c, bool dry) {
     c->ad_down_wT = carve_at(c, depth * RP * D, dry);
     c->ad_up_w = carve_at(c, depth * RP * D, dry);
     c->ad_up_wT = carve_at(c, depth * RP * D, dry);
-    c->ad_up_ws = c->prec != 0 ? carve_at(c, depth * RP * D, dry) : nullptr;
     c->ad_down_b = carve<float>(c, depth * RP, dry);
     c->slots.resize(cf.slots);
     for (int s = 0; s < cf.slots; ++s) {
@@ -313,6 +311,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.ddz = carve_at(c, M * RP, dry);
         T.du_at = carve_at(c, M * D, dry);
         T.dad = c->prec != DYT_PREC_FP32 ? carve_at(c, M * D, dry) : nullptr;
+        T.dact_s = c->prec != DYT_PREC_FP32 ? carve_at(c, M * RP, dry) : nullptr;
         T.a3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
         T.xn3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
         T.h3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
@@ -712,7 +711,7 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     else
         hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (bf16*)c->ad_down_w, (bf16*)c->ad_down_wT, (bf16*)c->ad_up_w,
-                           (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)c->ad_up_ws, c->cfg.adapter_scale);
+                           (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)nullptr, 0.f);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -936,6 +935,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
             a.row_map = tail ? c->cls_rows : nullptr;
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1); a.seed_dev = seed_dev;
+            if (cat) { a.out_at2 = T.dact_s; a.scale = c->cfg.adapter_scale; }
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
         GemmArgs up; up.A = L.d_act; up.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); up.M = Mr; up.N = D; up.K = RP;
@@ -990,7 +990,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
             SPLIT(a, W.fc2_w3); SPLIT_READY(a, T.h3);
             if (cat) {
-                a.A2 = L.d_act; a.W2 = at_off(c, c->ad_up_ws, (size_t)l * RP * D);
+                a.A2 = T.dact_s; a.W2 = at_off(c, c->ad_up_w, (size_t)l * RP * D);   // [s d_act | h] x [W_up | W2]^T
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
                 a.bias2 = base + c->off_ub; a.scale = c->cfg.adapter_scale; a.resid = L.u;
             }
