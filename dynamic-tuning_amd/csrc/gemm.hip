@@ -387,12 +387,12 @@ __device__ unsigned long long g_gemm_dbg[4];
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
 struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; };   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
-template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
+// One workgroup = one tile: `bid` of `nwg` logical workgroups that tile rows [m_begin, M).  A device function so that one launch
+// can hold workgroups of two tile shapes (gemm_bf16_rows_kernel below).
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT>
+__device__ __forceinline__ void gemm_bf16_nt_tile(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
-    const int* __restrict__ a_map, int m_begin, Epi epi, CatArgs cat) {
-    // rows [m_begin, M) are tiled by this launch (a GEMM may be covered by two launches with different tiles)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int* __restrict__ a_map, int m_begin, const Epi& epi, const CatArgs& cat, int bid, int nwg, char* smem) {
     constexpr int BK = 64;
     constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -404,7 +404,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
     const int Mv = m_dev ? min(*m_dev, M) : M;
     // XCD-aware block remap (bijective): consecutive logical tiles share an A row panel and
     // should land on the same XCD's L2; hardware places block b on XCD b % 8.
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     const int tiles_n = N / BN;
@@ -690,6 +689,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
     }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
+    const int* __restrict__ a_map, int m_begin, Epi epi, CatArgs cat) {
+    // rows [m_begin, M) are tiled by this launch
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x, smem);
+}
+
+// Narrow-N GEMM (N = 768) in ONE launch: the first n_big workgroups take 256x256 tiles of rows [0, body) -- whole rounds of the
+// 256 CUs --, the others 128x128 tiles (eight waves as 2x4) of rows [body, M).  Both shapes accumulate every dot product in the
+// same k order, so results do not depend on where the split falls; a compacted launch (device-side row count) leaves the
+// workgroups beyond the count with nothing to do instead of a second, empty launch.
+template <class Epi, bool CAT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_rows_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
+    const int* __restrict__ a_map, int body, int n_big, Epi epi, CatArgs cat) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (b < n_big) gemm_bf16_nt_tile<256, 256, 2, 4, Epi, 0, CAT>(A, W, body, N, K, m_dev, a_map, 0, epi, cat, b, n_big, smem);
+    else gemm_bf16_nt_tile<128, 128, 2, 4, Epi, 0, CAT>(A, W, M, N, K, m_dev, a_map, body, epi, cat, b - n_big, (int)gridDim.x - n_big, smem);
+}
+
 }  // namespace dyt
 #include "gemm_bpre.h"
 #include "gemm_f32_mfma.h"
@@ -726,6 +748,26 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
     const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, cat);
+    ++g_bf16_kernel_launches;
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <class Epi, bool CAT>
+static int launch_bf16_rows(const GemmArgs& a, const Epi& epi, hipStream_t s, int body) {
+    const int n_big = (body / 256) * (a.N / 256), n_small = ((a.M - body + 127) / 128) * (a.N / 128);
+    const size_t lds = 2 * (256 + 256) * 64 * 2;
+    auto kern = gemm_bf16_rows_kernel<Epi, CAT>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    DYT_HIP_CHECK(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev & 63] = true;
+    }
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale};
+    hipLaunchKernelGGL(kern, dim3(n_big + n_small), dim3(512), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W), a.M, a.N,
+                       a.K, a.m_dev, a.a_map, body, n_big, epi, cat);
     ++g_bf16_kernel_launches;
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -792,6 +834,11 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         if (rounds >= 1 || rem >= 3 * NCU / 4) {
             if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
             const int body = (rounds * NCU / tn) * 256;
+            // DYT_GEMM_ROWS_ONE_LAUNCH=1: both tile shapes in one launch (gemm_bf16_rows_kernel).  Measured: serial step 29.66 -> 29.17 ms
+            // (no second launch, no empty tail launches of compacted GEMMs), but the overlapped step 26.5-26.8 -> 27.07 ms: the tail
+            // workgroups then hold 128 KB of LDS like the big ones and keep the other pass's 64 KB kernels off their CUs.  Off.
+            static const bool one_launch = getenv("DYT_GEMM_ROWS_ONE_LAUNCH") && atoi(getenv("DYT_GEMM_ROWS_ONE_LAUNCH"));
+            if (one_launch) return launch_bf16_rows<Epi, CAT>(a, epi, s, body);
             int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s, 0, body);
             if (rc) return rc;
             return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT>(a, epi, s, body, a.M);
