@@ -392,7 +392,8 @@ struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_sc
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT>
 __device__ __forceinline__ void gemm_bf16_nt_tile(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
-    const int* __restrict__ a_map, int m_begin, const Epi& epi, const CatArgs& cat, int bid, int nwg, char* smem) {
+    const int* __restrict__ a_map, int m_begin, const Epi& epi, const CatArgs& cat, int bid, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // declared HERE, not passed in: a generic char* would lose the LDS address space
     constexpr int BK = 64;
     constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -694,8 +695,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, int m_begin, Epi epi, CatArgs cat) {
     // rows [m_begin, M) are tiled by this launch
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x, smem);
+    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x);
 }
 
 // Narrow-N GEMM (N = 768) in ONE launch: the first n_big workgroups take 256x256 tiles of rows [0, body) -- whole rounds of the
@@ -706,10 +706,9 @@ template <class Epi, bool CAT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_rows_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, int body, int n_big, Epi epi, CatArgs cat) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
-    if (b < n_big) gemm_bf16_nt_tile<256, 256, 2, 4, Epi, 0, CAT>(A, W, body, N, K, m_dev, a_map, 0, epi, cat, b, n_big, smem);
-    else gemm_bf16_nt_tile<128, 128, 2, 4, Epi, 0, CAT>(A, W, M, N, K, m_dev, a_map, body, epi, cat, b - n_big, (int)gridDim.x - n_big, smem);
+    if (b < n_big) gemm_bf16_nt_tile<256, 256, 2, 4, Epi, 0, CAT>(A, W, body, N, K, m_dev, a_map, 0, epi, cat, b, n_big);
+    else gemm_bf16_nt_tile<128, 128, 2, 4, Epi, 0, CAT>(A, W, M, N, K, m_dev, a_map, body, epi, cat, b - n_big, (int)gridDim.x - n_big);
 }
 
 }  // namespace dyt
@@ -834,8 +833,8 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         if (rounds >= 1 || rem >= 3 * NCU / 4) {
             if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
             const int body = (rounds * NCU / tn) * 256;
-            // DYT_GEMM_ROWS_ONE_LAUNCH=1: both tile shapes in one launch (gemm_bf16_rows_kernel).  Measured: serial step 29.66 -> 29.17 ms
-            // (no second launch, no empty tail launches of compacted GEMMs), but the overlapped step 26.5-26.8 -> 27.07 ms: the tail
+            // DYT_GEMM_ROWS_ONE_LAUNCH=1: both tile shapes in one launch (gemm_bf16_rows_kernel).  Measured: serial step 29.48 -> 28.92 ms
+            // (no second launch, no empty tail launches of compacted GEMMs), but the overlapped step 26.2-26.4 -> 26.7 ms: the tail
             // workgroups then hold 128 KB of LDS like the big ones and keep the other pass's 64 KB kernels off their CUs.  Off.
             static const bool one_launch = getenv("DYT_GEMM_ROWS_ONE_LAUNCH") && atoi(getenv("DYT_GEMM_ROWS_ONE_LAUNCH"));
             if (one_launch) return launch_bf16_rows<Epi, CAT>(a, epi, s, body);
