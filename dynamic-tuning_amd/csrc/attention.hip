@@ -906,6 +906,155 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, fp32 operands as 16-bit hi / lo parts (the fp32 mode's DYT_OPT_F32_SPLIT16 form)
+// ------------------------------------------------------------------------------------------
+// The tiling, layouts and lane mapping of attn_fwd_bf16_kernel with every product computed as hi*hi + hi*lo + lo*hi of two
+// 16-bit parts per fp32 operand (x = hi + lo, hi = rn16(x), lo = rn16(x - hi); the dropped lo*lo term is 2^-22 relative): K as
+// two row images, V^T as two transposed images (122.9 KB of LDS), q split in registers, the probabilities split per key tile
+// right where they are packed.  fp32 accumulation, fp32 softmax statistics, fp32 output.  Persistent over heads, no
+// cross-head prefetch (the fp32 rows would double the staging registers).
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (bf16)x0[i]; lo[i] = (bf16)(x0[i] - (float)hi[i]);
+        hi[4 + i] = (bf16)x1[i]; lo[4 + i] = (bf16)(x1[i] - (float)hi[4 + i]);
+    }
+}
+__global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, float* __restrict__ out,
+                                                             float* __restrict__ lse, int nheads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Kh = reinterpret_cast<bf16*>(smem);
+    bf16* Kl = reinterpret_cast<bf16*>(smem + ROW_IMG);
+    bf16* Vth = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG);
+    bf16* Vtl = reinterpret_cast<bf16*>(smem + 2 * ROW_IMG + TR_IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);
+    for (int bh = blockIdx.x; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        // ---- stage K (two row images) and V (two transposed images): task = (row pair, 8-column chunk), 896 tasks / 448 threads
+        const float* kb = k + (size_t)bh * NT * HD;
+        const float* vb = v + (size_t)bh * NT * HD;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + u * 448, pr = t >> 3, c = t & 7, r0 = pr * 2;
+            const float* k0 = kb + (size_t)min(r0, NT - 1) * HD + c * 8;
+            const float* k1 = kb + (size_t)min(r0 + 1, NT - 1) * HD + c * 8;
+            const float* v0 = vb + (size_t)min(r0, NT - 1) * HD + c * 8;
+            const float* v1 = vb + (size_t)min(r0 + 1, NT - 1) * HD + c * 8;
+            const f32x4 ka0 = *reinterpret_cast<const f32x4*>(k0), ka1 = *reinterpret_cast<const f32x4*>(k0 + 4);
+            const f32x4 kb0 = *reinterpret_cast<const f32x4*>(k1), kb1 = *reinterpret_cast<const f32x4*>(k1 + 4);
+            const f32x4 va0 = *reinterpret_cast<const f32x4*>(v0), va1 = *reinterpret_cast<const f32x4*>(v0 + 4);
+            const f32x4 vb0 = *reinterpret_cast<const f32x4*>(v1), vb1 = *reinterpret_cast<const f32x4*>(v1 + 4);
+            bf16x8 ah, al, bhh, bl;
+            split8(ka0, ka1, ah, al); split8(kb0, kb1, bhh, bl);
+            if (r0 >= NT) { ah = zero8(); al = zero8(); }
+            if (r0 + 1 >= NT) { bhh = zero8(); bl = zero8(); }
+            *reinterpret_cast<bf16x8*>(Kh + r0 * RLD + c * 8) = ah;
+            *reinterpret_cast<bf16x8*>(Kl + r0 * RLD + c * 8) = al;
+            *reinterpret_cast<bf16x8*>(Kh + (r0 + 1) * RLD + c * 8) = bhh;
+            *reinterpret_cast<bf16x8*>(Kl + (r0 + 1) * RLD + c * 8) = bl;
+            split8(va0, va1, ah, al); split8(vb0, vb1, bhh, bl);
+            if (r0 >= NT) { ah = zero8(); al = zero8(); }
+            if (r0 + 1 >= NT) { bhh = zero8(); bl = zero8(); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf16x2 ph = {ah[i], bhh[i]}, pl = {al[i], bl[i]};
+                *reinterpret_cast<bf16x2*>(Vth + (c * 8 + i) * TLD + r0) = ph;
+                *reinterpret_cast<bf16x2*>(Vtl + (c * 8 + i) * TLD + r0) = pl;
+            }
+        }
+        // ---- this wave's 32 query rows, split
+        bf16x8 qh[4], ql[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* qp = q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8;
+            split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[ks], ql[ks]);
+        }
+        __syncthreads();
+        f32x16 st[7];
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Kh + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(Kl + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                st[kt] = MFMA32(al, qh[ks], st[kt]);   // small terms first
+                st[kt] = MFMA32(ah, ql[ks], st[kt]);
+                st[kt] = MFMA32(ah, qh[ks], st[kt]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 192 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= NT) st[6][r] = -INFINITY;
+        }
+        float mp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mp[r & 3] = fmaxf(mp[r & 3], st[kt][r]);
+        float m = fmaxf(fmaxf(mp[0], mp[1]), fmaxf(mp[2], mp[3]));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sp[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x16 o[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt) {
+            bf16x8 vh[2][2], vl[2][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    vh[half][dt] = join44(Vth + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
+                    vl[half][dt] = join44(Vtl + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(st[kt][r] - m);
+                st[kt][r] = p;
+                sp[r & 3] += p;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p = st[kt][half * 8 + i];
+                    ph[i] = (bf16)p; pl[i] = (bf16)(p - (float)ph[i]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    o[dt] = MFMA32(vl[half][dt], ph, o[dt]);
+                    o[dt] = MFMA32(vh[half][dt], pl, o[dt]);
+                    o[dt] = MFMA32(vh[half][dt], ph, o[dt]);
+                }
+            }
+        }
+        float sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        sum += __shfl_xor(sum, 32, 64);
+        if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = m + logf(sum);
+        if (qrow < NT) {
+            const float inv = 1.0f / sum;
+            float* op = out + ((size_t)b * NT + qrow) * D + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store4(op + dt * 32 + 8 * g + 4 * hi, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
+                           o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        }
+        __syncthreads();   // every wave is done with this head's images before they are overwritten
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 static int set_lds(const void* f, size_t bytes) {
     DYT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
@@ -918,11 +1067,22 @@ static bool* attr_flag(int family) {
     return &done[family][dev & 63];
 }
 
+static int g_attn_f32_split = 0;   // process-wide: the split forward kernel for every fp32-mode call (unit entries; contexts pass their own flag)
+void set_attn_f32_split(int on) { g_attn_f32_split = on; }
+
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
-                    hipStream_t s) {
+                    hipStream_t s, int split16) {
     const int grid = batch * NH;
     if (dbg_skip(2)) return 0;
-    if (precision == 0) {
+    if (precision == 0 && (split16 || g_attn_f32_split)) {
+        const size_t lds = 2 * ROW_IMG + 2 * TR_IMG;
+        static bool done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (!done[dev & 63]) { if (set_lds((const void*)attn_fwd_split_kernel, lds)) return -2; done[dev & 63] = true; }
+        hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const float*)q, (const float*)k,
+                           (const float*)v, (float*)out, lse, grid);
+    } else if (precision == 0) {
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);
         bool* once = attr_flag(0);
         if (!*once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; *once = true; }

@@ -84,7 +84,8 @@ int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int
 // ------------------------------------------------------------------------------------------
 // q,k,v: [B*12][197][64] AT ; out: [B*197][768] AT ; lse: [B*12][197] f32
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
-                    int batch, hipStream_t s);
+                    int batch, hipStream_t s, int split16 = 0);   // split16 (fp32 mode): products as three 16-bit MFMA products
+void set_attn_f32_split(int on);   // process-wide version of split16 (unit entries)
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
                     const void* dout, const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles = 7,

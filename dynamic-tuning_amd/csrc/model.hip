@@ -160,6 +160,7 @@ struct dyt_ctx {
     // per-step AT copies of the adapters (all layers contiguous)
     void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
     float* ad_down_b;
+    bool split_attn = true;     // ... and the attention forward too (attn_fwd_split_kernel; DYT_SPLIT_ATTN=0: exact fp32 MFMA kernel)
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
     void* pe_w3 = nullptr;
@@ -641,6 +642,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
             c->split16 = value != 0;
             if (const char* e = getenv("DYT_SPLIT_GS_LOG2")) c->split_gs = (float)(1u << atoi(e));   // measurement knob
+            if (const char* e = getenv("DYT_SPLIT_ATTN")) c->split_attn = atoi(e) != 0;
             for (auto& S : c->slots) S.valid = false;
             if (c->split16) {   // parts of the weights uploaded so far (later dyt_set_frozen calls refresh theirs)
                 DYT_HIP_CHECK(hipDeviceSynchronize());   // uploads may be in flight on the caller's streams
@@ -662,6 +664,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
 
 extern "C" int dyt_set_global_option(int option, int value) {
     if (option == DYT_OPT_ATTN_BWD_FUSED) { set_attn_bwd_fused(value); return DYT_OK; }
+    if (option == DYT_OPT_F32_SPLIT16) { set_attn_f32_split(value); return DYT_OK; }   // unit entry dyt_attention(precision 0): split forward kernel
     set_error("option %d is not process-wide", option);
     return DYT_ERR_ARG;
 }
@@ -897,7 +900,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3); SPLIT_P(a, W.qkv_w3p); SPLIT_READY(a, T.xn3);
                 RUN_GEMM(EPI_QKV, a);
             }
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s));
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s, c->split16 && c->split_attn));
             if (c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows

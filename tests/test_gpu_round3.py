@@ -172,3 +172,28 @@ def test_split_fp16x3_mode_meets_the_fp32_parity_bars(mode):
             worst, wname = e, n
         assert e < 2e-3, (n, e)
     print("fp16x3/%s worst gradient rel-L2 %.2e (%s)" % (mode, worst, wname))
+
+
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_split_attention_forward_matches_fp64(B):
+    """attn_fwd_split_kernel (fp32 q / k / v / probabilities as two IEEE-half parts, three MFMA products per fp32-class product;
+    the fp16x3 mode's attention forward, Attention.forward models/vision_transformer_IN21K.py:60-70) against the fp64 reference
+    at the tolerance of the exact-fp32 MFMA kernel, and against that kernel."""
+    import gpu_diag as D
+    import _lib
+    from _lib import check, ptr, stream_ptr
+    L = _lib.lib(fp16=True)
+    g = torch.Generator().manual_seed(20 + B)
+    qkv = torch.randn(B * 197, 2304, generator=g) * 1.5
+    ref_o, _ = D.attn_ref(qkv, B)
+    outs = []
+    for split in (0, 1):
+        check(L.dyt_set_global_option(_lib.OPT_F32_SPLIT16, split))
+        out = torch.full((B * 197, 768), float("nan"), device="cuda")
+        check(L.dyt_attention(ptr(qkv.cuda()), ptr(out), None, None, B, 0, stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    check(L.dyt_set_global_option(_lib.OPT_F32_SPLIT16, 0))
+    e_exact, e_split = D.relerr(outs[0], ref_o), D.relerr(outs[1], ref_o)
+    print("attention forward vs fp64: exact-fp32 kernel %.2e, split kernel %.2e" % (e_exact, e_split))
+    assert e_split < 2e-5 and e_split < 4 * e_exact + 1e-6, (e_exact, e_split)
