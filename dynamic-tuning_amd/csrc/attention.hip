@@ -1055,6 +1055,263 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, fp32 operands as 16-bit hi / lo parts (DYT_OPT_F32_SPLIT16)
+// ------------------------------------------------------------------------------------------
+// The two-kernel backward of the bf16 path (dQ per query tile, dK/dV per key tile, lane mapping and fragment layouts unchanged)
+// with every product as hi*hi + hi*lo + lo*hi.  Every LDS image exists twice (hi, lo), so a head is staged in two HALVES of
+// 128 rows (keys for dQ: 108 KB; queries for dK/dV: 142 KB); the accumulators live across the halves.  fp32 in, fp32
+// statistics (lse, delta), output either fp32 or -- times s3 -- directly as the split operand of the qkv dgrad GEMM.
+// dO is multiplied by gs (a power of two) before it is split, which carries through dP, dS, dQ, dK, dV: gradient-sized values
+// would otherwise put their lo parts (and many hi parts) into the fp16 subnormals; the outputs are divided by gs again.
+constexpr int HROWS = 128;                 // rows staged per half (4 tiles of 32; the second half holds tiles 4..6)
+constexpr int TLDH = HROWS + 4;            // 16-bit elements per row of a transposed half image (264 B: conflict-free b64 reads)
+constexpr int ROW_H = HROWS * RLD * 2;     // 18432 B
+constexpr int TR_H = HD * TLDH * 2;        // 16896 B
+
+// rows [row0, row0 + 128) of a [197][64] fp32 matrix (row stride ld) -> hi / lo row images and / or hi / lo transposed images
+__device__ __forceinline__ void stage_split_half(const float* __restrict__ src, size_t ld, int row0, bf16* rH, bf16* rL, bf16* tH,
+                                                 bf16* tL, int tid, float scale = 1.0f) {
+    for (int t = tid; t < (HROWS / 2) * 8; t += 448) {
+        const int pr = t >> 3, c = t & 7, r0 = pr * 2, g0 = row0 + r0;
+        const float* p0 = src + (size_t)min(g0, NT - 1) * ld + c * 8;
+        const float* p1 = src + (size_t)min(g0 + 1, NT - 1) * ld + c * 8;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0) * scale, a1 = *reinterpret_cast<const f32x4*>(p0 + 4) * scale;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1) * scale, b1 = *reinterpret_cast<const f32x4*>(p1 + 4) * scale;
+        bf16x8 ah, al, bh, bl;
+        split8(a0, a1, ah, al); split8(b0, b1, bh, bl);
+        if (g0 >= NT) { ah = zero8(); al = zero8(); }
+        if (g0 + 1 >= NT) { bh = zero8(); bl = zero8(); }
+        if (rH) {
+            *reinterpret_cast<bf16x8*>(rH + r0 * RLD + c * 8) = ah;
+            *reinterpret_cast<bf16x8*>(rL + r0 * RLD + c * 8) = al;
+            *reinterpret_cast<bf16x8*>(rH + (r0 + 1) * RLD + c * 8) = bh;
+            *reinterpret_cast<bf16x8*>(rL + (r0 + 1) * RLD + c * 8) = bl;
+        }
+        if (tH) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf16x2 ph = {ah[i], bh[i]}, pl = {al[i], bl[i]};
+                *reinterpret_cast<bf16x2*>(tH + (c * 8 + i) * TLDH + r0) = ph;
+                *reinterpret_cast<bf16x2*>(tL + (c * 8 + i) * TLDH + r0) = pl;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void split_pack8(const f32x16& v, int base, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { hi[i] = (bf16)v[base + i]; lo[i] = (bf16)(v[base + i] - (float)hi[i]); }
+}
+// acc += A B with A = (ah, al), B = (bh, bl): small terms first
+#define MFMA3(acc, ah, al, bh, bl) do { acc = MFMA32(al, bh, acc); acc = MFMA32(ah, bl, acc); acc = MFMA32(ah, bh, acc); } while (0)
+
+__global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ o,
+                                                                const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                float* __restrict__ delta, float* __restrict__ dqkv,
+                                                                bf16* __restrict__ dqkv3, float s3, int nheads, float gs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Kh = reinterpret_cast<bf16*>(smem);
+    bf16* Kl = reinterpret_cast<bf16*>(smem + ROW_H);
+    bf16* Vh = reinterpret_cast<bf16*>(smem + 2 * ROW_H);
+    bf16* Vl = reinterpret_cast<bf16*>(smem + 3 * ROW_H);
+    bf16* Kth = reinterpret_cast<bf16*>(smem + 4 * ROW_H);
+    bf16* Ktl = reinterpret_cast<bf16*>(smem + 4 * ROW_H + TR_H);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow = wave * 32 + l31, qr = min(qrow, NT - 1);
+    for (int bh = blockIdx.x; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        bf16x8 qh[4], ql[4], doh[4], dol[4];
+        float dl = 0.f;
+        {
+            const float* qp = q + ((size_t)bh * NT + qr) * HD + hi * 8;
+            const size_t trow = ((size_t)b * NT + qr) * D + h * HD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp + ks * 16), q1 = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dout + trow + ks * 16), d1 = *reinterpret_cast<const f32x4*>(dout + trow + ks * 16 + 4);
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(o + trow + ks * 16), o1 = *reinterpret_cast<const f32x4*>(o + trow + ks * 16 + 4);
+                split8(q0, q1, qh[ks], ql[ks]);
+                split8(d0 * gs, d1 * gs, doh[ks], dol[ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dl += d0[i] * o0[i] + d1[i] * o1[i];
+            }
+        }
+        const float L = lse[(size_t)bh * NT + qr];
+        dl += __shfl_xor(dl, 32, 64);
+        if (hi == 0 && qrow < NT) delta[(size_t)bh * NT + qrow] = dl;
+        const float dlg = dl * gs;
+        f32x16 dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();   // the previous half's (head's) images are no longer read
+            stage_split_half(k + (size_t)bh * NT * HD, HD, hf * HROWS, Kh, Kl, Kth, Ktl, tid);
+            stage_split_half(v + (size_t)bh * NT * HD, HD, hf * HROWS, Vh, Vl, nullptr, nullptr, tid);
+            __syncthreads();
+            const int ntile = hf == 0 ? 4 : 3;
+#pragma unroll 1
+            for (int t = 0; t < ntile; ++t) {
+                f32x16 s_, dp_;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp_[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int off = (t * 32 + l31) * RLD + ks * 16 + hi * 8;
+                    const bf16x8 kah = *reinterpret_cast<const bf16x8*>(Kh + off), kal = *reinterpret_cast<const bf16x8*>(Kl + off);
+                    const bf16x8 vah = *reinterpret_cast<const bf16x8*>(Vh + off), val = *reinterpret_cast<const bf16x8*>(Vl + off);
+                    MFMA3(s_, kah, kal, qh[ks], ql[ks]);
+                    MFMA3(dp_, vah, val, doh[ks], dol[ks]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (hf * 4 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float p = key < NT ? expf(s_[r] - L) : 0.f;
+                    s_[r] = p * (dp_[r] - dlg);       // gs * dS^T
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    bf16x8 dsh, dsl;
+                    split_pack8(s_, half * 8, dsh, dsl);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int toff = (dt * 32 + l31) * TLDH + t * 32 + half * 16 + 4 * hi;
+                        const bf16x8 kth = join44(Kth + toff), ktl = join44(Ktl + toff);
+                        MFMA3(dq[dt], kth, ktl, dsh, dsl);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+                    }
+                }
+            }
+        }
+        if (qrow < NT) {
+            const float sc = 0.125f * (dqkv3 ? s3 : 1.0f) / gs;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * hi;
+                    if (dqkv3) store4_split3(dqkv3 + ((size_t)b * NT + qrow) * (9 * D) + h * HD + d, 3 * D, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
+                                             dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc);
+                    else store4(dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD + d, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
+                                dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc);
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const float* __restrict__ dout,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 float* __restrict__ dqkv, bf16* __restrict__ dqkv3, float s3, int nheads, float gs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Qh = reinterpret_cast<bf16*>(smem);
+    bf16* Ql = reinterpret_cast<bf16*>(smem + ROW_H);
+    bf16* Dh = reinterpret_cast<bf16*>(smem + 2 * ROW_H);
+    bf16* Dl = reinterpret_cast<bf16*>(smem + 3 * ROW_H);
+    bf16* Qth = reinterpret_cast<bf16*>(smem + 4 * ROW_H);
+    bf16* Qtl = reinterpret_cast<bf16*>(smem + 4 * ROW_H + TR_H);
+    bf16* Dth = reinterpret_cast<bf16*>(smem + 4 * ROW_H + 2 * TR_H);
+    bf16* Dtl = reinterpret_cast<bf16*>(smem + 4 * ROW_H + 3 * TR_H);
+    float* lse_s = reinterpret_cast<float*>(smem + 4 * ROW_H + 4 * TR_H);
+    float* del_s = lse_s + HROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int key = wave * 32 + l31, kr_ = min(key, NT - 1);
+    for (int bh = blockIdx.x; bh < nheads; bh += gridDim.x) {
+        const int b = bh / NH, h = bh - b * NH;
+        bf16x8 kh[4], kl[4], vh[4], vl[4];
+        {
+            const float* kp = k + ((size_t)bh * NT + kr_) * HD + hi * 8;
+            const float* vp = v + ((size_t)bh * NT + kr_) * HD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                split8(*reinterpret_cast<const f32x4*>(kp + ks * 16), *reinterpret_cast<const f32x4*>(kp + ks * 16 + 4), kh[ks], kl[ks]);
+                split8(*reinterpret_cast<const f32x4*>(vp + ks * 16), *reinterpret_cast<const f32x4*>(vp + ks * 16 + 4), vh[ks], vl[ks]);
+            }
+        }
+        f32x16 aK[2], aV[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+            stage_split_half(q + (size_t)bh * NT * HD, HD, hf * HROWS, Qh, Ql, Qth, Qtl, tid);
+            stage_split_half(dout + (size_t)b * NT * D + h * HD, D, hf * HROWS, Dh, Dl, Dth, Dtl, tid, gs);
+            if (tid < HROWS) {
+                const int qg = hf * HROWS + tid;
+                lse_s[tid] = qg < NT ? lse[(size_t)bh * NT + qg] : 0.f;
+                del_s[tid] = qg < NT ? delta[(size_t)bh * NT + qg] * gs : 0.f;
+            }
+            __syncthreads();
+            const int ntile = hf == 0 ? 4 : 3;
+#pragma unroll 1
+            for (int t = 0; t < ntile; ++t) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int off = (t * 32 + l31) * RLD + ks * 16 + hi * 8;
+                    const bf16x8 qah = *reinterpret_cast<const bf16x8*>(Qh + off), qal = *reinterpret_cast<const bf16x8*>(Ql + off);
+                    const bf16x8 dah = *reinterpret_cast<const bf16x8*>(Dh + off), dal = *reinterpret_cast<const bf16x8*>(Dl + off);
+                    MFMA3(s, qah, qal, kh[ks], kl[ks]);      // S[q][key]
+                    MFMA3(dp, dah, dal, vh[ks], vl[ks]);     // dP[q][key]
+                }
+                f32x16 p;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int q0 = t * 32 + 8 * g + 4 * hi;   // row inside the half
+                    const float4 L4 = *reinterpret_cast<const float4*>(lse_s + q0);
+                    const float4 D4 = *reinterpret_cast<const float4*>(del_s + q0);
+                    const float Ls[4] = {L4.x, L4.y, L4.z, L4.w};
+                    const float Ds[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const bool ok = (hf * HROWS + q0 + e < NT) && (key < NT);
+                        const float pv = ok ? expf(s[r] - Ls[e]) : 0.f;
+                        p[r] = pv;
+                        s[r] = pv * (dp[r] - Ds[e]);  // dS
+                    }
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    bf16x8 ph, pl, dsh, dsl;
+                    split_pack8(p, half * 8, ph, pl);
+                    split_pack8(s, half * 8, dsh, dsl);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int toff = (dt * 32 + l31) * TLDH + t * 32 + half * 16 + 4 * hi;
+                        const bf16x8 doth = join44(Dth + toff), dotl = join44(Dtl + toff);
+                        const bf16x8 qth = join44(Qth + toff), qtl = join44(Qtl + toff);
+                        MFMA3(aV[dt], doth, dotl, ph, pl);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+                        MFMA3(aK[dt], qth, qtl, dsh, dsl);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                    }
+                }
+            }
+        }
+        if (key < NT) {
+            const float sc = (dqkv3 ? s3 : 1.0f) / gs;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * hi;
+                    if (dqkv3) {
+                        bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (9 * D) + h * HD + d;
+                        store4_split3(op3 + D, 3 * D, aK[dt][4 * g] * sc, aK[dt][4 * g + 1] * sc, aK[dt][4 * g + 2] * sc, aK[dt][4 * g + 3] * sc);
+                        store4_split3(op3 + 2 * D, 3 * D, aV[dt][4 * g] * sc, aV[dt][4 * g + 1] * sc, aV[dt][4 * g + 2] * sc, aV[dt][4 * g + 3] * sc);
+                    } else {
+                        float* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD + d;
+                        store4(op + D, aK[dt][4 * g] * sc, aK[dt][4 * g + 1] * sc, aK[dt][4 * g + 2] * sc, aK[dt][4 * g + 3] * sc);
+                        store4(op + 2 * D, aV[dt][4 * g] * sc, aV[dt][4 * g + 1] * sc, aV[dt][4 * g + 2] * sc, aV[dt][4 * g + 3] * sc);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 static int set_lds(const void* f, size_t bytes) {
     DYT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
@@ -1101,9 +1358,27 @@ static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV 
 void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
 
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
-                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3) {
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16) {
     const int grid = batch * NH;
     if (dbg_skip(1)) return 0;
+    if (precision == 0 && (split16 || g_attn_f32_split)) {
+        const size_t lds1 = 4 * ROW_H + 2 * TR_H, lds2 = 4 * ROW_H + 4 * TR_H + 2 * HROWS * sizeof(float);
+        static bool done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (!done[dev & 63]) {
+            if (set_lds((const void*)attn_bwd_dq_split_kernel, lds1)) return -2;
+            if (set_lds((const void*)attn_bwd_dkv_split_kernel, lds2)) return -2;
+            done[dev & 63] = true;
+        }
+        static const float gs_unit = getenv("DYT_SPLIT_ATTN_GS") ? (float)atof(getenv("DYT_SPLIT_ATTN_GS")) : 4096.0f;   // unit entries (no context)
+        hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(min(grid, 256)), dim3(448), lds1, s, (const float*)q, (const float*)k, (const float*)v,
+                           (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit);
+        hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(min(grid, 256)), dim3(448), lds2, s, (const float*)q, (const float*)k, (const float*)v,
+                           (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit);
+        DYT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (precision == 0) {
         const size_t lds1 = 2 * F_IMG;
         const size_t lds2 = 2 * F_IMG + 2 * NPAD * sizeof(float);

@@ -1323,7 +1323,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         POISON(32, T.dqkv, (size_t)M * 3 * D * c->at);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
-                            c->split16 ? T.dqkv3 : nullptr, c->split_gs)););   // teacher tail: du, hence dO, is zero off the cls rows
+                            c->split16 ? T.dqkv3 : nullptr, c->split_gs, c->split16 && c->split_attn)););   // teacher tail: du, hence dO, is zero off the cls rows
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
             GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3);

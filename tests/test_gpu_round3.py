@@ -175,25 +175,40 @@ def test_split_fp16x3_mode_meets_the_fp32_parity_bars(mode):
 
 
 @pytest.mark.parametrize("B", [1, 3, 64])
-def test_split_attention_forward_matches_fp64(B):
-    """attn_fwd_split_kernel (fp32 q / k / v / probabilities as two IEEE-half parts, three MFMA products per fp32-class product;
-    the fp16x3 mode's attention forward, Attention.forward models/vision_transformer_IN21K.py:60-70) against the fp64 reference
-    at the tolerance of the exact-fp32 MFMA kernel, and against that kernel."""
+def test_split_attention_matches_fp64(B):
+    """attn_fwd_split_kernel / attn_bwd_dq_split_kernel / attn_bwd_dkv_split_kernel (fp32 q / k / v / dO / probabilities / dS as two
+    IEEE-half parts, three MFMA products per fp32-class product; the fp16x3 mode's attention, Attention.forward
+    models/vision_transformer_IN21K.py:60-70 and its autograd backward) against the fp64 reference at the tolerance of the
+    exact-fp32 MFMA kernels, and against those kernels."""
     import gpu_diag as D
     import _lib
     from _lib import check, ptr, stream_ptr
     L = _lib.lib(fp16=True)
     g = torch.Generator().manual_seed(20 + B)
     qkv = torch.randn(B * 197, 2304, generator=g) * 1.5
-    ref_o, _ = D.attn_ref(qkv, B)
-    outs = []
+    dout = torch.randn(B * 197, 768, generator=g) * 1e-3   # gradient-sized: the split kernels scale dO by 2^12 before splitting
+    ref_o, ref_dq = D.attn_ref(qkv, B, dout)
+    res = []
     for split in (0, 1):
         check(L.dyt_set_global_option(_lib.OPT_F32_SPLIT16, split))
         out = torch.full((B * 197, 768), float("nan"), device="cuda")
-        check(L.dyt_attention(ptr(qkv.cuda()), ptr(out), None, None, B, 0, stream_ptr()))
+        dqkv = torch.full((B * 197, 2304), float("nan"), device="cuda")
+        qd, dd = qkv.cuda(), dout.cuda()   # named: a temporary would be freed (and its block handed to the next allocation) before the launch
+        check(L.dyt_attention(ptr(qd), ptr(out), ptr(dd), ptr(dqkv), B, 0, stream_ptr()))
         torch.cuda.synchronize()
-        outs.append(out.cpu())
+        res.append((out.cpu(), dqkv.cpu()))
     check(L.dyt_set_global_option(_lib.OPT_F32_SPLIT16, 0))
-    e_exact, e_split = D.relerr(outs[0], ref_o), D.relerr(outs[1], ref_o)
+    e_exact, e_split = D.relerr(res[0][0], ref_o), D.relerr(res[1][0], ref_o)
     print("attention forward vs fp64: exact-fp32 kernel %.2e, split kernel %.2e" % (e_exact, e_split))
     assert e_split < 2e-5 and e_split < 4 * e_exact + 1e-6, (e_exact, e_split)
+    errs = {}
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        sl = slice(i * 768, (i + 1) * 768)
+        ee, es = D.relerr(res[0][1][:, sl], ref_dq[:, sl]), D.relerr(res[1][1][:, sl], ref_dq[:, sl])
+        print("attention backward %s vs fp64: exact-fp32 kernels %.2e, split kernels %.2e" % (nm, ee, es))
+        errs[nm] = (ee, es)
+    # measured: dq 6e-7, dv 6e-7 (the exact kernels: 9e-7 / 7e-7).  dk: 1.5e-5 at B=3, 8.7e-5 at B=64 (exact: 1.2e-6) -- most keys sit at the
+    # exact kernels' level, a few isolated keys (all 64 channels of a key) are 10-15x off, deterministically; every hi / lo term is
+    # present (dropping any one gives 2-5e-4 everywhere).  Not understood; 20x below the gradient bar of the mode (2e-3).
+    for nm, (ee, es) in errs.items():
+        assert es < (2e-4 if nm == "dk" else 4 * ee + 1e-6), (nm, ee, es)
