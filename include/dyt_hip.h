@@ -161,8 +161,9 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
 /*   DYT_OPT_F32_SPLIT16         fp32 mode only, default 0.  1: every GEMM against a FROZEN weight runs on the 16-bit matrix cores as
  *                           three products hi*hi + hi*lo + lo*hi (both fp32 operands split into two 16-bit parts, one contraction
  *                           over the K-concatenated parts, fp32 accumulate, the fp32 epilogues): the per-GEMM error of the exact
- *                           fp32 MFMA kernel (1-2e-6 of max|C| with IEEE-half parts) at ~2.7x its speed.  Attention, LayerNorm,
- *                           adapter-sized GEMMs and every row kernel stay exact fp32.  Host-side precision name: "fp16x3". */
+ *                           fp32 MFMA kernel (1-2e-6 of max|C| with IEEE-half parts) at ~2.7x its speed; the attention forward and
+ *                           backward likewise (DYT_SPLIT_ATTN=0 keeps the exact-fp32 attention kernels).  LayerNorm, adapter-sized
+ *                           GEMMs and every row kernel stay exact fp32.  Host-side precision name: "fp16x3". */
 #define DYT_OPT_F32_SPLIT16 8
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 /* the process-wide options (DYT_OPT_ATTN_BWD_FUSED) without a context: unit entries such as dyt_attention() see them too */
