@@ -916,8 +916,9 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __re
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = (bf16)x0[i]; lo[i] = (bf16)(x0[i] - (float)hi[i]);
-        hi[4 + i] = (bf16)x1[i]; lo[4 + i] = (bf16)(x1[i] - (float)hi[4 + i]);
+        const Split2 s0 = split2(x0[i]), s1 = split2(x1[i]);
+        hi[i] = s0.hi; lo[i] = s0.lo;
+        hi[4 + i] = s1.hi; lo[4 + i] = s1.lo;
     }
 }
 __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -1026,8 +1027,8 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
                 bf16x8 ph, pl;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float p = st[kt][half * 8 + i];
-                    ph[i] = (bf16)p; pl[i] = (bf16)(p - (float)ph[i]);
+                    const Split2 sp2 = split2(st[kt][half * 8 + i]);
+                    ph[i] = sp2.hi; pl[i] = sp2.lo;
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -1099,7 +1100,7 @@ __device__ __forceinline__ void stage_split_half(const float* __restrict__ src, 
 }
 __device__ __forceinline__ void split_pack8(const f32x16& v, int base, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { hi[i] = (bf16)v[base + i]; lo[i] = (bf16)(v[base + i] - (float)hi[i]); }
+    for (int i = 0; i < 8; ++i) { const Split2 s2 = split2(v[base + i]); hi[i] = s2.hi; lo[i] = s2.lo; }
 }
 // acc += A B with A = (ah, al), B = (bh, bl): small terms first
 #define MFMA3(acc, ah, al, bh, bl) do { acc = MFMA32(al, bh, acc); acc = MFMA32(ah, bl, acc); acc = MFMA32(ah, bh, acc); } while (0)

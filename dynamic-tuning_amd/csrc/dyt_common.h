@@ -77,9 +77,22 @@ __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float
 }
 // 4 consecutive fp32 values as 16-bit hi / hi / lo parts of the split operand layout [row][3K] (hi = rn16(x), lo = rn16(x - hi));
 // dst = &row[col], the three copies are K elements apart
+struct Split2 { bf16 hi, lo; };
+// The source value is pinned in ONE register first.  Without that the compiler folds the 16-bit conversion into the operation that
+// produced x in some uses (v_fma_mix*: a single rounding of the exact product) and not in others (v_cvt_pk_f16_f32 of the fp32 result:
+// two roundings), so the hi part that is stored / fed to the MFMA and the hi part lo is taken against can sit one 16-bit ulp apart
+// whenever the fp32 rounding crosses a 16-bit rounding boundary: x != hi + lo by a whole ulp of hi for about one value in 10^4.
+__device__ __forceinline__ Split2 split2(float x) {
+    asm("" : "+v"(x));
+    Split2 r;
+    r.hi = (bf16)x;
+    r.lo = (bf16)(x - (float)r.hi);
+    return r;
+}
 __device__ __forceinline__ void store4_split3(bf16* dst, int K, float a, float b, float c, float d) {
-    const bf16x4 hi = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
-    const bf16x4 lo = {(bf16)(a - (float)hi[0]), (bf16)(b - (float)hi[1]), (bf16)(c - (float)hi[2]), (bf16)(d - (float)hi[3])};
+    const Split2 sa = split2(a), sb = split2(b), sc = split2(c), sd = split2(d);
+    const bf16x4 hi = {sa.hi, sb.hi, sc.hi, sd.hi};
+    const bf16x4 lo = {sa.lo, sb.lo, sc.lo, sd.lo};
     *reinterpret_cast<bf16x4*>(dst) = hi;
     *reinterpret_cast<bf16x4*>(dst + K) = hi;
     *reinterpret_cast<bf16x4*>(dst + 2 * K) = lo;

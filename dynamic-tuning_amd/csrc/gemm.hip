@@ -999,8 +999,9 @@ __global__ __launch_bounds__(256) void split3_a_kernel(const float* __restrict__
     bf16x8 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = (bf16)x0[i]; lo[i] = (bf16)(x0[i] - (float)hi[i]);
-        hi[4 + i] = (bf16)x1[i]; lo[4 + i] = (bf16)(x1[i] - (float)hi[4 + i]);
+        const Split2 s0 = split2(x0[i]), s1 = split2(x1[i]);
+        hi[i] = s0.hi; lo[i] = s0.lo;
+        hi[4 + i] = s1.hi; lo[4 + i] = s1.lo;
     }
     bf16* dst = out + (size_t)row * 3 * K + c * 8;
     *reinterpret_cast<bf16x8*>(dst) = hi;
@@ -1013,7 +1014,8 @@ __global__ __launch_bounds__(256) void split3_w_kernel(const float* __restrict__
     if (idx >= (size_t)N * K) return;
     const size_t row = idx / K; const int k = (int)(idx - row * K);
     const float w = W[idx];
-    const bf16 hi = (bf16)w, lo = (bf16)(w - (float)hi);
+    const Split2 sw = split2(w);
+    const bf16 hi = sw.hi, lo = sw.lo;
     bf16* dst = out + row * 3 * K;
     dst[k] = hi; dst[K + k] = lo; dst[2 * K + k] = hi;
 }
