@@ -923,7 +923,7 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
 }
 __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, float* __restrict__ out,
-                                                             float* __restrict__ lse, int nheads) {
+                                                             float* __restrict__ lse, int nheads, bf16* __restrict__ out3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Kh = reinterpret_cast<bf16*>(smem);
     bf16* Kl = reinterpret_cast<bf16*>(smem + ROW_IMG);
@@ -1044,12 +1044,16 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
         if (qrow < NT) {
             const float inv = 1.0f / sum;
             float* op = out + ((size_t)b * NT + qrow) * D + h * HD;
+            bf16* op3 = out3 ? out3 + ((size_t)b * NT + qrow) * (3 * D) + h * HD : nullptr;   // + the split operand of the proj GEMM
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    store4(op + dt * 32 + 8 * g + 4 * hi, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
-                           o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * hi;
+                    const float o0 = o[dt][4 * g] * inv, o1 = o[dt][4 * g + 1] * inv, o2 = o[dt][4 * g + 2] * inv, o3 = o[dt][4 * g + 3] * inv;
+                    store4(op + d, o0, o1, o2, o3);
+                    if (op3) store4_split3(op3 + d, D, o0, o1, o2, o3);
+                }
         }
         __syncthreads();   // every wave is done with this head's images before they are overwritten
     }
@@ -1329,7 +1333,7 @@ static int g_attn_f32_split = 0;   // process-wide: the split forward kernel for
 void set_attn_f32_split(int on) { g_attn_f32_split = on; }
 
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
-                    hipStream_t s, int split16) {
+                    hipStream_t s, int split16, void* out3) {
     const int grid = batch * NH;
     if (dbg_skip(2)) return 0;
     if (precision == 0 && (split16 || g_attn_f32_split)) {
@@ -1339,8 +1343,9 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (!done[dev & 63]) { if (set_lds((const void*)attn_fwd_split_kernel, lds)) return -2; done[dev & 63] = true; }
         hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const float*)q, (const float*)k,
-                           (const float*)v, (float*)out, lse, grid);
+                           (const float*)v, (float*)out, lse, grid, (bf16*)out3);
     } else if (precision == 0) {
+        if (out3) { set_error("attention forward: split output without the split kernel"); return -1; }
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);
         bool* once = attr_flag(0);
         if (!*once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; *once = true; }

@@ -1033,7 +1033,7 @@ int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
                            a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
         GemmArgs b = a;
-        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_map = nullptr; b.Wp = a.W3p; b.W3 = nullptr; b.W3p = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = a.W3p; b.W3 = nullptr; b.W3p = nullptr; b.out_scale = 1.0f / a.a3_scale;
         return dispatch<float, true>(kind, b, s);
     }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;

@@ -45,6 +45,7 @@ struct GemmArgs {
                             // subnormals); the accumulators are multiplied by out_scale = 1 / a3_scale before the epilogue functor
     float out_scale = 1.f;
     bool a3_ready = false;   // a3 already holds the split A (written by the producing kernel): no pre-pass
+    bool a3_mapped = false;  // ... one split row per SOURCE row: the GEMM gathers through a_map (the pre-pass compacts instead)
     // FC1 / GELU_BWD in the split form: the result also (instead of out_at) goes out as the split A operand of the NEXT GEMM
     void* out3 = nullptr; float out3_scale = 1.f;
     const float* bias = nullptr;
@@ -84,7 +85,7 @@ int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int
 // ------------------------------------------------------------------------------------------
 // q,k,v: [B*12][197][64] AT ; out: [B*197][768] AT ; lse: [B*12][197] f32
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
-                    int batch, hipStream_t s, int split16 = 0);   // split16 (fp32 mode): products as three 16-bit MFMA products
+                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr);   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
 void set_attn_f32_split(int on);   // process-wide version of split16 (unit entries)
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
@@ -104,7 +105,7 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx_out, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  float gs, hipStream_t s);   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
+                  float gs, hipStream_t s, void* out3 = nullptr, float s3 = 1.0f);   // out3: + dx * s3 as a [rows][3*768] split operand (fp32 mode)   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
 
 struct GateArgs {
     const float* u;          // [B*197,768] residual stream after attention
@@ -232,6 +233,8 @@ struct TokBwdArgs {
     const void* cat_ddz = nullptr;    // [M, 64] AT
     const float* cat_bup = nullptr;   // unused (kept for ABI stability of the struct)
     float cat_scale = 0.f, cat_ddz_scale = 0.f;   // s ; 1 / (inv_keep * gs)
+    void* du3 = nullptr;           // fp32 split form: + du * du3_scale as the [M][3*768] 16-bit hi / hi / lo operand of the proj dgrad
+    float du3_scale = 1.0f;
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
 // out[i] += alpha * sum_p partial[p*stride + i], i < n

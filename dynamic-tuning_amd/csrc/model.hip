@@ -115,6 +115,7 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
     void* dact_s = nullptr;   // 16-bit modes: adapter_scale * d_act, the A2 operand of the fc2 + up-projection contraction
     void* a3 = nullptr;   // fp32 mode: [M, 3 * 3072] 16-bit scratch for the split A operand of a GEMM
+    void* g3 = nullptr;   // [M, 3*768]: the gradient stream as a split operand, written by ln_bwd (next block's GELU' dgrad) and tok_bwd (proj dgrad); attention output in the forward pass
     void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
 };
@@ -161,6 +162,7 @@ struct dyt_ctx {
     void *ad_down_w, *ad_down_wT, *ad_up_w, *ad_up_wT;
     float* ad_down_b;
     bool split_attn = true;     // ... and the attention forward too (attn_fwd_split_kernel; DYT_SPLIT_ATTN=0: exact fp32 MFMA kernel)
+    bool split_prod = true;     // ... attention forward / ln_bwd / tok_bwd write the split operand of the GEMM that follows (DYT_SPLIT_PROD=0: pre-passes)
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
     void* pe_w3 = nullptr;
@@ -315,6 +317,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.dact_s = c->prec != DYT_PREC_FP32 ? carve_at(c, M * RP, dry) : nullptr;
         T.a3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
         T.xn3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
+        T.g3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
         T.h3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
         T.dqkv3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 9 * D, dry) : nullptr;
         T.dO = carve_at(c, M * D, dry);
@@ -643,6 +646,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             c->split16 = value != 0;
             if (const char* e = getenv("DYT_SPLIT_GS_LOG2")) c->split_gs = (float)(1u << atoi(e));   // measurement knob
             if (const char* e = getenv("DYT_SPLIT_ATTN")) c->split_attn = atoi(e) != 0;
+            if (const char* e = getenv("DYT_SPLIT_PROD")) c->split_prod = atoi(e) != 0;
             for (auto& S : c->slots) S.valid = false;
             if (c->split16) {   // parts of the weights uploaded so far (later dyt_set_frozen calls refresh theirs)
                 DYT_HIP_CHECK(hipDeviceSynchronize());   // uploads may be in flight on the caller's streams
@@ -900,7 +904,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3); SPLIT_P(a, W.qkv_w3p); SPLIT_READY(a, T.xn3);
                 RUN_GEMM(EPI_QKV, a);
             }
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s, c->split16 && c->split_attn));
+            void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? T.g3 : nullptr;   // the split attention kernel also writes the proj GEMM's operand
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3));
             if (c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
@@ -910,6 +915,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             } else {
                 GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
                 a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at; SPLIT(a, W.proj_w3);
+                if (ao3) SPLIT_READY(a, ao3);
                 RUN_GEMM(EPI_BIAS_RESID, a);
             }
             if (l == 0 && ev_b0_record) DYT_HIP_CHECK(hipEventRecord(ev_b0_record, s));
@@ -1200,6 +1206,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
 
     ReduceQueue rq;   // adapter weight-gradient / gate-gradient reductions: queued per block, flushed where the gradients must be final
     bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
+    bool g3_ready = false; // ... and (fp32 split form) T.g3 = g as the 16-bit split operand of this block's GELU' dgrad
+    const bool split_prod = c->split16 && c->split_prod;
     for (int l = depth - 1; l >= 0; --l) {
         const LayerW& W = c->W[l];
         LayerS& L = S.L[l];
@@ -1253,6 +1261,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
                 a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3); SPLIT_P(a, W.fc2_wT3p);
+                if (g3_ready && !tail) { SPLIT_READY(a, T.g3); a.a3_mapped = true; }   // ln_bwd of the block above wrote g as the split operand
                 if (c->split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; }   // dZ as the split operand of the fc1 dgrad
                 if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
@@ -1293,6 +1302,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
             a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = S.tok_part[l]; a.M = M; a.write_du = !first;
+            if (split_prod && !first) { a.du3 = T.g3; a.du3_scale = c->split_gs; }
             int nblk = 0;
             if (a.du_at) POISON(8, T.du_at, (size_t)M * D * c->at);
             ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s)););
@@ -1315,7 +1325,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
             GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.Wp = W.proj_wTp; a.M = M; a.N = D; a.K = D;
-            a.out_at = T.dO; SPLIT_G(a, W.proj_wT3);
+            a.out_at = T.dO; SPLIT_G(a, W.proj_wT3); if (split_prod) SPLIT_READY(a, T.g3);
             POISON(16, T.dO, (size_t)M * D * c->at);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
             CK("proj_dgrad dO", T.dO, (size_t)M * D * c->at);
@@ -1335,7 +1345,9 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             const LayerS& Ln = S.L[l - 1];
             if (g_at) POISON(256, g_at, (size_t)M * D * c->at);
             ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
-                                    (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, gs, s)););
+                                    (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, gs, s,
+                                    (split_prod && l > 1) ? T.g3 : nullptr, c->split_gs)););
+            g3_ready = split_prod && l > 1;
             CK("ln_bwd g", g, (size_t)M * D * 4);
             if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * c->at);
             if (student) CK("ln_bwd dmask", T.dmask, (size_t)M * 4);

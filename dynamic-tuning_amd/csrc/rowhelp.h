@@ -33,6 +33,12 @@ struct Row12 {
             v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
         }
     }
+    // the row times `scale` as the 16-bit hi / hi / lo split operand of a GEMM (row base p3 of a [rows][3 * 768] image)
+    __device__ __forceinline__ void store_split3(bf16* p3, int lane, float scale) const {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            store4_split3(p3 + i * 256 + lane * 4, 768, v[4 * i] * scale, v[4 * i + 1] * scale, v[4 * i + 2] * scale, v[4 * i + 3] * scale);
+    }
     template <class T>
     __device__ __forceinline__ void store(T* p, int lane) const {
 #pragma unroll
