@@ -801,7 +801,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_f32_kernel(const float* __res
         }
     }
     if (qrow < NT && dqkv3) {
-        bf16* op3 = dqkv3 + ((size_t)b * NT + qrow) * (9 * D) + h * HD;
+        bf16* op3 = dqkv3 + ((size_t)b * NT + qrow) * (SPLIT_A * 3 * D) + h * HD;
         const float sc = 0.125f * s3;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __re
         }
     }
     if (key < NT && dqkv3) {
-        bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (9 * D) + h * HD;
+        bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (SPLIT_A * 3 * D) + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
         if (qrow < NT) {
             const float inv = 1.0f / sum;
             float* op = out + ((size_t)b * NT + qrow) * D + h * HD;
-            bf16* op3 = out3 ? out3 + ((size_t)b * NT + qrow) * (3 * D) + h * HD : nullptr;   // + the split operand of the proj GEMM
+            bf16* op3 = out3 ? out3 + ((size_t)b * NT + qrow) * (SPLIT_A * D) + h * HD : nullptr;   // + the split operand of the proj GEMM
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d = dt * 32 + 8 * g + 4 * hi;
-                    if (dqkv3) store4_split3(dqkv3 + ((size_t)b * NT + qrow) * (9 * D) + h * HD + d, 3 * D, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
+                    if (dqkv3) store4_split3(dqkv3 + ((size_t)b * NT + qrow) * (SPLIT_A * 3 * D) + h * HD + d, 3 * D, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
                                              dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc);
                     else store4(dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD + d, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
                                 dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc);
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __
                 for (int g = 0; g < 4; ++g) {
                     const int d = dt * 32 + 8 * g + 4 * hi;
                     if (dqkv3) {
-                        bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (9 * D) + h * HD + d;
+                        bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (SPLIT_A * 3 * D) + h * HD + d;
                         store4_split3(op3 + D, 3 * D, aK[dt][4 * g] * sc, aK[dt][4 * g + 1] * sc, aK[dt][4 * g + 2] * sc, aK[dt][4 * g + 3] * sc);
                         store4_split3(op3 + 2 * D, 3 * D, aV[dt][4 * g] * sc, aV[dt][4 * g + 1] * sc, aV[dt][4 * g + 2] * sc, aV[dt][4 * g + 3] * sc);
                     } else {

@@ -75,8 +75,6 @@ __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float
     bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
     *reinterpret_cast<bf16x4*>(p) = v;
 }
-// 4 consecutive fp32 values as 16-bit hi / hi / lo parts of the split operand layout [row][3K] (hi = rn16(x), lo = rn16(x - hi));
-// dst = &row[col], the three copies are K elements apart
 struct Split2 { bf16 hi, lo; };
 // The source value is pinned in ONE register first.  Without that the compiler folds the 16-bit conversion into the operation that
 // produced x in some uses (v_fma_mix*: a single rounding of the exact product) and not in others (v_cvt_pk_f16_f32 of the fp32 result:
@@ -89,13 +87,17 @@ __device__ __forceinline__ Split2 split2(float x) {
     r.lo = (bf16)(x - (float)r.hi);
     return r;
 }
+// The split A operand of a GEMM in memory: [row][hi (K) | lo (K)].  The contraction runs over 3K -- [A_hi | A_hi | A_lo] against the
+// weight image [W_hi | W_lo | W_hi] -- and the kernel reads the hi part for the first TWO thirds (GemmArgs / CatArgs::a_fold), so the
+// producers write, and HBM holds, two 16-bit copies per value instead of three.
+constexpr int SPLIT_A = 2;
+// 4 consecutive fp32 values as the hi / lo parts of that layout; dst = &row[col], the lo part K elements further
 __device__ __forceinline__ void store4_split3(bf16* dst, int K, float a, float b, float c, float d) {
     const Split2 sa = split2(a), sb = split2(b), sc = split2(c), sd = split2(d);
     const bf16x4 hi = {sa.hi, sb.hi, sc.hi, sd.hi};
     const bf16x4 lo = {sa.lo, sb.lo, sc.lo, sd.lo};
     *reinterpret_cast<bf16x4*>(dst) = hi;
-    *reinterpret_cast<bf16x4*>(dst + K) = hi;
-    *reinterpret_cast<bf16x4*>(dst + 2 * K) = lo;
+    *reinterpret_cast<bf16x4*>(dst + K) = lo;
 }
 __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
     float4 v = *reinterpret_cast<const float4*>(p);

@@ -138,7 +138,7 @@ struct EpiFc1 {
             for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + c.b[i]);
         }
         if constexpr (sizeof(AT) == 4) {
-            if (h3) { store4_split3(h3 + (size_t)row * 3 * ld + col, ld, hv[0], hv[1], hv[2], hv[3]); return; }
+            if (h3) { store4_split3(h3 + (size_t)row * SPLIT_A * ld + col, ld, hv[0], hv[1], hv[2], hv[3]); return; }
         }
         store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
@@ -226,7 +226,7 @@ struct EpiGeluBwd {
         float g[4];
         p.get(g);
         if constexpr (sizeof(AT) == 4) {
-            if (out3) { store4_split3(out3 + (size_t)row * 3 * ld + col, ld, a[0] * g[0] * s3, a[1] * g[1] * s3, a[2] * g[2] * s3, a[3] * g[3] * s3); return; }
+            if (out3) { store4_split3(out3 + (size_t)row * SPLIT_A * ld + col, ld, a[0] * g[0] * s3, a[1] * g[1] * s3, a[2] * g[2] * s3, a[3] * g[3] * s3); return; }
         }
         store4(out + (size_t)row * ld + col, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
     }
@@ -386,7 +386,7 @@ __device__ unsigned long long g_gemm_dbg[4];
 // gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
-struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; };   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; };   // a_fold: k-tiles of ONE part of a split A operand stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads column tile kt - (kt >= a_fold ? a_fold : 0); 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
 // One workgroup = one tile: `bid` of `nwg` logical workgroups that tile rows [m_begin, M).  A device function so that one launch
 // can hold workgroups of two tile shapes (gemm_bf16_rows_kernel below).
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT>
@@ -421,12 +421,13 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     const int lrow = lane >> 3, slot = lane & 7, chunk = slot ^ lrow;
     const bf16* a_src[A_INSTR];
     const bf16* b_src[B_INSTR];
+    const int fold = cat.a_fold, lda = K - fold * BK;   // split A operand stored [hi | lo]: the hi part serves the first two thirds of the contraction
 #pragma unroll
     for (int t = 0; t < A_INSTR; ++t) {
         const int row = (t * NW + wave) * 8 + lrow;
         int grow = min(m0 + row, Mv - 1);
         if (a_map) grow = a_map[grow];  // gathered A rows (compacted MLP backward)
-        a_src[t] = A + (size_t)grow * K + chunk * 8 - (CAT ? BK : 0);
+        a_src[t] = A + (size_t)grow * lda + chunk * 8 - (CAT ? BK : 0);
     }
 #pragma unroll
     for (int t = 0; t < B_INSTR; ++t) {
@@ -438,7 +439,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     auto stage_one = [&](int buf, int kt, int idx) {
         char* base = smem + buf * STAGE;
         if (idx < A_INSTR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[idx] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[idx] + (kt - (kt >= fold ? fold : 0)) * BK),
                                              (__attribute__((address_space(3))) void*)(base + (idx * NW + wave) * 1024),
                                              16, 0, 0);
         else
@@ -450,7 +451,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int t = 0; t < A_INSTR; ++t)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[t] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[t] + (kt - (kt >= fold ? fold : 0)) * BK),
                                              (__attribute__((address_space(3))) void*)(base + (t * NW + wave) * 1024),
                                              16, 0, 0);
 #pragma unroll
@@ -744,7 +745,7 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
                                           (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, cat);
     ++g_bf16_kernel_launches;
@@ -764,7 +765,7 @@ static int launch_bf16_rows(const GemmArgs& a, const Epi& epi, hipStream_t s, in
         DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold};
     hipLaunchKernelGGL(kern, dim3(n_big + n_small), dim3(512), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W), a.M, a.N,
                        a.K, a.m_dev, a.a_map, body, n_big, epi, cat);
     ++g_bf16_kernel_launches;
@@ -1003,10 +1004,9 @@ __global__ __launch_bounds__(256) void split3_a_kernel(const float* __restrict__
         hi[i] = s0.hi; lo[i] = s0.lo;
         hi[4 + i] = s1.hi; lo[4 + i] = s1.lo;
     }
-    bf16* dst = out + (size_t)row * 3 * K + c * 8;
+    bf16* dst = out + (size_t)row * SPLIT_A * K + c * 8;
     *reinterpret_cast<bf16x8*>(dst) = hi;
-    *reinterpret_cast<bf16x8*>(dst + K) = hi;
-    *reinterpret_cast<bf16x8*>(dst + 2 * K) = lo;
+    *reinterpret_cast<bf16x8*>(dst + K) = lo;
 }
 // W [N,K] fp32 -> [N, 3K] = [hi | lo | hi]
 __global__ __launch_bounds__(256) void split3_w_kernel(const float* __restrict__ W, bf16* __restrict__ out, int N, int K) {
@@ -1027,13 +1027,13 @@ int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s) {
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
     if (precision == 0 && a.W3 && a.a3) {
-        if (a.K % 8 != 0 || a.A2) { set_error("gemm split form: K=%d %% 8", a.K); return -1; }
+        if (a.K % 64 != 0 || a.A2) { set_error("gemm split form: K=%d %% 64", a.K); return -1; }
         const size_t tasks = (size_t)a.M * (a.K / 8);
         if (!a.a3_ready)
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
                            a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
         GemmArgs b = a;
-        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = a.W3p; b.W3 = nullptr; b.W3p = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_fold = a.K / 64; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = nullptr; b.W3 = nullptr; b.W3p = nullptr; b.out_scale = 1.0f / a.a3_scale;
         return dispatch<float, true>(kind, b, s);
     }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;

@@ -44,6 +44,7 @@ struct GemmArgs {
     float a3_scale = 1.f;   // power of two the fp32 A is multiplied by before it is split (gradients: keeps the lo part out of the fp16
                             // subnormals); the accumulators are multiplied by out_scale = 1 / a3_scale before the epilogue functor
     float out_scale = 1.f;
+    int a_fold = 0;          // (internal) k-tiles per part of a split A operand stored [hi | lo]: set by launch_gemm
     bool a3_ready = false;   // a3 already holds the split A (written by the producing kernel): no pre-pass
     bool a3_mapped = false;  // ... one split row per SOURCE row: the GEMM gathers through a_map (the pre-pass compacts instead)
     // FC1 / GELU_BWD in the split form: the result also (instead of out_at) goes out as the split A operand of the NEXT GEMM

@@ -33,7 +33,7 @@ struct Row12 {
             v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
         }
     }
-    // the row times `scale` as the 16-bit hi / hi / lo split operand of a GEMM (row base p3 of a [rows][3 * 768] image)
+    // the row times `scale` as the 16-bit hi / lo split operand of a GEMM (row base p3 of a [rows][SPLIT_A * 768] image)
     __device__ __forceinline__ void store_split3(bf16* p3, int lane, float scale) const {
 #pragma unroll
         for (int i = 0; i < 3; ++i)

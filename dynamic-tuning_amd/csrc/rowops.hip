@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (out3) {   // fp32 split form: the row as the 16-bit hi / hi / lo operand of the next GEMM
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            store4_split3(out3 + (size_t)row * 3 * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
+            store4_split3(out3 + (size_t)row * SPLIT_A * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
     } else {
         xr.store(out + (size_t)row * D, lane);
     }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
     g.store(dx + (size_t)row * D, lane);
-    if (out3) g.store_split3(out3 + (size_t)row * 3 * D, lane, s3);   // fp32 split form: the next block's GELU' dgrad operand
+    if (out3) g.store_split3(out3 + (size_t)row * SPLIT_A * D, lane, s3);   // fp32 split form: the next block's GELU' dgrad operand
     if (g_at) {
         Row12 gsc;
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
     if (out3) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            store4_split3(out3 + (size_t)dst * 3 * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
+            store4_split3(out3 + (size_t)dst * SPLIT_A * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
     } else {
         xr.store(out + (size_t)dst * D, lane);
     }
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         }
         if (a.write_du) {
             du.store(a.du + (size_t)t * D, lane);
-            if (a.du3) du.store_split3(reinterpret_cast<bf16*>(a.du3) + (size_t)t * 3 * D, lane, a.du3_scale);   // proj dgrad operand (fp32 split form)
+            if (a.du3) du.store_split3(reinterpret_cast<bf16*>(a.du3) + (size_t)t * SPLIT_A * D, lane, a.du3_scale);   // proj dgrad operand (fp32 split form)
             if (a.du_at) {
                 Row12 dsc;
 #pragma unroll
