@@ -1,5 +1,4 @@
-python -m pytest tests/test_gpu_round3.py tests/test_gpu_parity.py -x -q -s 2>&1 | grep -E "worst|fp16x3.*logits|passed|failed|Error|assert" | head -12
-python bench.py --precision fp16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode 2>&1 | tail -1 | cut -c150-260
-DYT_LIB_DIR=tools/probes/_ab python -c "print(1)"
-python bench.py --precision fp16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode 2>&1 | tail -1 | cut -c150-260
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode 2>&1 | tail -1 | cut -c150-260
+python bench.py > gpurun_out/r3_final_bench.log 2>&1; grep '^{' gpurun_out/r3_final_bench.log > gpurun_out/r3_final_bench.json
+python bench.py --precision fp16x3 --steps 8 --warmup 2 --no-cpu-baseline --no-parity-mode 2>&1 | grep '^{' > gpurun_out/r3_final_fp16x3_bench.json
+tools/rocprof_bench.sh r3_final_fp16x3_serial DYT_NO_OVERLAP=1 -- --precision fp16x3 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
+cut -c1-300 gpurun_out/r3_final_bench.json; cut -c1-300 gpurun_out/r3_final_fp16x3_bench.json
