@@ -386,7 +386,7 @@ __device__ unsigned long long g_gemm_dbg[4];
 // gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
-struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; };   // a_fold: k-tiles of ONE part of a split A operand stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads column tile kt - (kt >= a_fold ? a_fold : 0); 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; };   // a_fold: k-tiles of ONE part of split operands stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads A column tile kt - (kt >= a_fold ? a_fold : 0) and W column tile kt - (kt >= 2 a_fold ? 2 a_fold : 0), i.e. [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]; 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
 // One workgroup = one tile: `bid` of `nwg` logical workgroups that tile rows [m_begin, M).  A device function so that one launch
 // can hold workgroups of two tile shapes (gemm_bf16_rows_kernel below).
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT>
@@ -432,7 +432,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
 #pragma unroll
     for (int t = 0; t < B_INSTR; ++t) {
         const int row = (t * NW + wave) * 8 + lrow;
-        b_src[t] = W + (size_t)(n0 + row) * K + chunk * 8 - (CAT ? BK : 0);
+        b_src[t] = W + (size_t)(n0 + row) * lda + chunk * 8 - (CAT ? BK : 0);   // split form: W stored [hi | lo] like A (same row stride)
     }
     // one 1-KiB DMA piece (idx < A_INSTR: A rows, else W rows) -- issued interleaved with the MFMAs so the
     // in-order wave never sits behind a burst of LDS-DMA issues (each costs ~100+ cycles back-to-back)
@@ -444,7 +444,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
                                              16, 0, 0);
         else
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(b_src[idx - A_INSTR] + kt * BK),
+                (const __attribute__((address_space(1))) void*)(b_src[idx - A_INSTR] + (kt - (kt >= 2 * fold ? 2 * fold : 0)) * BK),
                 (__attribute__((address_space(3))) void*)(base + A_BYTES + ((idx - A_INSTR) * NW + wave) * 1024), 16, 0, 0);
     };
     auto stage = [&](int buf, int kt) {
@@ -456,7 +456,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
                                              16, 0, 0);
 #pragma unroll
         for (int t = 0; t < B_INSTR; ++t)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[t] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[t] + (kt - (kt >= 2 * fold ? 2 * fold : 0)) * BK),
                                              (__attribute__((address_space(3))) void*)(base + A_BYTES + (t * NW + wave) * 1024),
                                              16, 0, 0);
     };
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void split3_a_kernel(const float* __restrict__
     *reinterpret_cast<bf16x8*>(dst) = hi;
     *reinterpret_cast<bf16x8*>(dst + K) = lo;
 }
-// W [N,K] fp32 -> [N, 3K] = [hi | lo | hi]
+// W [N,K] fp32 -> [N, 2K] = [hi | lo]; the contraction reads it as [hi | lo | hi] (the B loader folds the last third onto the first)
 __global__ __launch_bounds__(256) void split3_w_kernel(const float* __restrict__ W, bf16* __restrict__ out, int N, int K) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)N * K) return;
@@ -1016,8 +1016,8 @@ __global__ __launch_bounds__(256) void split3_w_kernel(const float* __restrict__
     const float w = W[idx];
     const Split2 sw = split2(w);
     const bf16 hi = sw.hi, lo = sw.lo;
-    bf16* dst = out + row * 3 * K;
-    dst[k] = hi; dst[K + k] = lo; dst[2 * K + k] = hi;
+    bf16* dst = out + row * SPLIT_A * K;
+    dst[k] = hi; dst[K + k] = lo;
 }
 int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s) {
     hipLaunchKernelGGL(split3_w_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, W, static_cast<bf16*>(W3), N, K);
@@ -1033,7 +1033,7 @@ int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
                            a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
         GemmArgs b = a;
-        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_fold = a.K / 64; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = nullptr; b.W3 = nullptr; b.W3p = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_fold = a.K / 64; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = nullptr; b.W3 = nullptr; b.out_scale = 1.0f / a.a3_scale;
         return dispatch<float, true>(kind, b, s);
     }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;

@@ -40,7 +40,6 @@ struct GemmArgs {
     // on the fly into a3 [M, 3K] = [hi | hi | lo] and the GEMM runs as ONE 16-bit MFMA contraction over 3K (hi*hi + hi*lo + lo*hi)
     // with the fp32 epilogue: the accuracy of the exact-fp32 MFMA kernel at ~2.7x its speed (tools/probes/split_precision_probe.py)
     const void* W3 = nullptr; void* a3 = nullptr;
-    const void* W3p = nullptr;   // W3 pre-shuffled into MFMA fragment order (wide-N GEMMs: the pre-shuffled-weight kernel)
     float a3_scale = 1.f;   // power of two the fp32 A is multiplied by before it is split (gradients: keeps the lo part out of the fp16
                             // subnormals); the accumulators are multiplied by out_scale = 1 / a3_scale before the epilogue functor
     float out_scale = 1.f;

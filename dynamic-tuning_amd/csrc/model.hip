@@ -99,9 +99,8 @@ struct LayerW {  // frozen, library-owned
     void *qkv_w, *qkv_wT, *proj_w, *proj_wT, *fc1_w, *fc1_wT, *fc2_w, *fc2_wT;
     void *qkv_wp = nullptr, *fc1_wp = nullptr, *fc2_wTp = nullptr;   // bf16 mode: MFMA-fragment-order twins (gemm_bpre.h)
     void *proj_wp = nullptr, *proj_wTp = nullptr, *qkv_wTp = nullptr, *fc1_wTp = nullptr;
-    // fp32 mode: [N, 3K] 16-bit hi / lo / hi parts of the eight matrices (DYT_OPT_F32_SPLIT16, launch_split3_w)
+    // fp32 mode: [N, 2K] 16-bit [hi | lo] images of the eight matrices (DYT_OPT_F32_SPLIT16, launch_split3_w)
     void *qkv_w3 = nullptr, *qkv_wT3 = nullptr, *proj_w3 = nullptr, *proj_wT3 = nullptr, *fc1_w3 = nullptr, *fc1_wT3 = nullptr, *fc2_w3 = nullptr, *fc2_wT3 = nullptr;
-    void *qkv_w3p = nullptr, *fc1_w3p = nullptr, *fc2_wT3p = nullptr;   // the wide-N ones also in MFMA fragment order
 };
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
@@ -248,8 +247,6 @@ static void layout(dyt_ctx* c, bool dry) {
             w.proj_w3 = carve<uint16_t>(c, (size_t)3 * D * D, dry); w.proj_wT3 = carve<uint16_t>(c, (size_t)3 * D * D, dry);
             w.fc1_w3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry); w.fc1_wT3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
             w.fc2_w3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry); w.fc2_wT3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
-            w.qkv_w3p = carve<uint16_t>(c, (size_t)3 * 3 * D * D, dry); w.fc1_w3p = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
-            w.fc2_wT3p = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
         }
     }
     c->ad_down_w = carve_at(c, depth * RP * D, dry);
@@ -513,7 +510,7 @@ static int set_matrix(dyt_ctx* c, const float* src, void* w, void* wT, int N, in
     if (wT) rc = launch_transpose_convert(c->prec, src, wT, N, K, K, N, s);
     return rc;
 }
-// fp32 mode: refresh the 16-bit hi / lo / hi parts of one layer's (layer < 0: the patch embedding's) frozen matrices
+// fp32 mode: refresh the 16-bit [hi | lo] images of one layer's (layer < 0: the patch embedding's) frozen matrices
 static int refresh_split(dyt_ctx* c, int layer, hipStream_t s) {
     if (c->prec != 0) return 0;
     if (layer < 0) return launch_split3_w((const float*)c->pe_w, c->pe_w3, D, D, s);
@@ -526,9 +523,6 @@ static int refresh_split(dyt_ctx* c, int layer, hipStream_t s) {
     if (!rc) rc = launch_split3_w((const float*)w.fc1_wT, w.fc1_wT3, D, DM, s);
     if (!rc) rc = launch_split3_w((const float*)w.fc2_w, w.fc2_w3, D, DM, s);
     if (!rc) rc = launch_split3_w((const float*)w.fc2_wT, w.fc2_wT3, DM, D, s);
-    if (!rc) rc = launch_preshuffle_w(w.qkv_w3, w.qkv_w3p, 3 * D, 3 * D, s);
-    if (!rc) rc = launch_preshuffle_w(w.fc1_w3, w.fc1_w3p, DM, 3 * D, s);
-    if (!rc) rc = launch_preshuffle_w(w.fc2_wT3, w.fc2_wT3p, DM, 3 * D, s);
     return rc;
 }
 static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
@@ -751,7 +745,6 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
 
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 #define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
-#define SPLIT_P(a, w3p) do { static const bool _on = getenv("DYT_SPLIT_BPRE") && atoi(getenv("DYT_SPLIT_BPRE"));   /* measured slower (80.5 vs 79.2 ms/step): off unless asked for */ if (c->split16 && _on) (a).W3p = (w3p); } while (0)
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
@@ -901,7 +894,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr));
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
-                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3); SPLIT_P(a, W.qkv_w3p); SPLIT_READY(a, T.xn3);
+                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3); SPLIT_READY(a, T.xn3);
                 RUN_GEMM(EPI_QKV, a);
             }
             void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? T.g3 : nullptr;   // the split attention kernel also writes the proj GEMM's operand
@@ -981,7 +974,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const int* kdev = (dense || tail) ? nullptr : L.total;
         {
             GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
-            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT(a, W.fc1_w3); SPLIT_P(a, W.fc1_w3p);
+            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT(a, W.fc1_w3);
             if (!tail) SPLIT_READY(a, T.xn3);   // (the cls tail's LN2 rows come from ln_cls in fp32: pre-pass)
             if (c->split16) a.out3 = T.h3;
             RUN_GEMM(EPI_FC1, a);
@@ -1260,7 +1253,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             {
                 GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
-                a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3); SPLIT_P(a, W.fc2_wT3p);
+                a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3);
                 if (g3_ready && !tail) { SPLIT_READY(a, T.g3); a.a3_mapped = true; }   // ln_bwd of the block above wrote g as the split operand
                 if (c->split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; }   // dZ as the split operand of the fc1 dgrad
                 if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);

@@ -1,4 +1,5 @@
-python bench.py > gpurun_out/r3_final_bench.log 2>&1; grep '^{' gpurun_out/r3_final_bench.log > gpurun_out/r3_final_bench.json
-python bench.py --precision fp16x3 --steps 8 --warmup 2 --no-cpu-baseline --no-parity-mode 2>&1 | grep '^{' > gpurun_out/r3_final_fp16x3_bench.json
-tools/rocprof_bench.sh r3_final_fp16x3_serial DYT_NO_OVERLAP=1 -- --precision fp16x3 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
-cut -c1-300 gpurun_out/r3_final_bench.json; cut -c1-300 gpurun_out/r3_final_fp16x3_bench.json
+python -m pytest tests/test_gpu_round3.py -x -q -s -k fp16x3 2>&1 | grep -E "worst|fp16x3.*logits|passed|failed|Error|assert" | head -12
+for i in 1 2; do
+PPREC=fp16x3 python tools/probes/ab_step.py 2>&1 | tail -1
+PPREC=fp16x3 DYT_LIB_PATH=tools/probes/_ab/prev_fold.so python tools/probes/ab_step.py 2>&1 | tail -1
+done
