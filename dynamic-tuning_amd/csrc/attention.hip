@@ -1108,7 +1108,11 @@ __device__ __forceinline__ void split_pack8(const f32x16& v, int base, bf16x8& h
 }
 // acc += A B with A = (ah, al), B = (bh, bl): small terms first
 #define MFMA3(acc, ah, al, bh, bl) do { acc = MFMA32(al, bh, acc); acc = MFMA32(ah, bl, acc); acc = MFMA32(ah, bh, acc); } while (0)
+// the gradient products (dP, dQ, dK, dV) of the backward kernels: GP = 3 as above, GP = 1 the hi * hi product alone (the score
+// recomputation always takes three: an error of S is an error of the exponent)
+#define MFMAG(acc, ah, al, bh, bl) do { if constexpr (GP == 3) MFMA3(acc, ah, al, bh, bl); else acc = MFMA32(ah, bh, acc); } while (0)
 
+template <int GP>
 __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                 const float* __restrict__ v, const float* __restrict__ o,
                                                                 const float* __restrict__ dout, const float* __restrict__ lse,
@@ -1167,7 +1171,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
                     const bf16x8 kah = *reinterpret_cast<const bf16x8*>(Kh + off), kal = *reinterpret_cast<const bf16x8*>(Kl + off);
                     const bf16x8 vah = *reinterpret_cast<const bf16x8*>(Vh + off), val = *reinterpret_cast<const bf16x8*>(Vl + off);
                     MFMA3(s_, kah, kal, qh[ks], ql[ks]);
-                    MFMA3(dp_, vah, val, doh[ks], dol[ks]);
+                    MFMAG(dp_, vah, val, doh[ks], dol[ks]);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
                     for (int dt = 0; dt < 2; ++dt) {
                         const int toff = (dt * 32 + l31) * TLDH + t * 32 + half * 16 + 4 * hi;
                         const bf16x8 kth = join44(Kth + toff), ktl = join44(Ktl + toff);
-                        MFMA3(dq[dt], kth, ktl, dsh, dsl);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+                        MFMAG(dq[dt], kth, ktl, dsh, dsl);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
                     }
                 }
             }
@@ -1204,6 +1208,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
     }
 }
 
+template <int GP>
 __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                  const float* __restrict__ v, const float* __restrict__ dout,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __
                     const bf16x8 qah = *reinterpret_cast<const bf16x8*>(Qh + off), qal = *reinterpret_cast<const bf16x8*>(Ql + off);
                     const bf16x8 dah = *reinterpret_cast<const bf16x8*>(Dh + off), dal = *reinterpret_cast<const bf16x8*>(Dl + off);
                     MFMA3(s, qah, qal, kh[ks], kl[ks]);      // S[q][key]
-                    MFMA3(dp, dah, dal, vh[ks], vl[ks]);     // dP[q][key]
+                    MFMAG(dp, dah, dal, vh[ks], vl[ks]);     // dP[q][key]
                 }
                 f32x16 p;
 #pragma unroll
@@ -1289,8 +1294,8 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __
                         const int toff = (dt * 32 + l31) * TLDH + t * 32 + half * 16 + 4 * hi;
                         const bf16x8 doth = join44(Dth + toff), dotl = join44(Dtl + toff);
                         const bf16x8 qth = join44(Qth + toff), qtl = join44(Qtl + toff);
-                        MFMA3(aV[dt], doth, dotl, ph, pl);    // dV^T[d][key] += dO^T[d][q] P[q][key]
-                        MFMA3(aK[dt], qth, qtl, dsh, dsl);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                        MFMAG(aV[dt], doth, dotl, ph, pl);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+                        MFMAG(aK[dt], qth, qtl, dsh, dsl);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
                     }
                 }
             }
@@ -1364,7 +1369,7 @@ static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV 
 void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
 
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
-                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16) {
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16, int grad_parts) {
     const int grid = batch * NH;
     if (dbg_skip(1)) return 0;
     if (precision == 0 && (split16 || g_attn_f32_split)) {
@@ -1373,14 +1378,16 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (!done[dev & 63]) {
-            if (set_lds((const void*)attn_bwd_dq_split_kernel, lds1)) return -2;
-            if (set_lds((const void*)attn_bwd_dkv_split_kernel, lds2)) return -2;
+            if (set_lds((const void*)attn_bwd_dq_split_kernel<3>, lds1) || set_lds((const void*)attn_bwd_dq_split_kernel<1>, lds1)) return -2;
+            if (set_lds((const void*)attn_bwd_dkv_split_kernel<3>, lds2) || set_lds((const void*)attn_bwd_dkv_split_kernel<1>, lds2)) return -2;
             done[dev & 63] = true;
         }
         static const float gs_unit = getenv("DYT_SPLIT_ATTN_GS") ? (float)atof(getenv("DYT_SPLIT_ATTN_GS")) : 4096.0f;   // unit entries (no context)
-        hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(min(grid, 256)), dim3(448), lds1, s, (const float*)q, (const float*)k, (const float*)v,
+        auto* kq = grad_parts >= 3 ? attn_bwd_dq_split_kernel<3> : attn_bwd_dq_split_kernel<1>;
+        auto* kkv = grad_parts >= 3 ? attn_bwd_dkv_split_kernel<3> : attn_bwd_dkv_split_kernel<1>;
+        hipLaunchKernelGGL(kq, dim3(min(grid, 256)), dim3(448), lds1, s, (const float*)q, (const float*)k, (const float*)v,
                            (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit);
-        hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(min(grid, 256)), dim3(448), lds2, s, (const float*)q, (const float*)k, (const float*)v,
+        hipLaunchKernelGGL(kkv, dim3(min(grid, 256)), dim3(448), lds2, s, (const float*)q, (const float*)k, (const float*)v,
                            (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit);
         DYT_HIP_CHECK(hipGetLastError());
         return 0;

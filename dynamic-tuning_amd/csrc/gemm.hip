@@ -386,7 +386,8 @@ __device__ unsigned long long g_gemm_dbg[4];
 // gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
-struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; };   // a_fold: k-tiles of ONE part of split operands stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads A column tile kt - (kt >= a_fold ? a_fold : 0) and W column tile kt - (kt >= 2 a_fold ? 2 a_fold : 0), i.e. [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]; 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; int a_ld; };   // a_ld: row stride of split operands when the contraction runs over fewer than three parts (0: K - a_fold * 64)
+// a_fold: k-tiles of ONE part of split operands stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads A column tile kt - (kt >= a_fold ? a_fold : 0) and W column tile kt - (kt >= 2 a_fold ? 2 a_fold : 0), i.e. [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]; 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
 // One workgroup = one tile: `bid` of `nwg` logical workgroups that tile rows [m_begin, M).  A device function so that one launch
 // can hold workgroups of two tile shapes (gemm_bf16_rows_kernel below).
 template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT>
@@ -421,7 +422,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     const int lrow = lane >> 3, slot = lane & 7, chunk = slot ^ lrow;
     const bf16* a_src[A_INSTR];
     const bf16* b_src[B_INSTR];
-    const int fold = cat.a_fold, lda = K - fold * BK;   // split A operand stored [hi | lo]: the hi part serves the first two thirds of the contraction
+    const int fold = cat.a_fold, lda = cat.a_ld ? cat.a_ld : K - fold * BK;   // split A operand stored [hi | lo]: the hi part serves the first two thirds of the contraction
 #pragma unroll
     for (int t = 0; t < A_INSTR; ++t) {
         const int row = (t * NW + wave) * 8 + lrow;
@@ -745,7 +746,7 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
                                           (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold, a.a_ld};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, cat);
     ++g_bf16_kernel_launches;
@@ -765,7 +766,7 @@ static int launch_bf16_rows(const GemmArgs& a, const Epi& epi, hipStream_t s, in
         DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold, a.a_ld};
     hipLaunchKernelGGL(kern, dim3(n_big + n_small), dim3(512), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W), a.M, a.N,
                        a.K, a.m_dev, a.a_map, body, n_big, epi, cat);
     ++g_bf16_kernel_launches;
@@ -1033,7 +1034,8 @@ int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
                            a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
         GemmArgs b = a;
-        b.A = a.a3; b.W = a.W3; b.K = 3 * a.K; b.a_fold = a.K / 64; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = nullptr; b.W3 = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        // a3_parts products of the contraction: 3 = hi*hi + hi*lo + lo*hi, 2 = hi * (hi + lo) (A rounded to half, W exact), 1 = hi*hi
+        b.A = a.a3; b.W = a.W3; b.K = a.a3_parts * a.K; b.a_fold = a.K / 64; b.a_ld = 2 * a.K; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = nullptr; b.W3 = nullptr; b.out_scale = 1.0f / a.a3_scale;
         return dispatch<float, true>(kind, b, s);
     }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;

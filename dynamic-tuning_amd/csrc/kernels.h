@@ -43,6 +43,8 @@ struct GemmArgs {
     float a3_scale = 1.f;   // power of two the fp32 A is multiplied by before it is split (gradients: keeps the lo part out of the fp16
                             // subnormals); the accumulators are multiplied by out_scale = 1 / a3_scale before the epilogue functor
     float out_scale = 1.f;
+    int a3_parts = 3;        // products of the split contraction (3: full; 2 / 1: gradient GEMMs of the forward-parity variant)
+    int a_ld = 0;            // (internal) row stride of the split operands
     int a_fold = 0;          // (internal) k-tiles per part of a split A operand stored [hi | lo]: set by launch_gemm
     bool a3_ready = false;   // a3 already holds the split A (written by the producing kernel): no pre-pass
     bool a3_mapped = false;  // ... one split row per SOURCE row: the GEMM gathers through a_map (the pre-pass compacts instead)
@@ -90,7 +92,7 @@ void set_attn_f32_split(int on);   // process-wide version of split16 (unit entr
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
                     const void* dout, const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles = 7,
-                    void* dqkv3 = nullptr, float s3 = 1.f, int split16 = 0);   // split16 (fp32 mode): the split backward kernels   // dqkv3 (fp32 mode): dqkv * s3 as split 16-bit operand [M, 3 * 2304] instead of fp32
+                    void* dqkv3 = nullptr, float s3 = 1.f, int split16 = 0, int grad_parts = 3);   // split16 (fp32 mode): the split backward kernels; grad_parts = 1: their dP / dQ / dK / dV products as hi * hi alone   // dqkv3 (fp32 mode): dqkv * s3 as split 16-bit operand [M, 3 * 2304] instead of fp32
 // q_tiles: 32-row query tiles that can carry a non-zero dout (1: only the cls rows do); honoured by the fused 16-bit kernel, exact
 // 16-bit modes: 1 (default) = dQ and dK/dV of a head in one persistent kernel, 0 = the two separate kernels (process-wide)
 void set_attn_bwd_fused(int on);

@@ -163,6 +163,8 @@ struct dyt_ctx {
     bool split_attn = true;     // ... and the attention forward too (attn_fwd_split_kernel; DYT_SPLIT_ATTN=0: exact fp32 MFMA kernel)
     bool split_prod = true;     // ... attention forward / ln_bwd / tok_bwd write the split operand of the GEMM that follows (DYT_SPLIT_PROD=0: pre-passes)
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
+    int split_bwd_parts = 3;    // ... products of the GRADIENT GEMMs' contraction (DYT_SPLIT_BWD_PARTS: 3 full, 2 = dY_hi * (W_hi + W_lo), 1 = dY_hi * W_hi)
+    int split_bwd_attn_parts = 3;   // ... and of the split attention backward's dP / dQ / dK / dV products (3 or 1; the score recomputation keeps three)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
     void* pe_w3 = nullptr;
     bool fc2_cat = true;        // 16-bit modes: adapter up-projection rides on the fc2 GEMM where no separate h is needed
@@ -637,8 +639,14 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_FC2_CAT: c->fc2_cat = value != 0; return DYT_OK;
         case DYT_OPT_F32_SPLIT16: {   // fp32 mode only: the frozen-weight GEMMs as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
             if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
+            if (value < 0 || value > 2) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part)", value); return DYT_ERR_ARG; }
             c->split16 = value != 0;
+            // 2 ("fp16x3f"): the forward (logits, gate decisions, losses, saved activations) as in 1; the gradient GEMMs contract
+            // dY_hi * W_hi alone and the attention backward's dP / dQ / dK / dV take the hi * hi product (its score recomputation keeps three)
+            c->split_bwd_parts = c->split_bwd_attn_parts = value == 2 ? 1 : 3;
             if (const char* e = getenv("DYT_SPLIT_GS_LOG2")) c->split_gs = (float)(1u << atoi(e));   // measurement knob
+            if (const char* e = getenv("DYT_SPLIT_BWD_PARTS")) c->split_bwd_parts = std::min(3, std::max(1, atoi(e)));
+            if (const char* e = getenv("DYT_SPLIT_BWD_ATTN_PARTS")) c->split_bwd_attn_parts = atoi(e) >= 3 ? 3 : 1;
             if (const char* e = getenv("DYT_SPLIT_ATTN")) c->split_attn = atoi(e) != 0;
             if (const char* e = getenv("DYT_SPLIT_PROD")) c->split_prod = atoi(e) != 0;
             for (auto& S : c->slots) S.valid = false;
@@ -748,7 +756,7 @@ static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return 
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
-#define SPLIT_G(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; (a).a3_scale = c->split_gs; } } while (0)
+#define SPLIT_G(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; (a).a3_scale = c->split_gs; (a).a3_parts = c->split_bwd_parts; } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // video model: attentive pooling head (video_models/video_vision_transformer_IN21K.py:463-483)
@@ -1326,7 +1334,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         POISON(32, T.dqkv, (size_t)M * 3 * D * c->at);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
-                            c->split16 ? T.dqkv3 : nullptr, c->split_gs, c->split16 && c->split_attn)););   // teacher tail: du, hence dO, is zero off the cls rows
+                            c->split16 ? T.dqkv3 : nullptr, c->split_gs, c->split16 && c->split_attn, c->split_bwd_attn_parts)););   // teacher tail: du, hence dO, is zero off the cls rows
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
             GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3);

@@ -163,7 +163,12 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           over the K-concatenated parts, fp32 accumulate, the fp32 epilogues): the per-GEMM error of the exact
  *                           fp32 MFMA kernel (1-2e-6 of max|C| with IEEE-half parts) at ~2.7x its speed; the attention forward and
  *                           backward likewise (DYT_SPLIT_ATTN=0 keeps the exact-fp32 attention kernels).  LayerNorm, adapter-sized
- *                           GEMMs and every row kernel stay exact fp32.  Host-side precision name: "fp16x3". */
+ *                           GEMMs and every row kernel stay exact fp32.  Host-side precision name: "fp16x3".
+ *                           2 ("fp16x3f"): the forward pass as in 1 -- logits, token-keep decisions, losses and saved activations
+ *                           are those of value 1 bit for bit -- while every GRADIENT product takes the hi*hi term alone (the
+ *                           frozen-weight dgrad GEMMs contract dY_hi * W_hi; the attention backward's dP / dQ / dK / dV likewise, its
+ *                           score recomputation keeps three products): gradients within 7e-4 relative L2 of the fp32 oracle
+ *                           (value 1: 1.5e-4; the bar of the exact mode's test: 2e-3) at 0.81x the step time of value 1. */
 #define DYT_OPT_F32_SPLIT16 8
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 /* the process-wide options (DYT_OPT_ATTN_BWD_FUSED) without a context: unit entries such as dyt_attention() see them too */
