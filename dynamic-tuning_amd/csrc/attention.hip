@@ -913,6 +913,17 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_f32_kernel(const float* __re
 // two row images, V^T as two transposed images (122.9 KB of LDS), q split in registers, the probabilities split per key tile
 // right where they are packed.  fp32 accumulation, fp32 softmax statistics, fp32 output.  Persistent over heads, no
 // cross-head prefetch (the fp32 rows would double the staging registers).
+// exp(x) for the split kernels: v_exp_f32 of the compensated product x * log2(e) -- h = rn(x * L2E), l = the product's remainder plus
+// x times the low part of log2(e), exp(x) = 2^h (1 + l ln 2) -- six instructions instead of libm expf's ~25, within ~1.5 ulp
+// (a bare __expf is off by |x| 2^-24 relative: 2e-6 at the scores' range, the level of the whole split mode's error)
+__device__ __forceinline__ float exp_c(float x) {
+    x = fmaxf(x, -104.0f);   // masked scores (-inf, -1e30) would make h - h a NaN; exp(-104) is 0 in fp32 anyway
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.925962991e-8f;
+    const float h = x * L2E;
+    const float l = __fmaf_rn(x, L2E_LO, __fmaf_rn(x, L2E, -h));
+    const float e = __builtin_amdgcn_exp2f(h);
+    return __fmaf_rn(e * 0.693147182464599609375f, l, e);
+}
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = expf(st[kt][r] - m);
+                const float p = exp_c(st[kt][r] - m);
                 st[kt][r] = p;
                 sp[r & 3] += p;
             }
@@ -1176,7 +1187,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = (hf * 4 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float p = key < NT ? expf(s_[r] - L) : 0.f;
+                    const float p = key < NT ? exp_c(s_[r] - L) : 0.f;
                     s_[r] = p * (dp_[r] - dlg);       // gs * dS^T
                 }
 #pragma unroll
@@ -1279,7 +1290,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
                         const bool ok = (hf * HROWS + q0 + e < NT) && (key < NT);
-                        const float pv = ok ? expf(s[r] - Ls[e]) : 0.f;
+                        const float pv = ok ? exp_c(s[r] - Ls[e]) : 0.f;
                         p[r] = pv;
                         s[r] = pv * (dp[r] - Ds[e]);  // dS
                     }

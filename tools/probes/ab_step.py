@@ -7,7 +7,7 @@ if os.environ.get("PMASK", "none") != "none":   # the two passes on complementar
 import torch
 import _lib, synth
 if os.environ.get("DYT_LIB_PATH"):
-    if os.environ.get("PPREC") in ("fp16", "fp16x3"):
+    if os.environ.get("PPREC") in ("fp16", "fp16x3", "fp16x3f"):
         _lib.LIB_PATH_F16 = os.environ["DYT_LIB_PATH"]   # an IEEE-half build (libdyt_hip_f16.so twin)
     else:
         _lib.LIB_PATH = os.environ["DYT_LIB_PATH"]
