@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
                                                                 const float* __restrict__ v, const float* __restrict__ o,
                                                                 const float* __restrict__ dout, const float* __restrict__ lse,
                                                                 float* __restrict__ delta, float* __restrict__ dqkv,
-                                                                bf16* __restrict__ dqkv3, float s3, int nheads, float gs) {
+                                                                bf16* __restrict__ dqkv3, float s3, int nheads, float gs, int hi_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Kh = reinterpret_cast<bf16*>(smem);
     bf16* Kl = reinterpret_cast<bf16*>(smem + ROW_H);
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
                 for (int g = 0; g < 4; ++g) {
                     const int d = dt * 32 + 8 * g + 4 * hi;
                     if (dqkv3) store4_split3(dqkv3 + ((size_t)b * NT + qrow) * (SPLIT_A * 3 * D) + h * HD + d, 3 * D, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
-                                             dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc);
+                                             dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc, hi_only != 0);
                     else store4(dqkv + ((size_t)b * NT + qrow) * (3 * D) + h * HD + d, dq[dt][4 * g] * sc, dq[dt][4 * g + 1] * sc,
                                 dq[dt][4 * g + 2] * sc, dq[dt][4 * g + 3] * sc);
                 }
@@ -1223,7 +1223,7 @@ template <int GP>
 __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                  const float* __restrict__ v, const float* __restrict__ dout,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 float* __restrict__ dqkv, bf16* __restrict__ dqkv3, float s3, int nheads, float gs) {
+                                                                 float* __restrict__ dqkv, bf16* __restrict__ dqkv3, float s3, int nheads, float gs, int hi_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Qh = reinterpret_cast<bf16*>(smem);
     bf16* Ql = reinterpret_cast<bf16*>(smem + ROW_H);
@@ -1320,8 +1320,8 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __
                     const int d = dt * 32 + 8 * g + 4 * hi;
                     if (dqkv3) {
                         bf16* op3 = dqkv3 + ((size_t)b * NT + key) * (SPLIT_A * 3 * D) + h * HD + d;
-                        store4_split3(op3 + D, 3 * D, aK[dt][4 * g] * sc, aK[dt][4 * g + 1] * sc, aK[dt][4 * g + 2] * sc, aK[dt][4 * g + 3] * sc);
-                        store4_split3(op3 + 2 * D, 3 * D, aV[dt][4 * g] * sc, aV[dt][4 * g + 1] * sc, aV[dt][4 * g + 2] * sc, aV[dt][4 * g + 3] * sc);
+                        store4_split3(op3 + D, 3 * D, aK[dt][4 * g] * sc, aK[dt][4 * g + 1] * sc, aK[dt][4 * g + 2] * sc, aK[dt][4 * g + 3] * sc, hi_only != 0);
+                        store4_split3(op3 + 2 * D, 3 * D, aV[dt][4 * g] * sc, aV[dt][4 * g + 1] * sc, aV[dt][4 * g + 2] * sc, aV[dt][4 * g + 3] * sc, hi_only != 0);
                     } else {
                         float* op = dqkv + ((size_t)b * NT + key) * (3 * D) + h * HD + d;
                         store4(op + D, aK[dt][4 * g] * sc, aK[dt][4 * g + 1] * sc, aK[dt][4 * g + 2] * sc, aK[dt][4 * g + 3] * sc);
@@ -1380,7 +1380,7 @@ static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV 
 void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
 
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
-                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16, int grad_parts) {
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16, int grad_parts, int out_hi_only) {
     const int grid = batch * NH;
     if (dbg_skip(1)) return 0;
     if (precision == 0 && (split16 || g_attn_f32_split)) {
@@ -1397,9 +1397,9 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
         auto* kq = grad_parts >= 3 ? attn_bwd_dq_split_kernel<3> : attn_bwd_dq_split_kernel<1>;
         auto* kkv = grad_parts >= 3 ? attn_bwd_dkv_split_kernel<3> : attn_bwd_dkv_split_kernel<1>;
         hipLaunchKernelGGL(kq, dim3(min(grid, 256)), dim3(448), lds1, s, (const float*)q, (const float*)k, (const float*)v,
-                           (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit);
+                           (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit, out_hi_only);
         hipLaunchKernelGGL(kkv, dim3(min(grid, 256)), dim3(448), lds2, s, (const float*)q, (const float*)k, (const float*)v,
-                           (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit);
+                           (const float*)dout, lse, delta, (float*)dqkv, (bf16*)dqkv3, s3, grid, dqkv3 ? s3 : gs_unit, out_hi_only);
         DYT_HIP_CHECK(hipGetLastError());
         return 0;
     }

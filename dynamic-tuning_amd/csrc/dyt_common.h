@@ -99,6 +99,12 @@ __device__ __forceinline__ void store4_split3(bf16* dst, int K, float a, float b
     *reinterpret_cast<bf16x4*>(dst) = hi;
     *reinterpret_cast<bf16x4*>(dst + K) = lo;
 }
+// ... with the lo half left unwritten when its consumer contracts over the hi part alone (gradient operands of the "fp16x3f" form)
+__device__ __forceinline__ void store4_split3(bf16* dst, int K, float a, float b, float c, float d, bool hi_only) {
+    if (!hi_only) { store4_split3(dst, K, a, b, c, d); return; }
+    const bf16x4 hi = {split2(a).hi, split2(b).hi, split2(c).hi, split2(d).hi};
+    *reinterpret_cast<bf16x4*>(dst) = hi;
+}
 __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
     float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;

@@ -210,6 +210,7 @@ struct EpiGeluBwd {
     const AT* gp; AT* out; int ld;   // gp = gelu'(z) saved by the fc1 epilogue
     const int* row_map;
     bf16* out3; float s3;   // split fp32 form: dZ * s3 goes out as the split operand of the fc1 dgrad GEMM instead of as fp32
+    bool hi_only;           // ... its hi half alone (that GEMM contracts one part)
     typedef NoCtx Col; typedef Raw4<AT> Pre;
     __device__ __forceinline__ Col col_init(int) const { return {}; }
     __device__ __forceinline__ Pre pre(int row, int col) const {   // gelu'(z) is read exactly once: streaming load
@@ -226,7 +227,7 @@ struct EpiGeluBwd {
         float g[4];
         p.get(g);
         if constexpr (sizeof(AT) == 4) {
-            if (out3) { store4_split3(out3 + (size_t)row * SPLIT_A * ld + col, ld, a[0] * g[0] * s3, a[1] * g[1] * s3, a[2] * g[2] * s3, a[3] * g[3] * s3); return; }
+            if (out3) { store4_split3(out3 + (size_t)row * SPLIT_A * ld + col, ld, a[0] * g[0] * s3, a[1] * g[1] * s3, a[2] * g[2] * s3, a[3] * g[3] * s3, hi_only); return; }
         }
         store4(out + (size_t)row * ld + col, a[0] * g[0], a[1] * g[1], a[2] * g[2], a[3] * g[3]);
     }
@@ -914,8 +915,8 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             return run<AT, SPLIT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
         }
         case EPI_GELU_BWD:
-            if (a.row_map) return run<AT, SPLIT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map, (bf16*)a.out3, a.out3_scale}, s);
-            return run<AT, SPLIT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr, (bf16*)a.out3, a.out3_scale}, s);
+            if (a.row_map) return run<AT, SPLIT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map, (bf16*)a.out3, a.out3_scale, a.out3_hi_only}, s);
+            return run<AT, SPLIT>(a, EpiGeluBwd<AT, false>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, nullptr, (bf16*)a.out3, a.out3_scale, a.out3_hi_only}, s);
         case EPI_STORE_F32: return run<AT, SPLIT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
         case EPI_STORE_AT: return run<AT, SPLIT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:

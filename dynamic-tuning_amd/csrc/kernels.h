@@ -49,7 +49,7 @@ struct GemmArgs {
     bool a3_ready = false;   // a3 already holds the split A (written by the producing kernel): no pre-pass
     bool a3_mapped = false;  // ... one split row per SOURCE row: the GEMM gathers through a_map (the pre-pass compacts instead)
     // FC1 / GELU_BWD in the split form: the result also (instead of out_at) goes out as the split A operand of the NEXT GEMM
-    void* out3 = nullptr; float out3_scale = 1.f;
+    void* out3 = nullptr; float out3_scale = 1.f; bool out3_hi_only = false;   // hi_only: the next GEMM contracts the hi part alone
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -92,7 +92,8 @@ void set_attn_f32_split(int on);   // process-wide version of split16 (unit entr
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
                     const void* dout, const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles = 7,
-                    void* dqkv3 = nullptr, float s3 = 1.f, int split16 = 0, int grad_parts = 3);   // split16 (fp32 mode): the split backward kernels; grad_parts = 1: their dP / dQ / dK / dV products as hi * hi alone   // dqkv3 (fp32 mode): dqkv * s3 as split 16-bit operand [M, 3 * 2304] instead of fp32
+                    void* dqkv3 = nullptr, float s3 = 1.f, int split16 = 0, int grad_parts = 3, int out_hi_only = 0);   // out_hi_only: dqkv3 without its lo half (the qkv dgrad contracts one part)
+      // split16 (fp32 mode): the split backward kernels; grad_parts = 1: their dP / dQ / dK / dV products as hi * hi alone   // dqkv3 (fp32 mode): dqkv * s3 as split 16-bit operand [M, 3 * 2304] instead of fp32
 // q_tiles: 32-row query tiles that can carry a non-zero dout (1: only the cls rows do); honoured by the fused 16-bit kernel, exact
 // 16-bit modes: 1 (default) = dQ and dK/dV of a head in one persistent kernel, 0 = the two separate kernels (process-wide)
 void set_attn_bwd_fused(int on);

@@ -1263,7 +1263,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
                 a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3);
                 if (g3_ready && !tail) { SPLIT_READY(a, T.g3); a.a3_mapped = true; }   // ln_bwd of the block above wrote g as the split operand
-                if (c->split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; }   // dZ as the split operand of the fc1 dgrad
+                if (c->split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; a.out3_hi_only = c->split_bwd_parts == 1; }   // dZ as the split operand of the fc1 dgrad
                 if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
                 CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
@@ -1334,7 +1334,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         POISON(32, T.dqkv, (size_t)M * 3 * D * c->at);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
             launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
-                            c->split16 ? T.dqkv3 : nullptr, c->split_gs, c->split16 && c->split_attn, c->split_bwd_attn_parts)););   // teacher tail: du, hence dO, is zero off the cls rows
+                            c->split16 ? T.dqkv3 : nullptr, c->split_gs, c->split16 && c->split_attn, c->split_bwd_attn_parts, c->split_bwd_parts == 1)););   // teacher tail: du, hence dO, is zero off the cls rows
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
         {
             GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3);
