@@ -165,6 +165,7 @@ struct dyt_ctx {
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     int split_bwd_parts = 3;    // ... products of the GRADIENT GEMMs' contraction (DYT_SPLIT_BWD_PARTS: 3 full, 2 = dY_hi * (W_hi + W_lo), 1 = dY_hi * W_hi)
     int split_bwd_attn_parts = 3;   // ... and of the split attention backward's dP / dQ / dK / dV products (3 or 1; the score recomputation keeps three)
+    int split_fwd_parts[4] = {3, 3, 3, 3};   // ... products of the FORWARD GEMMs per class (qkv, proj, fc1, fc2): measurement knob
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
     void* pe_w3 = nullptr;
     bool fc2_cat = true;        // 16-bit modes: adapter up-projection rides on the fc2 GEMM where no separate h is needed
@@ -647,6 +648,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             if (const char* e = getenv("DYT_SPLIT_GS_LOG2")) c->split_gs = (float)(1u << atoi(e));   // measurement knob
             if (const char* e = getenv("DYT_SPLIT_BWD_PARTS")) c->split_bwd_parts = std::min(3, std::max(1, atoi(e)));
             if (const char* e = getenv("DYT_SPLIT_BWD_ATTN_PARTS")) c->split_bwd_attn_parts = atoi(e) >= 3 ? 3 : 1;
+            if (const char* e = getenv("DYT_SPLIT_FWD_PARTS")) sscanf(e, "%d,%d,%d,%d", &c->split_fwd_parts[0], &c->split_fwd_parts[1], &c->split_fwd_parts[2], &c->split_fwd_parts[3]);
             if (const char* e = getenv("DYT_SPLIT_ATTN")) c->split_attn = atoi(e) != 0;
             if (const char* e = getenv("DYT_SPLIT_PROD")) c->split_prod = atoi(e) != 0;
             for (auto& S : c->slots) S.valid = false;
@@ -753,6 +755,8 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
 
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 #define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
+// forward GEMM class g (0 qkv, 1 proj, 2 fc1, 3 fc2): products of its contraction (measurement knob DYT_SPLIT_FWD_PARTS="qkv,proj,fc1,fc2")
+#define SPLIT_F(a, w3, g) do { SPLIT(a, w3); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; } while (0)
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
@@ -902,7 +906,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr));
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
-                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT(a, W.qkv_w3); SPLIT_READY(a, T.xn3);
+                a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT_F(a, W.qkv_w3, 0); SPLIT_READY(a, T.xn3);
                 RUN_GEMM(EPI_QKV, a);
             }
             void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? T.g3 : nullptr;   // the split attention kernel also writes the proj GEMM's operand
@@ -911,11 +915,11 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
                 GemmArgs a; a.A = L.attn_o; a.a_map = c->cls_rows; a.W = W.proj_w; a.M = B; a.N = D; a.K = D; a.bias = W.proj_b;
-                a.resid = x; a.out_f32 = L.u; a.scale = 1.0f; a.row_map = c->cls_rows; SPLIT(a, W.proj_w3);
+                a.resid = x; a.out_f32 = L.u; a.scale = 1.0f; a.row_map = c->cls_rows; SPLIT_F(a, W.proj_w3, 1);
                 RUN_GEMM(EPI_AD_UP, a);
             } else {
                 GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
-                a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at; SPLIT(a, W.proj_w3);
+                a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at; SPLIT_F(a, W.proj_w3, 1);
                 if (ao3) SPLIT_READY(a, ao3);
                 RUN_GEMM(EPI_BIAS_RESID, a);
             }
@@ -982,7 +986,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const int* kdev = (dense || tail) ? nullptr : L.total;
         {
             GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
-            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT(a, W.fc1_w3);
+            a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT_F(a, W.fc1_w3, 2);
             if (!tail) SPLIT_READY(a, T.xn3);   // (the cls tail's LN2 rows come from ln_cls in fp32: pre-pass)
             if (c->split16) a.out3 = T.h3;
             RUN_GEMM(EPI_FC1, a);
@@ -998,7 +1002,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.row_map = tail ? c->cls_rows : (dense ? nullptr : L.row_src);
             a.row_mask = (masked_dense && !tail) ? L.maskf : nullptr;   // the cls token is never gated
             a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
-            SPLIT(a, W.fc2_w3); SPLIT_READY(a, T.h3);
+            SPLIT_F(a, W.fc2_w3, 3); SPLIT_READY(a, T.h3);
             if (cat) {
                 a.A2 = T.dact_s; a.W2 = at_off(c, c->ad_up_w, (size_t)l * RP * D);   // [s d_act | h] x [W_up | W2]^T
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
