@@ -823,6 +823,12 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         return launch_bf16_bpre<0>(b, epi, s);
     }
     }
+    if constexpr (!CAT) {
+        // one-part split GEMMs with a wide N (GELU' dgrad of "fp16x3f": 12 k-tiles against an epilogue that reads gelu' and writes dZ):
+        // the 256x256 kernel's exposed epilogue outweighs its main loop -> 128x128 tiles, two workgroups per CU (DYT_SPLIT_SHORTK_SMALL=0: off)
+        static const int shortk_small = getenv("DYT_SPLIT_SHORTK_SMALL") ? atoi(getenv("DYT_SPLIT_SHORTK_SMALL")) : 1;   // 2: the N = 768 ones (proj dgrad) too
+        if (shortk_small && a.a_ld && a.K <= D && (a.N >= g_big_tile_min_n || shortk_small == 2) && a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
+    }
     if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
     if (a.N % 256 == 0 && a.K >= 256 && g_split_rows) {
         // Narrow-N GEMMs (N = 768): per row, 256x256 tiles are ~1.6x cheaper than 128x128 tiles (half the L2->LDS bytes
