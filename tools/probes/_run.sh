@@ -1,4 +1,3 @@
-for i in 1 2; do
-PPREC=fp16x3f PSTEPS=10 PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1
-DYT_SPLIT_SHORTK_SMALL=2 PPREC=fp16x3f PSTEPS=10 PREPS=2 python tools/probes/ab_step.py 2>&1 | tail -1
+for i in 1 2 3; do
+python -m pytest tests/test_gpu_round2.py -x -q -s -k "adapter_submodule" 2>&1 | grep -E "adapter_bwd|passed|failed" | grep -E "197, 768|passed|failed|, 768\)" | tr '\n' ';' ; echo
 done
