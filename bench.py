@@ -208,7 +208,7 @@ def main():
                   "steps": pm["steps"], "step_gflop_per_image": pm["step_gflop_per_image"], "step_mfma_frac": pm["step_mfma_frac"],
                   "keep_ratio_measured": pm["keep_ratio_measured"], "roofline": pm["roofline"],
                   "parity": "vs the CPU oracle at B=16 (tests/test_gpu_round3.py::test_split_fp16x3_mode_meets_the_fp32_parity_bars): logits "
-                            "max abs err 5.7e-6 (bar 1e-3), 0 of 37 632 token-keep decisions differ, losses 1e-6 (forward = fp16x3's bit for bit); "
+                            "max abs err 6.6e-6 (bar 1e-3), 0 of 37 632 token-keep decisions differ, losses 1e-6 (forward = fp16x3's bit for bit); "
                             "74 gradients rel-L2 <= 6.3e-4 (gradient products hi * hi only; bar of the exact mode's test 2e-3); "
                             "`roofline.peak` = 2500 / 2 TFLOP/s (forward three half-precision products per useful product, backward one)"}
         torch.cuda.empty_cache()
