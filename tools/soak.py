@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "d
 import bench, synth
 from engine_finetune import FusedAdamW, train_one_epoch
 from models.losses import AdaLoss
-args = types.SimpleNamespace(classes=100, ffn_num=64, precision="bf16", batch=128, mode="compact", video_frames=0)
+args = types.SimpleNamespace(classes=100, ffn_num=64, precision=os.environ.get("PPREC", "bf16"), batch=128, mode="compact", video_frames=0)
 dev = torch.device("cuda", 0)
 model = bench.build_model(args, dev)
 x, y = synth.make_batch(128, 100, seed=1)
