@@ -252,6 +252,9 @@ struct WgradArgs {
     float* out_w; int sc, sj; float alpha;
     float* out_xsum; float alpha_x;
     float* out_ysum = nullptr; float alpha_y = 0.f;   // out_ysum[j] += alpha_y * sum_m Y[m][j], j < r
+    // fp32 mode only: the products on the 16-bit matrix cores from fp32 inputs converted as they are loaded (one-part gradient
+    // products of "fp16x3f"); X / Y are multiplied by x_scale / y_scale (powers of two) first, the outputs divided again
+    bool half_products = false; float x_scale = 1.f, y_scale = 1.f;
 };
 // Reductions of per-chunk partials deferred to ONE batched launch (the backward pass queues the adapter weight-gradient and the
 // gate-gradient reductions of several blocks -- each with its own partial buffer -- and flushes them where the gradients have to

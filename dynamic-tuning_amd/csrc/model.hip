@@ -166,6 +166,7 @@ struct dyt_ctx {
     int split_bwd_parts = 3;    // ... products of the GRADIENT GEMMs' contraction (DYT_SPLIT_BWD_PARTS: 3 full, 2 = dY_hi * (W_hi + W_lo), 1 = dY_hi * W_hi)
     int split_bwd_attn_parts = 3;   // ... and of the split attention backward's dP / dQ / dK / dV products (3 or 1; the score recomputation keeps three)
     int split_fwd_parts[4] = {3, 3, 3, 3};   // ... products of the FORWARD GEMMs per class (qkv, proj, fc1, fc2): measurement knob
+    bool split_wgrad16 = true;  // ... adapter weight gradients as one-part products too (DYT_SPLIT_WGRAD16=0: the exact-fp32 kernel)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
     void* pe_w3 = nullptr;
     bool fc2_cat = true;        // 16-bit modes: adapter up-projection rides on the fc2 GEMM where no separate h is needed
@@ -649,6 +650,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             if (const char* e = getenv("DYT_SPLIT_BWD_PARTS")) c->split_bwd_parts = std::min(3, std::max(1, atoi(e)));
             if (const char* e = getenv("DYT_SPLIT_BWD_ATTN_PARTS")) c->split_bwd_attn_parts = atoi(e) >= 3 ? 3 : 1;
             if (const char* e = getenv("DYT_SPLIT_FWD_PARTS")) sscanf(e, "%d,%d,%d,%d", &c->split_fwd_parts[0], &c->split_fwd_parts[1], &c->split_fwd_parts[2], &c->split_fwd_parts[3]);
+            if (const char* e = getenv("DYT_SPLIT_WGRAD16")) c->split_wgrad16 = atoi(e) != 0;
             if (const char* e = getenv("DYT_SPLIT_ATTN")) c->split_attn = atoi(e) != 0;
             if (const char* e = getenv("DYT_SPLIT_PROD")) c->split_prod = atoi(e) != 0;
             for (auto& S : c->slots) S.valid = false;
@@ -1257,6 +1259,11 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = inv_gs;      // down_proj.weight [r, 768]  (Y = ddz carries gs)
             b.out_xsum = nullptr; b.alpha_x = 0.f;
             b.out_ysum = gbase + c->off_db; b.alpha_y = inv_gs;                     // down_proj.bias
+            if (c->split16 && c->split_bwd_parts == 1 && c->split_wgrad16) {   // "fp16x3f": gradient products one-part here too
+                a.half_products = b.half_products = true;
+                a.x_scale = c->split_gs;   // X = g (gradient-sized), Y = d_act
+                b.y_scale = c->split_gs;   // X = u, Y = ddz (gradient-sized)
+            }
             ISO(32, RUN_ON(sb, 2, 4.0 * Mr * D * (double)RP, launch_wgrad(P, w, 2, s, sb ? nullptr : &rq)););
             CK("wgrad up_w", gbase + c->off_uw, (size_t)D * r * 4); CK("wgrad down_w", gbase + c->off_dw, (size_t)D * r * 4);
         }

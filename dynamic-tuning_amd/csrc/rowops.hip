@@ -961,11 +961,25 @@ constexpr int WG_CHUNK = 512;   // minimum tokens per workgroup (the partial buf
 // of X (-> partial[..][c][64]) and of Y (wave 0 of the first channel block, -> partial[..][768][j]) are
 // taken from the same fragments on the vector ALU.
 constexpr int WG_ROWS = D + 8;  // partial rows per chunk: 768 channels + 1 row of Y column sums (+pad)
-struct WgSrc { const void* X; const void* Y; float* partial; };
+struct WgSrc { const void* X; const void* Y; float* partial; float xscale, yscale; };   // x / yscale: fp32 inputs of the half-product form are multiplied by these before the 16-bit conversion
 struct WgPair { WgSrc p[2]; };   // blockIdx.z selects the product: both adapter weight gradients of a block are ONE launch
+// IT = float: the same kernel on fp32 inputs, converted (times a power of two that keeps gradient-sized values out of the 16-bit
+// subnormals) as they are loaded -- the one-part gradient products of the "fp16x3f" form (wgrad_f32_kernel runs at the fp32-MFMA rate)
+template <class IT>
+__device__ __forceinline__ bf16x8 wg_load8(const IT* p, float scale) {
+    if constexpr (sizeof(IT) == 2) {
+        return *reinterpret_cast<const bf16x8*>(p);
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p) * scale, b = *reinterpret_cast<const f32x4*>(p + 4) * scale;
+        bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+        return v;
+    }
+}
+template <class IT>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, int chunk) {
-    const bf16* __restrict__ X = static_cast<const bf16*>(src.p[blockIdx.z].X);
-    const bf16* __restrict__ Y = static_cast<const bf16*>(src.p[blockIdx.z].Y);
+    const IT* __restrict__ X = static_cast<const IT*>(src.p[blockIdx.z].X);
+    const IT* __restrict__ Y = static_cast<const IT*>(src.p[blockIdx.z].Y);
+    const float xscale = src.p[blockIdx.z].xscale, yscale = src.p[blockIdx.z].yscale;
     float* __restrict__ partial = src.p[blockIdx.z].partial;
     constexpr int TS = 64;        // tokens per step
     constexpr int LDT = TS + 8;   // bf16 per LDS row (144 B: 16-B aligned rows)
@@ -996,13 +1010,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
         for (int h = 0; h < 2; ++h) {
             const int t = tb + 2 * (xp0 + 16 * h);
             zero(xr[h][0]); zero(xr[h][1]);
-            if (t < mend) xr[h][0] = *reinterpret_cast<const bf16x8*>(X + (size_t)t * D + c0 + xc * 8);
-            if (t + 1 < mend) xr[h][1] = *reinterpret_cast<const bf16x8*>(X + (size_t)(t + 1) * D + c0 + xc * 8);
+            if (t < mend) xr[h][0] = wg_load8<IT>(X + (size_t)t * D + c0 + xc * 8, xscale);
+            if (t + 1 < mend) xr[h][1] = wg_load8<IT>(X + (size_t)(t + 1) * D + c0 + xc * 8, xscale);
         }
         const int ty = tb + 2 * yp;
         zero(yr[0]); zero(yr[1]);
-        if (ty < mend) yr[0] = *reinterpret_cast<const bf16x8*>(Y + (size_t)ty * RP + yc * 8);
-        if (ty + 1 < mend) yr[1] = *reinterpret_cast<const bf16x8*>(Y + (size_t)(ty + 1) * RP + yc * 8);
+        if (ty < mend) yr[0] = wg_load8<IT>(Y + (size_t)ty * RP + yc * 8, yscale);
+        if (ty + 1 < mend) yr[1] = wg_load8<IT>(Y + (size_t)(ty + 1) * RP + yc * 8, yscale);
     };
     if (m0 < mend) load_step(m0);
     for (int tb = m0; tb < mend; tb += TS) {
@@ -1240,19 +1254,23 @@ int launch_wgrad(int precision, const WgradArgs* a, int n, hipStream_t s, Reduce
     WgOutPair outs;
     for (int i = 0; i < 2; ++i) {
         const WgradArgs& w = a[i < n ? i : 0];
-        src.p[i] = WgSrc{w.X, w.Y, w.partial};
-        outs.p[i] = WgOut{w.partial, w.out_w, w.sc, w.sj, w.alpha, w.out_xsum, w.alpha_x, w.out_ysum, w.alpha_y};
+        const bool half = precision == 0 && w.half_products;
+        const float xs = half ? w.x_scale : 1.f, ys = half ? w.y_scale : 1.f;
+        src.p[i] = WgSrc{w.X, w.Y, w.partial, xs, ys};
+        outs.p[i] = WgOut{w.partial, w.out_w, w.sc, w.sj, w.alpha / (xs * ys), w.out_xsum, w.alpha_x / xs, w.out_ysum, w.alpha_y / ys};
     }
-    if (precision == 0) hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
+    if (precision == 0 && a[0].half_products != (n == 2 ? a[1].half_products : a[0].half_products)) { set_error("launch_wgrad: mixed product forms in a pair"); return -1; }
+    if (precision == 0 && a[0].half_products) hipLaunchKernelGGL(wgrad_bf16_kernel<float>, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
+    else if (precision == 0) hipLaunchKernelGGL(wgrad_f32_kernel, dim3(D / 128, nchunks, n), dim3(256), 0, s, src, M, chunk);
     else {
         // measurement hook: DYT_DBG_WGRAD_LDS = extra dynamic LDS bytes per workgroup (keeps other workgroups off the CU)
         static int extra = -1;
         if (extra < 0) {
             const char* e = getenv("DYT_DBG_WGRAD_LDS");
             extra = e ? atoi(e) : 0;
-            if (extra > 0) DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, extra));
+            if (extra > 0) DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, extra));
         }
-        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(D / 128, nchunks, n), dim3(256), extra, s, src, M, chunk);
+        hipLaunchKernelGGL(wgrad_bf16_kernel<bf16>, dim3(D / 128, nchunks, n), dim3(256), extra, s, src, M, chunk);
     }
     if (defer) {
         if (defer->n_wg + n > ReduceQueue::MAX_WG || (defer->n_wg > 0 && defer->r != r)) { set_error("reduce queue full / mixed ranks"); return -1; }
