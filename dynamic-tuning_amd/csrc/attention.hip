@@ -1099,15 +1099,23 @@ __device__ __forceinline__ void stage_split_half(const float* __restrict__ src, 
         if (g0 + 1 >= NT) { bh = zero8(); bl = zero8(); }
         if (rH) {
             *reinterpret_cast<bf16x8*>(rH + r0 * RLD + c * 8) = ah;
-            *reinterpret_cast<bf16x8*>(rL + r0 * RLD + c * 8) = al;
             *reinterpret_cast<bf16x8*>(rH + (r0 + 1) * RLD + c * 8) = bh;
+        }
+        if (rL) {   // (null where only one-part products read the image: the lo half is never looked at)
+            *reinterpret_cast<bf16x8*>(rL + r0 * RLD + c * 8) = al;
             *reinterpret_cast<bf16x8*>(rL + (r0 + 1) * RLD + c * 8) = bl;
         }
         if (tH) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                bf16x2 ph = {ah[i], bh[i]}, pl = {al[i], bl[i]};
+                bf16x2 ph = {ah[i], bh[i]};
                 *reinterpret_cast<bf16x2*>(tH + (c * 8 + i) * TLDH + r0) = ph;
+            }
+        }
+        if (tL) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf16x2 pl = {al[i], bl[i]};
                 *reinterpret_cast<bf16x2*>(tL + (c * 8 + i) * TLDH + r0) = pl;
             }
         }
@@ -1167,8 +1175,8 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_split_kernel(const float* __r
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();   // the previous half's (head's) images are no longer read
-            stage_split_half(k + (size_t)bh * NT * HD, HD, hf * HROWS, Kh, Kl, Kth, Ktl, tid);
-            stage_split_half(v + (size_t)bh * NT * HD, HD, hf * HROWS, Vh, Vl, nullptr, nullptr, tid);
+            stage_split_half(k + (size_t)bh * NT * HD, HD, hf * HROWS, Kh, Kl, Kth, GP == 3 ? Ktl : nullptr, tid);
+            stage_split_half(v + (size_t)bh * NT * HD, HD, hf * HROWS, Vh, GP == 3 ? Vl : nullptr, nullptr, nullptr, tid);
             __syncthreads();
             const int ntile = hf == 0 ? 4 : 3;
 #pragma unroll 1
@@ -1256,8 +1264,8 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_split_kernel(const float* __
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
-            stage_split_half(q + (size_t)bh * NT * HD, HD, hf * HROWS, Qh, Ql, Qth, Qtl, tid);
-            stage_split_half(dout + (size_t)b * NT * D + h * HD, D, hf * HROWS, Dh, Dl, Dth, Dtl, tid, gs);
+            stage_split_half(q + (size_t)bh * NT * HD, HD, hf * HROWS, Qh, Ql, Qth, GP == 3 ? Qtl : nullptr, tid);
+            stage_split_half(dout + (size_t)b * NT * D + h * HD, D, hf * HROWS, Dh, GP == 3 ? Dl : nullptr, Dth, GP == 3 ? Dtl : nullptr, tid, gs);
             if (tid < HROWS) {
                 const int qg = hf * HROWS + tid;
                 lse_s[tid] = qg < NT ? lse[(size_t)bh * NT + qg] : 0.f;
