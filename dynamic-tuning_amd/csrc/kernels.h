@@ -108,7 +108,7 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx_out, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  float gs, hipStream_t s, void* out3 = nullptr, float s3 = 1.0f);   // out3: + dx * s3 as a [rows][3*768] split operand (fp32 mode)   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
+                  float gs, hipStream_t s, void* out3 = nullptr, float s3 = 1.0f, int out3_hi_only = 0);   // out3: + dx * s3 as a [rows][3*768] split operand (fp32 mode)   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
 
 struct GateArgs {
     const float* u;          // [B*197,768] residual stream after attention
@@ -237,7 +237,7 @@ struct TokBwdArgs {
     const float* cat_bup = nullptr;   // unused (kept for ABI stability of the struct)
     float cat_scale = 0.f, cat_ddz_scale = 0.f;   // s ; 1 / (inv_keep * gs)
     void* du3 = nullptr;           // fp32 split form: + du * du3_scale as the [M][3*768] 16-bit hi / hi / lo operand of the proj dgrad
-    float du3_scale = 1.0f;
+    float du3_scale = 1.0f; bool du3_hi_only = false;   // hi_only: without the lo half (one-part proj dgrad)
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
 // out[i] += alpha * sum_p partial[p*stride + i], i < n

@@ -1314,7 +1314,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
             a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = S.tok_part[l]; a.M = M; a.write_du = !first;
-            if (split_prod && !first) { a.du3 = T.g3; a.du3_scale = c->split_gs; }
+            if (split_prod && !first) { a.du3 = T.g3; a.du3_scale = c->split_gs; a.du3_hi_only = c->split_bwd_parts == 1; }
             int nblk = 0;
             if (a.du_at) POISON(8, T.du_at, (size_t)M * D * c->at);
             ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s)););
@@ -1358,7 +1358,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             if (g_at) POISON(256, g_at, (size_t)M * D * c->at);
             ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
                                     (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, gs, s,
-                                    (split_prod && l > 1) ? T.g3 : nullptr, c->split_gs)););
+                                    (split_prod && l > 1) ? T.g3 : nullptr, c->split_gs, c->split_bwd_parts == 1)););
             g3_ready = split_prod && l > 1;
             CK("ln_bwd g", g, (size_t)M * D * 4);
             if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * c->at);

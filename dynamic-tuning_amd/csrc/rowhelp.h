@@ -34,10 +34,10 @@ struct Row12 {
         }
     }
     // the row times `scale` as the 16-bit hi / lo split operand of a GEMM (row base p3 of a [rows][SPLIT_A * 768] image)
-    __device__ __forceinline__ void store_split3(bf16* p3, int lane, float scale) const {
+    __device__ __forceinline__ void store_split3(bf16* p3, int lane, float scale, bool hi_only = false) const {   // hi_only: the consumer contracts the hi part alone
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            store4_split3(p3 + i * 256 + lane * 4, 768, v[4 * i] * scale, v[4 * i + 1] * scale, v[4 * i + 2] * scale, v[4 * i + 3] * scale);
+            store4_split3(p3 + i * 256 + lane * 4, 768, v[4 * i] * scale, v[4 * i + 1] * scale, v[4 * i + 2] * scale, v[4 * i + 3] * scale, hi_only);
     }
     template <class T>
     __device__ __forceinline__ void store(T* p, int lane) const {

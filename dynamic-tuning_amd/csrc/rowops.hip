@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
                                                      const float* __restrict__ base, float* __restrict__ dx, int rows,
                                                      AT* __restrict__ g_at, const AT* __restrict__ h_next,
                                                      const int* __restrict__ dst_of_next, float* __restrict__ dmask_next,
-                                                     float gs, float inv_gs, bf16* __restrict__ out3, float s3) {
+                                                     float gs, float inv_gs, bf16* __restrict__ out3, float s3, int hi3) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
     g.store(dx + (size_t)row * D, lane);
-    if (out3) g.store_split3(out3 + (size_t)row * SPLIT_A * D, lane, s3);   // fp32 split form: the next block's GELU' dgrad operand
+    if (out3) g.store_split3(out3 + (size_t)row * SPLIT_A * D, lane, s3, hi3 != 0);   // fp32 split form: the next block's GELU' dgrad operand
     if (g_at) {
         Row12 gsc;
 #pragma unroll
@@ -136,14 +136,14 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 }
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  float gs, hipStream_t s, void* out3, float s3) {
+                  float gs, hipStream_t s, void* out3, float s3, int out3_hi_only) {
     if (dbg_skip(16)) return 0;
     if (precision == 0)
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx,
-                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next, 1.0f, 1.0f, (bf16*)out3, s3);
+                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next, 1.0f, 1.0f, (bf16*)out3, s3, out3_hi_only);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)dy, x, stats, w, base, dx,
-                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next, gs, 1.0f / gs, (bf16*)nullptr, 1.0f);
+                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next, gs, 1.0f / gs, (bf16*)nullptr, 1.0f, 0);
     LAUNCH_CHECK();
     return 0;
 }
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         }
         if (a.write_du) {
             du.store(a.du + (size_t)t * D, lane);
-            if (a.du3) du.store_split3(reinterpret_cast<bf16*>(a.du3) + (size_t)t * SPLIT_A * D, lane, a.du3_scale);   // proj dgrad operand (fp32 split form)
+            if (a.du3) du.store_split3(reinterpret_cast<bf16*>(a.du3) + (size_t)t * SPLIT_A * D, lane, a.du3_scale, a.du3_hi_only);   // proj dgrad operand (fp32 split form)
             if (a.du_at) {
                 Row12 dsc;
 #pragma unroll
