@@ -44,7 +44,8 @@ STEP_GFLOP_AT_07 = 126.851   # SURVEY.md section 8d / BASELINE.md section 3, com
 STEP_GFLOP_SLOPE = 42.542    # d(GFLOP)/d(keep ratio)
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3,   # TFLOP/s dense MFMA, MI355X_MICROARCH.md
         "fp16x3": 2500.0 / 3,   # three half-precision products per fp32-class product: the USEFUL-FLOP ceiling of the split form
-        "fp16x3f": 2500.0 / 2}  # forward GEMMs three products, gradient GEMMs one (equal useful FLOPs either side): two on average
+        "fp16x3f": 2500.0 / 2,  # forward GEMMs three products, gradient GEMMs one (equal useful FLOPs either side): two on average
+        "fp16x3h": 2500.0 / 2}  # the same product counts; the backward runs on 16-bit operands with the fp16 mode's kernels
 TRAFFIC_JSON = os.path.join("round3", "gemm_traffic.json")
 
 
@@ -134,7 +135,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32", "fp16x3", "fp16x3f"],
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32", "fp16x3", "fp16x3f", "fp16x3h"],
                     help="16-bit operand type of the fast kernels (bf16, or fp16 = the reference's own autocast dtype, same MFMA rate) or the exact-fp32 parity mode")
     ap.add_argument("--mode", default="compact", choices=["compact", "masked"])
     ap.add_argument("--classes", type=int, default=100)
@@ -348,7 +349,10 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
                           "fp32-class product, fp32 epilogues; adapter-sized GEMMs on gemm_f32_mfma_nt_kernel); achieved = USEFUL FLOPs"
                           ,
                 "fp16x3f": "gemm_bf16_nt_kernel on IEEE-half hi / lo parts of fp32 operands: forward GEMMs three f16 MFMA 16x16x32 products per "
-                           "fp32-class product, gradient GEMMs the hi * hi product alone, fp32 epilogues; achieved = USEFUL FLOPs"
+                           "fp32-class product, gradient GEMMs the hi * hi product alone, fp32 epilogues; achieved = USEFUL FLOPs",
+                "fp16x3h": "forward: gemm_bf16_nt_kernel on IEEE-half hi / lo parts of fp32 operands (three f16 MFMA 16x16x32 products per fp32-class "
+                           "product, fp32 epilogues); backward: the fp16 mode's gemm_bf16_nt_kernel + gemm_bf16_bpre_kernel on 16-bit operands; "
+                           "achieved = USEFUL FLOPs"
                 }.get(precision, "gemm_bf16_nt_kernel + gemm_bf16_bpre_kernel (%s MFMA 16x16x32, all epilogues)" % precision)
         roof = {"bound": "mfma", "kernel": kern,
                 "achieved": round(ach, 2), "peak": PEAK[precision], "unit": "TFLOP/s", "frac": round(ach / PEAK[precision], 4),

@@ -934,7 +934,11 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
 }
 __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, float* __restrict__ out,
-                                                             float* __restrict__ lse, int nheads, bf16* __restrict__ out3) {
+                                                             float* __restrict__ lse, int nheads, bf16* __restrict__ out3,
+                                                             bf16* __restrict__ q16, bf16* __restrict__ k16, bf16* __restrict__ v16,
+                                                             bf16* __restrict__ o16) {
+    // q16 / k16 / v16 / o16 (optional): the hi parts = the 16-bit roundings of q, k, v and the output, saved for a backward pass that
+    // runs on 16-bit operands ("fp16x3h"); `out` may then be null (the proj GEMM reads out3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Kh = reinterpret_cast<bf16*>(smem);
     bf16* Kl = reinterpret_cast<bf16*>(smem + ROW_IMG);
@@ -967,9 +971,17 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
             *reinterpret_cast<bf16x8*>(Kl + r0 * RLD + c * 8) = al;
             *reinterpret_cast<bf16x8*>(Kh + (r0 + 1) * RLD + c * 8) = bhh;
             *reinterpret_cast<bf16x8*>(Kl + (r0 + 1) * RLD + c * 8) = bl;
+            if (k16) {
+                if (r0 < NT) *reinterpret_cast<bf16x8*>(k16 + ((size_t)bh * NT + r0) * HD + c * 8) = ah;
+                if (r0 + 1 < NT) *reinterpret_cast<bf16x8*>(k16 + ((size_t)bh * NT + r0 + 1) * HD + c * 8) = bhh;
+            }
             split8(va0, va1, ah, al); split8(vb0, vb1, bhh, bl);
             if (r0 >= NT) { ah = zero8(); al = zero8(); }
             if (r0 + 1 >= NT) { bhh = zero8(); bl = zero8(); }
+            if (v16) {
+                if (r0 < NT) *reinterpret_cast<bf16x8*>(v16 + ((size_t)bh * NT + r0) * HD + c * 8) = ah;
+                if (r0 + 1 < NT) *reinterpret_cast<bf16x8*>(v16 + ((size_t)bh * NT + r0 + 1) * HD + c * 8) = bhh;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 bf16x2 ph = {ah[i], bhh[i]}, pl = {al[i], bl[i]};
@@ -983,6 +995,7 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
         for (int ks = 0; ks < 4; ++ks) {
             const float* qp = q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8;
             split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[ks], ql[ks]);
+            if (q16 && qrow < NT) *reinterpret_cast<bf16x8*>(q16 + ((size_t)bh * NT + qrow) * HD + ks * 16 + hi * 8) = qh[ks];
         }
         __syncthreads();
         f32x16 st[7];
@@ -1054,7 +1067,8 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
         if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = m + logf(sum);
         if (qrow < NT) {
             const float inv = 1.0f / sum;
-            float* op = out + ((size_t)b * NT + qrow) * D + h * HD;
+            float* op = out ? out + ((size_t)b * NT + qrow) * D + h * HD : nullptr;
+            bf16* op16 = o16 ? o16 + ((size_t)b * NT + qrow) * D + h * HD : nullptr;
             bf16* op3 = out3 ? out3 + ((size_t)b * NT + qrow) * (SPLIT_A * D) + h * HD : nullptr;   // + the split operand of the proj GEMM
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -1062,7 +1076,8 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
                 for (int g = 0; g < 4; ++g) {
                     const int d = dt * 32 + 8 * g + 4 * hi;
                     const float o0 = o[dt][4 * g] * inv, o1 = o[dt][4 * g + 1] * inv, o2 = o[dt][4 * g + 2] * inv, o3 = o[dt][4 * g + 3] * inv;
-                    store4(op + d, o0, o1, o2, o3);
+                    if (op) store4(op + d, o0, o1, o2, o3);
+                    if (op16) store4(op16 + d, o0, o1, o2, o3);
                     if (op3) store4_split3(op3 + d, D, o0, o1, o2, o3);
                 }
         }
@@ -1357,9 +1372,11 @@ static int g_attn_f32_split = 0;   // process-wide: the split forward kernel for
 void set_attn_f32_split(int on) { g_attn_f32_split = on; }
 
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
-                    hipStream_t s, int split16, void* out3) {
+                    hipStream_t s, int split16, void* out3, const AttnSave16* save16) {
     const int grid = batch * NH;
     if (dbg_skip(2)) return 0;
+    if ((save16 || !out) && !(precision == 0 && (split16 || g_attn_f32_split))) { set_error("attention forward: 16-bit copies / no fp32 output need the split kernel"); return -1; }
+    if (!out && !out3) { set_error("attention forward: no output"); return -1; }
     if (precision == 0 && (split16 || g_attn_f32_split)) {
         const size_t lds = 2 * ROW_IMG + 2 * TR_IMG;
         static bool done[64] = {};
@@ -1367,7 +1384,8 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (!done[dev & 63]) { if (set_lds((const void*)attn_fwd_split_kernel, lds)) return -2; done[dev & 63] = true; }
         hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const float*)q, (const float*)k,
-                           (const float*)v, (float*)out, lse, grid, (bf16*)out3);
+                           (const float*)v, (float*)out, lse, grid, (bf16*)out3, save16 ? (bf16*)save16->q : nullptr, save16 ? (bf16*)save16->k : nullptr,
+                           save16 ? (bf16*)save16->v : nullptr, save16 ? (bf16*)save16->o : nullptr);
     } else if (precision == 0) {
         if (out3) { set_error("attention forward: split output without the split kernel"); return -1; }
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);

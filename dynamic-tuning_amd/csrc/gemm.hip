@@ -93,9 +93,10 @@ struct EpiQKV {
     }
 };
 
-template <class AT>
+// OT: type of the optional operand copy (the 16-bit type in the fp32 split form whose backward runs on 16-bit operands: GemmArgs::save16)
+template <class AT, class OT = AT>
 struct EpiBiasResid {
-    const float* bias; const float* resid; float* out; AT* out_at; int ld;
+    const float* bias; const float* resid; float* out; OT* out_at; int ld;
     typedef Bias4 Col; typedef Raw4<float> Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(resid + (size_t)row * ld + col); }
@@ -110,9 +111,9 @@ struct EpiBiasResid {
     }
 };
 
-template <class AT, bool HAS_GP>
+template <class AT, bool HAS_GP, class GT = AT>   // GT: type gelu'(z) is saved in (GemmArgs::save16: 16 bits under fp32 arithmetic)
 struct EpiFc1 {
-    const float* bias; AT* h; AT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
+    const float* bias; AT* h; GT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
     bf16* h3;   // split fp32 form: h goes out as the 16-bit hi / hi / lo operand of the fc2 GEMM ([rows, 3 ld]) instead of as fp32
     typedef Bias4 Col; typedef NoCtx Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
@@ -150,9 +151,9 @@ struct EpiFc1 {
 // `resid` is the residual the row is added to (x itself for the in-place form; the block's `u` when the adapter's
 // up-projection rides along as an extra k-tile of the contraction (CatArgs): x = u + (h W2^T + b2) + (d_act (s Wup)^T + s b_up)
 // is then ONE read of u and ONE write of x instead of two fp32 read-modify-write passes over [M,768]).
-template <class AT, bool PLAIN>
+template <class AT, bool PLAIN, class HT = AT>   // HT: type the MLP output is saved in for the gate gradient (GemmArgs::save16)
 struct EpiFc2 {
-    const float* bias; float* x; const int* row_map; const float* row_mask; AT* h_out;
+    const float* bias; float* x; const int* row_map; const float* row_mask; HT* h_out;
     const float* resid; const float* bias2; float scale2;
     // b: what is added to the accumulator for x (fc2 bias + s * up-projection bias); hb: the same for the saved MLP output h_out
     // (fc2 bias only: with the up-projection riding on the contraction h_out = mlp(x) + s up_nobias(d_act), and tok_bwd takes
@@ -270,14 +271,14 @@ struct EpiBiasAT {
     }
 };
 
-template <class AT>
+template <class AT, class ST = AT>   // ST: type of the second copy (GemmArgs::save16: the 16-bit d_act the 16-bit backward reads)
 struct EpiAdDown {
     const float* bias;  // padded to RP
     AT* out;            // [M, RP]
     const uint8_t* keep; int r; float inv_keep; float drop_p; uint64_t seed, subseq;
     const int* row_map;  // token row of compact row `row` (mask / RNG are indexed by token), or null
     const uint64_t* seed_dev;   // overrides `seed` when set (captured graphs draw fresh noise per replay)
-    AT* out_s; float s_out;     // optional second copy s_out * result: the A2 operand of the fc2 + up-projection contraction (the adapter
+    ST* out_s; float s_out;     // optional second copy s_out * result: the A2 operand of the fc2 + up-projection contraction (the adapter
                                 // scale goes on the O(1) activations, not on the possibly tiny up-projection weights: fp16 subnormals)
     typedef Bias4 Col;
     struct Pre { int trow; };
@@ -901,8 +902,10 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_QKV:
             return run<AT, SPLIT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
         case EPI_BIAS_RESID:
+            if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N}, s); }
             return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1:
+            if constexpr (SPLIT) { if (a.save16 && a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, bf16>{a.bias, (AT*)a.out_at, (bf16*)a.out_at2, a.N, (bf16*)a.out3}, s); }
             if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3}, s);
             return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3}, s);
         case EPI_FC2: {
@@ -917,6 +920,12 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
                     return -1;
                 }
             }
+            if constexpr (SPLIT) {
+                if (a.save16 && a.h_out) {
+                    if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true, bf16>{a.bias, a.out_f32, nullptr, nullptr, (bf16*)a.h_out, resid, nullptr, 0.f}, s);
+                    return run<AT, SPLIT>(a, EpiFc2<AT, false, bf16>{a.bias, a.out_f32, a.row_map, a.row_mask, (bf16*)a.h_out, resid, nullptr, 0.f}, s);
+                }
+            }
             if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, nullptr, 0.f}, s);
             return run<AT, SPLIT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
         }
@@ -926,6 +935,9 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_STORE_F32: return run<AT, SPLIT>(a, EpiStoreF32{a.out_f32, a.N, a.accumulate, a.scale}, s);
         case EPI_STORE_AT: return run<AT, SPLIT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
+            if constexpr (!SPLIT && sizeof(AT) == 4) {
+                if (a.save16) return run<AT, SPLIT>(a, EpiAdDown<AT, bf16>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (bf16*)a.out_at2, a.scale}, s);
+            }
             return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (AT*)a.out_at2, a.scale}, s);
         case EPI_AD_UP:
             if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr}, s);

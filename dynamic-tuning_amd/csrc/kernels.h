@@ -50,6 +50,9 @@ struct GemmArgs {
     bool a3_mapped = false;  // ... one split row per SOURCE row: the GEMM gathers through a_map (the pre-pass compacts instead)
     // FC1 / GELU_BWD in the split form: the result also (instead of out_at) goes out as the split A operand of the NEXT GEMM
     void* out3 = nullptr; float out3_scale = 1.f; bool out3_hi_only = false;   // hi_only: the next GEMM contracts the hi part alone
+    // fp32 mode whose backward runs on 16-bit operands ("fp16x3h"): the outputs that exist only for the backward pass -- BIAS_RESID's
+    // out_at (copy of u), FC1's out_at2 (gelu'), FC2's h_out, AD_DOWN's out_at2 (copy of d_act) -- are of the 16-bit operand type
+    bool save16 = false;
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -86,8 +89,10 @@ int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int
 // attention (N = 197, d = 64, 12 heads); q pre-scaled by 1/8 in the QKV epilogue
 // ------------------------------------------------------------------------------------------
 // q,k,v: [B*12][197][64] AT ; out: [B*197][768] AT ; lse: [B*12][197] f32
+// 16-bit copies of q / k / v (same layout) and of the output [B*197][768] written by the split forward kernel for a 16-bit backward
+struct AttnSave16 { void* q = nullptr; void* k = nullptr; void* v = nullptr; void* o = nullptr; };
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
-                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr);   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
+                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr, const AttnSave16* save16 = nullptr);   // out may be null when out3 is given   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
 void set_attn_f32_split(int on);   // process-wide version of split16 (unit entries)
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,

@@ -101,6 +101,10 @@ struct LayerW {  // frozen, library-owned
     void *proj_wp = nullptr, *proj_wTp = nullptr, *qkv_wTp = nullptr, *fc1_wTp = nullptr;
     // fp32 mode: [N, 2K] 16-bit [hi | lo] images of the eight matrices (DYT_OPT_F32_SPLIT16, launch_split3_w)
     void *qkv_w3 = nullptr, *qkv_wT3 = nullptr, *proj_w3 = nullptr, *proj_wT3 = nullptr, *fc1_w3 = nullptr, *fc1_wT3 = nullptr, *fc2_w3 = nullptr, *fc2_wT3 = nullptr;
+    // fp32 mode with a 16-bit backward ("fp16x3h", dyt_ctx::bwd16): the transposed matrices the dgrad GEMMs multiply by, in the 16-bit
+    // operand type, plain [in,out] and in MFMA fragment order (what the 16-bit mode keeps as *_wT / *_wTp)
+    void *qkv_wT16 = nullptr, *qkv_wTp16 = nullptr, *proj_wT16 = nullptr, *proj_wTp16 = nullptr, *fc1_wT16 = nullptr, *fc1_wTp16 = nullptr,
+         *fc2_wT16 = nullptr, *fc2_wTp16 = nullptr;
 };
 struct LayerS {  // saved activations of one pass
     float2 *st1, *st2;
@@ -109,6 +113,10 @@ struct LayerS {  // saved activations of one pass
     void* h;
     int *keep_local, *offsets, *total, *row_src, *dst_of;
     bool h_has_adapter = false;   // h = mlp(x) + s up(d_act) + s b_up (fc2 carried the up-projection, DYT_OPT_FC2_CAT)
+    // dyt_ctx::bwd16: what the backward pass reads, in the 16-bit operand type (written by the exact forward next to / instead of
+    // the fp32 tensors above: q16 / k16 / v16 / o16 by the split attention kernel, u16 by the proj epilogue, z16 = gelu'(z) by the
+    // fc1 epilogue, dact16 by the down-projection epilogue, h16 by the fc2 epilogue)
+    void *q16 = nullptr, *k16 = nullptr, *v16 = nullptr, *o16 = nullptr, *u16 = nullptr, *z16 = nullptr, *dact16 = nullptr, *h16 = nullptr;
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
@@ -117,6 +125,7 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
     void* g3 = nullptr;   // [M, 3*768]: the gradient stream as a split operand, written by ln_bwd (next block's GELU' dgrad) and tok_bwd (proj dgrad); attention output in the forward pass
     void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
+    void* dad16 = nullptr;   // dyt_ctx::bwd16: the adapter dgrad as a 16-bit [M,768] operand of tok_bwd (T.dad of the 16-bit modes)
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
     float *xf = nullptr, *P = nullptr, *o = nullptr, *y = nullptr, *qn = nullptr, *qhat = nullptr, *qs = nullptr, *st_q = nullptr;
@@ -138,11 +147,14 @@ struct Slot {
     std::vector<float*> xs;  // depth+1 residual-stream snapshots
     int* counts = nullptr;   // [depth*B]
     void* ucls_at = nullptr; // last block: AT(u[cls rows]) [B,768] (adapter-down operand, kept for its wgrad)
+    void* ucls16 = nullptr;  // dyt_ctx::bwd16: its 16-bit copy
+    void* u0_16_own = nullptr;   // block-0 u16 of this slot (slot 1 may alias slot 0's, like u0_own)
     float* gcls = nullptr;   // last block backward: gradient at the cls rows [B,768]
     float* cls_n = nullptr;
     float2* head_stats = nullptr;
     int batch = 0, flags = 0;
     bool valid = false;
+    bool saved16 = false;    // the saved pass holds the 16-bit tensors of a 16-bit backward (dyt_ctx::bwd16)
     const float* trainable = nullptr;  // flat trainable buffer the saved pass was computed with
 };
 struct ProfRec { int cat; double flops; hipEvent_t a, b; const int* m_dev; int M; };
@@ -153,6 +165,14 @@ struct dyt_ctx {
     size_t at;  // bytes per activation element
     char* arena = nullptr;
     size_t arena_size = 0, arena_used = 0;
+    // second arena, allocated when DYT_OPT_F32_SPLIT16 is first switched on: everything only the split forms of the fp32 mode use
+    // (the [hi | lo] weight images, the split operand scratch, the 16-bit tensors of a 16-bit backward) -- a plain fp32 context
+    // does not carry it
+    char* aux_arena = nullptr;
+    size_t aux_size = 0;
+    bool aux_bwd16 = false;     // the aux arena holds the bwd16 buffers
+    bool bwd16 = false;         // "fp16x3h": the fp16x3 forward, the backward on the 16-bit mode's operands and kernels (DYT_OPT_F32_SPLIT16 = 3)
+    void *ad_up_wT16 = nullptr, *ad_down_wT16 = nullptr, *ad_scratch16 = nullptr;   // bwd16: per-step 16-bit copies of the adapter matrices the dgrads read
     // frozen
     float *cls, *pos, *pe_b, *norm_w, *norm_b;
     void* pe_w;
@@ -229,7 +249,6 @@ static void layout(dyt_ctx* c, bool dry) {
     c->norm_w = carve<float>(c, D, dry);
     c->norm_b = carve<float>(c, D, dry);
     c->pe_w = carve_at(c, (size_t)D * D, dry);
-    if (c->prec == 0) c->pe_w3 = carve<uint16_t>(c, (size_t)3 * D * D, dry);
     c->W.resize(depth);
     for (size_t l = 0; l < depth; ++l) {
         LayerW& w = c->W[l];
@@ -246,11 +265,6 @@ static void layout(dyt_ctx* c, bool dry) {
             w.fc2_wTp = carve_at(c, (size_t)DM * D, dry);
             w.proj_wp = carve_at(c, (size_t)D * D, dry); w.proj_wTp = carve_at(c, (size_t)D * D, dry);
             w.qkv_wTp = carve_at(c, (size_t)3 * D * D, dry); w.fc1_wTp = carve_at(c, (size_t)DM * D, dry);
-        } else {
-            w.qkv_w3 = carve<uint16_t>(c, (size_t)3 * 3 * D * D, dry); w.qkv_wT3 = carve<uint16_t>(c, (size_t)3 * 3 * D * D, dry);
-            w.proj_w3 = carve<uint16_t>(c, (size_t)3 * D * D, dry); w.proj_wT3 = carve<uint16_t>(c, (size_t)3 * D * D, dry);
-            w.fc1_w3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry); w.fc1_wT3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
-            w.fc2_w3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry); w.fc2_wT3 = carve<uint16_t>(c, (size_t)3 * DM * D, dry);
         }
     }
     c->ad_down_w = carve_at(c, depth * RP * D, dry);
@@ -316,11 +330,6 @@ static void layout(dyt_ctx* c, bool dry) {
         T.du_at = carve_at(c, M * D, dry);
         T.dad = c->prec != DYT_PREC_FP32 ? carve_at(c, M * D, dry) : nullptr;
         T.dact_s = c->prec != DYT_PREC_FP32 ? carve_at(c, M * RP, dry) : nullptr;
-        T.a3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
-        T.xn3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
-        T.g3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * D, dry) : nullptr;
-        T.h3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 3 * DM, dry) : nullptr;
-        T.dqkv3 = c->prec == DYT_PREC_FP32 ? carve<uint16_t>(c, M * 9 * D, dry) : nullptr;
         T.dO = carve_at(c, M * D, dry);
         T.dqkv = carve_at(c, M * 3 * D, dry);
         T.dA2 = carve_at(c, M * D, dry);
@@ -348,6 +357,76 @@ static void layout(dyt_ctx* c, bool dry) {
     c->dtok = carve<float>(c, 4, dry);
     c->loss_part = carve<float>(c, 4 * B, dry);
     c->losses = carve<float>(c, 8, dry);
+}
+
+// The aux arena (fp32 contexts, allocated by DYT_OPT_F32_SPLIT16): [hi | lo] images of the frozen matrices ([N, SPLIT_A * K] 16-bit),
+// the split A-operand scratch of a pass ([M, SPLIT_A * K]) and -- bwd16 -- the 16-bit tensors a 16-bit backward pass reads.
+// Carved with the main arena's helpers (the caller swaps the arena fields around the call).
+static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
+    const dyt_config& cf = c->cfg;
+    const size_t B = cf.max_batch, M = B * NT, depth = cf.depth, SA = SPLIT_A;
+    c->arena_used = 0;
+    c->pe_w3 = carve<uint16_t>(c, SA * D * D, dry);
+    for (size_t l = 0; l < depth; ++l) {
+        LayerW& w = c->W[l];
+        w.qkv_w3 = carve<uint16_t>(c, SA * 3 * D * D, dry); w.qkv_wT3 = carve<uint16_t>(c, SA * 3 * D * D, dry);
+        w.proj_w3 = carve<uint16_t>(c, SA * D * D, dry); w.proj_wT3 = carve<uint16_t>(c, SA * D * D, dry);
+        w.fc1_w3 = carve<uint16_t>(c, SA * DM * D, dry); w.fc1_wT3 = carve<uint16_t>(c, SA * DM * D, dry);
+        w.fc2_w3 = carve<uint16_t>(c, SA * DM * D, dry); w.fc2_wT3 = carve<uint16_t>(c, SA * DM * D, dry);
+        if (bwd16) {
+            w.qkv_wT16 = carve<uint16_t>(c, (size_t)3 * D * D, dry); w.qkv_wTp16 = carve<uint16_t>(c, (size_t)3 * D * D, dry);
+            w.proj_wT16 = carve<uint16_t>(c, (size_t)D * D, dry); w.proj_wTp16 = carve<uint16_t>(c, (size_t)D * D, dry);
+            w.fc1_wT16 = carve<uint16_t>(c, (size_t)DM * D, dry); w.fc1_wTp16 = carve<uint16_t>(c, (size_t)DM * D, dry);
+            w.fc2_wT16 = carve<uint16_t>(c, (size_t)DM * D, dry); w.fc2_wTp16 = carve<uint16_t>(c, (size_t)DM * D, dry);
+        }
+    }
+    if (bwd16) {
+        c->ad_up_wT16 = carve<uint16_t>(c, depth * RP * D, dry);
+        c->ad_down_wT16 = carve<uint16_t>(c, depth * RP * D, dry);
+        c->ad_scratch16 = carve<uint16_t>(c, 2 * depth * RP * D, dry);   // the two layouts of prep_adapters_kernel the backward does not read
+    }
+    for (int sl = 0; sl < cf.slots; ++sl) {
+        Slot& S = c->slots[sl];
+        Transients& T = S.T;
+        T.a3 = carve<uint16_t>(c, M * SA * DM, dry);
+        T.xn3 = carve<uint16_t>(c, M * SA * D, dry);
+        T.g3 = carve<uint16_t>(c, M * SA * D, dry);
+        T.h3 = carve<uint16_t>(c, M * SA * DM, dry);
+        T.dqkv3 = carve<uint16_t>(c, M * SA * 3 * D, dry);
+        if (!bwd16) continue;
+        T.dad16 = carve<uint16_t>(c, M * D, dry);
+        S.ucls16 = carve<uint16_t>(c, B * D, dry);
+        for (size_t l = 0; l < depth; ++l) {
+            LayerS& L = S.L[l];
+            L.q16 = carve<uint16_t>(c, M * D, dry); L.k16 = carve<uint16_t>(c, M * D, dry); L.v16 = carve<uint16_t>(c, M * D, dry);
+            L.o16 = carve<uint16_t>(c, M * D, dry); L.u16 = carve<uint16_t>(c, M * D, dry); L.h16 = carve<uint16_t>(c, M * D, dry);
+            L.z16 = carve<uint16_t>(c, M * DM, dry); L.dact16 = carve<uint16_t>(c, M * RP, dry);
+        }
+        if (!dry) S.u0_16_own = S.L[0].u16;
+    }
+}
+// (re)allocates the aux arena; with_bwd16: including the 16-bit backward's buffers
+static int alloc_aux(dyt_ctx* c, bool with_bwd16) {
+    if (c->aux_arena && (c->aux_bwd16 || !with_bwd16)) return 0;
+    DYT_HIP_CHECK(hipDeviceSynchronize());
+    if (c->aux_arena) { DYT_HIP_CHECK(hipFree(c->aux_arena)); c->aux_arena = nullptr; }
+    char* main_base = c->arena; const size_t main_used = c->arena_used;
+    layout_aux(c, true, with_bwd16);
+    c->aux_size = c->arena_used;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->aux_arena), c->aux_size);
+    if (e == hipSuccess) e = hipMemset(c->aux_arena, 0, c->aux_size);
+    if (e != hipSuccess) {
+        set_error("aux arena: hipMalloc / hipMemset(%zu bytes) failed: %s", c->aux_size, hipGetErrorString(e));
+        if (c->aux_arena) { (void)hipFree(c->aux_arena); c->aux_arena = nullptr; }
+        c->arena = main_base; c->arena_used = main_used;
+        return DYT_ERR_HIP;
+    }
+    c->arena = c->aux_arena;
+    layout_aux(c, false, with_bwd16);
+    c->arena = main_base; c->arena_used = main_used;
+    c->aux_bwd16 = with_bwd16;
+    DYT_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
 }
 
 static void trainable_layout(dyt_ctx* c) {
@@ -457,13 +536,14 @@ extern "C" int dyt_ctx_destroy(dyt_ctx* c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side) hipStreamDestroy(c->side);
     if (c->arena) hipFree(c->arena);
+    if (c->aux_arena) hipFree(c->aux_arena);
     delete c;
     return DYT_OK;
 }
 
 extern "C" int dyt_ctx_bytes(const dyt_ctx* c, int64_t* bytes) {
     if (!c || !bytes) { set_error("null argument"); return DYT_ERR_ARG; }
-    *bytes = (int64_t)c->arena_size;
+    *bytes = (int64_t)(c->arena_size + c->aux_size);
     return DYT_OK;
 }
 
@@ -529,6 +609,20 @@ static int refresh_split(dyt_ctx* c, int layer, hipStream_t s) {
     if (!rc) rc = launch_split3_w((const float*)w.fc2_wT, w.fc2_wT3, DM, D, s);
     return rc;
 }
+// bwd16: the 16-bit transposed copies (plain + MFMA fragment order) of one layer's matrices, from the fp32 transposed copies
+static int refresh_bwd16(dyt_ctx* c, int layer, hipStream_t s) {
+    if (c->prec != 0 || !c->bwd16 || layer < 0) return 0;
+    LayerW& w = c->W[layer];
+    struct M16 { const void* src; void* dst; void* dstp; int N, K; };
+    const M16 m[4] = {{w.qkv_wT, w.qkv_wT16, w.qkv_wTp16, D, 3 * D}, {w.proj_wT, w.proj_wT16, w.proj_wTp16, D, D},
+                      {w.fc1_wT, w.fc1_wT16, w.fc1_wTp16, D, DM}, {w.fc2_wT, w.fc2_wT16, w.fc2_wTp16, DM, D}};
+    for (const M16& x : m) {
+        int rc = launch_convert(1, (const float*)x.src, x.dst, (int64_t)x.N * x.K, s);
+        if (!rc) rc = launch_preshuffle_w(x.dst, x.dstp, x.N, x.K, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
 static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
     DYT_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
@@ -537,8 +631,10 @@ static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
 static int set_frozen_impl(dyt_ctx* c, int param, int layer, const float* src, void* stream);
 extern "C" int dyt_set_frozen(dyt_ctx* c, int param, int layer, const float* src, void* stream) {
     int rc = set_frozen_impl(c, param, layer, src, stream);
-    if (!rc && c->split16 && (param == DYT_P_PE_W || param == DYT_P_QKV_W || param == DYT_P_PROJ_W || param == DYT_P_FC1_W || param == DYT_P_FC2_W))
+    if (!rc && c->split16 && (param == DYT_P_PE_W || param == DYT_P_QKV_W || param == DYT_P_PROJ_W || param == DYT_P_FC1_W || param == DYT_P_FC2_W)) {
         rc = refresh_split(c, param == DYT_P_PE_W ? -1 : layer, static_cast<hipStream_t>(stream));
+        if (!rc && param != DYT_P_PE_W) rc = refresh_bwd16(c, layer, static_cast<hipStream_t>(stream));
+    }
     return rc;
 }
 static int set_frozen_impl(dyt_ctx* c, int param, int layer, const float* src, void* stream) {
@@ -636,13 +732,22 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
         case DYT_OPT_GRAD_SCALE_LOG2:   // 16-bit gradient operands carry 2^value (0 = none); fp32 mode ignores it
             if (value < 0 || value > 24) { set_error("grad scale log2 %d out of range 0..24", value); return DYT_ERR_ARG; }
-            c->gs = c->prec == DYT_PREC_FP32 ? 1.0f : (float)(1u << value);
+            c->gs = (c->prec == DYT_PREC_FP32 && !c->bwd16) ? 1.0f : (float)(1u << value);
             return DYT_OK;
         case DYT_OPT_FC2_CAT: c->fc2_cat = value != 0; return DYT_OK;
         case DYT_OPT_F32_SPLIT16: {   // fp32 mode only: the frozen-weight GEMMs as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
             if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
-            if (value < 0 || value > 2) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part)", value); return DYT_ERR_ARG; }
+            if (value < 0 || value > 3) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part, 3 backward on 16-bit operands)", value); return DYT_ERR_ARG; }
+            if (value != 0) { int rc = alloc_aux(c, value == 3); if (rc) return rc; }
             c->split16 = value != 0;
+            // 3 ("fp16x3h"): the forward as in 1 / 2 bit for bit, with what the backward needs saved in the 16-bit operand type (the hi
+            // parts the forward computes anyway; ReLU / dropout / gate masks are the exact forward's), and the backward pass on the
+            // 16-bit mode's data flow and kernels (fused attention backward, pre-shuffled-weight dgrads, 16-bit weight gradients)
+            c->bwd16 = value == 3;
+            c->gs = 1.0f;
+#ifdef DYT_FP16
+            if (c->bwd16) c->gs = 4096.0f;   // the fixed loss scale of the fp16 mode (dyt_ctx::gs)
+#endif
             // 2 ("fp16x3f"): the forward (logits, gate decisions, losses, saved activations) as in 1; the gradient GEMMs contract
             // dY_hi * W_hi alone and the attention backward's dP / dQ / dK / dV take the hi * hi product (its score recomputation keeps three)
             c->split_bwd_parts = c->split_bwd_attn_parts = value == 2 ? 1 : 3;
@@ -657,7 +762,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             if (c->split16) {   // parts of the weights uploaded so far (later dyt_set_frozen calls refresh theirs)
                 DYT_HIP_CHECK(hipDeviceSynchronize());   // uploads may be in flight on the caller's streams
                 int rc = refresh_split(c, -1, nullptr);
-                for (int l = 0; l < c->cfg.depth && !rc; ++l) rc = refresh_split(c, l, nullptr);
+                for (int l = 0; l < c->cfg.depth && !rc; ++l) { rc = refresh_split(c, l, nullptr); if (!rc) rc = refresh_bwd16(c, l, nullptr); }
                 if (rc) return rc;
                 DYT_HIP_CHECK(hipDeviceSynchronize());
             }
@@ -717,11 +822,17 @@ extern "C" int dyt_profile_read(dyt_ctx* c, int category, double* ms, int64_t* l
 // ------------------------------------------------------------------------------------------
 static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     const dim3 grid((RP * D + 255) / 256, c->cfg.depth);
-    if (c->prec == 0)
+    if (c->prec == 0) {
         hipLaunchKernelGGL(prep_adapters_kernel<float>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (float*)c->ad_down_w, (float*)c->ad_down_wT, (float*)c->ad_up_w,
                            (float*)c->ad_up_wT, c->ad_down_b, (float*)nullptr, 0.f);
-    else
+        if (c->bwd16) {   // + the 16-bit transposes the 16-bit backward's adapter dgrads multiply by
+            bf16* scr = (bf16*)c->ad_scratch16;
+            hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
+                               c->off_uw, c->cfg.ffn_num, scr, (bf16*)c->ad_down_wT16, scr + (size_t)c->cfg.depth * RP * D,
+                               (bf16*)c->ad_up_wT16, c->ad_down_b, (bf16*)nullptr, 0.f);
+        }
+    } else
         hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (bf16*)c->ad_down_w, (bf16*)c->ad_down_wT, (bf16*)c->ad_up_w,
                            (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)nullptr, 0.f);
@@ -872,6 +983,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const uint64_t* seed_dev = (flags & DYT_F_DEVICE_SEED) ? c->seed_dev : nullptr;
+    const bool save16 = save && c->bwd16 && c->split16 && c->split_attn;   // "fp16x3h": what the backward reads is saved in the 16-bit operand type
     Slot& S = c->slots[slot];
     Transients& T = S.T;
     S.valid = false;
@@ -912,8 +1024,11 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 RUN_GEMM(EPI_QKV, a);
             }
             void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? T.g3 : nullptr;   // the split attention kernel also writes the proj GEMM's operand
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3));
-            if (c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate) {
+            // last block of a pass without a gate (teacher / complete model): the proj GEMM runs on the gathered cls rows of the fp32 output
+            const bool tail_proj = c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate;
+            const AttnSave16 sv16{L.q16, L.k16, L.v16, L.o16};   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, save16 ? &sv16 : nullptr));
+            if (tail_proj) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
                 GemmArgs a; a.A = L.attn_o; a.a_map = c->cls_rows; a.W = W.proj_w; a.M = B; a.N = D; a.K = D; a.bias = W.proj_b;
@@ -922,6 +1037,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             } else {
                 GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
                 a.out_f32 = L.u; a.out_at = P == 0 ? nullptr : L.u_at; SPLIT_F(a, W.proj_w3, 1);
+                if (save16) { a.out_at = L.u16; a.save16 = true; }
                 if (ao3) SPLIT_READY(a, ao3);
                 RUN_GEMM(EPI_BIAS_RESID, a);
             }
@@ -929,8 +1045,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         }
         const bool tail = c->cls_tail && l == depth - 1 && !tokens_out;  // only the cls rows of the last block reach the head
         const int Mr = tail ? B : M;                       // rows the adapter / MLP of this block run on
-        if (tail)   // LN2 of the cls rows + their AT copy (adapter operand); everything below works on B rows
+        if (tail) {  // LN2 of the cls rows + their AT copy (adapter operand); everything below works on B rows
             RUN(2, 0, launch_ln_cls(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, S.ucls_at, B, s));
+            if (save16) RUN(2, 0, launch_convert(1, (const float*)S.ucls_at, S.ucls16, (int64_t)B * D, s));
+        }
         // ---- adapter branch: x_out = u + scale * up(dropout(relu(down(u)))) -- independent of the
         //      gate / gather / fc1 chain below, so it runs on the pass's side stream until fc2 needs x_out
         // 16-bit modes: wherever the MLP output h is not needed on its own (teacher pass, cls tail, inference) the
@@ -952,6 +1070,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.row_map = tail ? c->cls_rows : nullptr;
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1); a.seed_dev = seed_dev;
             if (cat) { a.out_at2 = T.dact_s; a.scale = c->cfg.adapter_scale; }
+            if (save16) { a.out_at2 = L.dact16; a.scale = 1.0f; a.save16 = true; }
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
         GemmArgs up; up.A = L.d_act; up.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); up.M = Mr; up.N = D; up.K = RP;
@@ -989,6 +1108,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         {
             GemmArgs a; a.A = T.xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.bias = W.fc1_b;
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT_F(a, W.fc1_w3, 2);
+            if (save16) { a.out_at2 = L.z16; a.save16 = true; }
             if (!tail) SPLIT_READY(a, T.xn3);   // (the cls tail's LN2 rows come from ln_cls in fp32: pre-pass)
             if (c->split16) a.out3 = T.h3;
             RUN_GEMM(EPI_FC1, a);
@@ -1004,6 +1124,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.row_map = tail ? c->cls_rows : (dense ? nullptr : L.row_src);
             a.row_mask = (masked_dense && !tail) ? L.maskf : nullptr;   // the cls token is never gated
             a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
+            if (save16 && need_h) { a.h_out = L.h16; a.save16 = true; }
             SPLIT_F(a, W.fc2_w3, 3); SPLIT_READY(a, T.h3);
             if (cat) {
                 a.A2 = T.dact_s; a.W2 = at_off(c, c->ad_up_w, (size_t)l * RP * D);   // [s d_act | h] x [W_up | W2]^T
@@ -1022,7 +1143,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
                                   S.head_stats, logits, B, c->cfg.num_classes, s));
     }
-    S.batch = B; S.flags = flags; S.valid = save && !tokens_in && !tokens_out; S.trainable = trainable;   // token-level passes are forward only
+    S.batch = B; S.flags = flags; S.valid = save && !tokens_in && !tokens_out; S.trainable = trainable; S.saved16 = save16;   // token-level passes are forward only
     return DYT_OK;
 }
 
@@ -1032,7 +1153,7 @@ extern "C" int dyt_forward(dyt_ctx* c, int slot, const float* images, int batch,
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
     if (slot >= 0 && slot < c->cfg.slots) {  // a stand-alone pass owns its block-0 buffers
         Slot& S = c->slots[slot];
-        S.L[0].u = S.u0_own; S.L[0].u_at = S.u0_at_own;
+        S.L[0].u = S.u0_own; S.L[0].u_at = S.u0_at_own; S.L[0].u16 = S.u0_16_own;
     }
     return forward_impl(c, slot, images, batch, flags, trainable, g1, g2, keep_mask, seed, logits, token_select,
                         token_logits, true, static_cast<hipStream_t>(stream));
@@ -1181,7 +1302,13 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     Transients& T = S.T;
     if (!S.valid) { set_error("slot %d holds no saved forward (call dyt_forward with DYT_F_SAVE)", slot); return DYT_ERR_STATE; }
     if (!dlogits || !grad || !trainable) { set_error("null argument"); return DYT_ERR_ARG; }
-    const int P = c->prec, depth = c->cfg.depth, B = S.batch, M = B * NT, r = c->cfg.ffn_num;
+    // b16 ("fp16x3h"): the saved pass came from the exact (split fp32) forward, this backward runs in the 16-bit mode: P = 1, the
+    // 16-bit copies of the saved tensors and of the dgrad matrices, none of the split forms below
+    const bool b16 = S.saved16;
+    const int P = b16 ? 1 : c->prec, depth = c->cfg.depth, B = S.batch, M = B * NT, r = c->cfg.ffn_num;
+    const bool split16 = c->split16 && !b16;
+    const size_t atb = at_size(P);
+    auto at_offb = [atb](void* base, size_t elems) { return static_cast<void*>(static_cast<char*>(base) + elems * atb); };
     const int flags = S.flags;
     const bool training = flags & DYT_F_TRAINING, complete = flags & DYT_F_COMPLETE;
     // masked_dense: the student forward evaluated the MLP for every token and multiplied by the mask (the reference's
@@ -1214,13 +1341,21 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     ReduceQueue rq;   // adapter weight-gradient / gate-gradient reductions: queued per block, flushed where the gradients must be final
     bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
     bool g3_ready = false; // ... and (fp32 split form) T.g3 = g as the 16-bit split operand of this block's GELU' dgrad
-    const bool split_prod = c->split16 && c->split_prod;
+    const bool split_prod = split16 && c->split_prod;
     for (int l = depth - 1; l >= 0; --l) {
         const LayerW& W = c->W[l];
         LayerS& L = S.L[l];
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* gbase = grad + (int64_t)l * c->layer_stride;
         const bool first = l == 0;
+        // saved tensors / dgrad matrices in this backward's operand type
+        const void* Lh = b16 ? L.h16 : L.h; const void* Ldact = b16 ? L.dact16 : L.d_act; const void* Lz = b16 ? L.z16 : L.z;
+        const void* Luat = b16 ? L.u16 : L.u_at; const void* ucls = b16 ? S.ucls16 : S.ucls_at;
+        const void *fc2_wT = b16 ? W.fc2_wT16 : W.fc2_wT, *fc2_wTp = b16 ? W.fc2_wTp16 : W.fc2_wTp, *fc1_wT = b16 ? W.fc1_wT16 : W.fc1_wT,
+                   *fc1_wTp = b16 ? W.fc1_wTp16 : W.fc1_wTp, *proj_wT = b16 ? W.proj_wT16 : W.proj_wT, *proj_wTp = b16 ? W.proj_wTp16 : W.proj_wTp,
+                   *qkv_wT = b16 ? W.qkv_wT16 : W.qkv_wT, *qkv_wTp = b16 ? W.qkv_wTp16 : W.qkv_wTp;
+        void* ad_up_wT = b16 ? c->ad_up_wT16 : c->ad_up_wT; void* ad_down_wT = b16 ? c->ad_down_wT16 : c->ad_down_wT;
+        void* Tdad = b16 ? T.dad16 : T.dad;
 
         const bool tail = cls_tail && l == depth - 1;  // incoming gradient lives at the cls rows only (S.gcls)
         const int Mr = tail ? B : M;
@@ -1229,12 +1364,12 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         void* g_at = P == 0 ? nullptr : T.g_at;
         if (!prepped && (g_at || (student && !tail))) {
             BwdPrepArgs a;
-            a.g = gin; a.h = (student && !tail) ? L.h : nullptr; a.dst_of = (dense || tail || h_by_token) ? nullptr : L.dst_of;
+            a.g = gin; a.h = (student && !tail) ? Lh : nullptr; a.dst_of = (dense || tail || h_by_token) ? nullptr : L.dst_of;
             a.row_mask = nullptr;
             a.g_at = g_at; a.dH = nullptr; a.dmask = (student && !tail) ? T.dmask : nullptr;
             a.M = Mr; a.gs = gs;
             ISO(64, RUN(2, 0, launch_bwd_prep(P, a, s)););
-            if (g_at) CK("bwd_prep g_at", g_at, (size_t)Mr * D * c->at);
+            if (g_at) CK("bwd_prep g_at", g_at, (size_t)Mr * D * atb);
             if (a.dmask) CK("bwd_prep dmask", T.dmask, (size_t)Mr * 4);
         }
         const void* A_g = g_at ? g_at : (const void*)gin;
@@ -1242,24 +1377,24 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // ---- 2. adapter branch on the side stream: dgrad through up_proj, both wgrads, bias grads ----
         FORK(sb);
         {
-            GemmArgs a; a.A = A_g; a.W = at_off(c, c->ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
-            a.aux_at = L.d_act; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
-            POISON(64, T.ddz, (size_t)Mr * RP * c->at);
+            GemmArgs a; a.A = A_g; a.W = at_offb(ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
+            a.aux_at = Ldact; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
+            POISON(64, T.ddz, (size_t)Mr * RP * atb);
             ISO(16, RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s)););
-            CK("ad_dgrad_up ddz", T.ddz, (size_t)Mr * RP * c->at);
+            CK("ad_dgrad_up ddz", T.ddz, (size_t)Mr * RP * atb);
         }
         {   // both weight gradients (+ the two bias gradients as ones columns / rows) in one launch
             WgradArgs w[2];
             WgradArgs& a = w[0];
-            a.X = A_g; a.Y = L.d_act; a.M = Mr; a.r = r; a.partial = S.wg_part[l];
+            a.X = A_g; a.Y = Ldact; a.M = Mr; a.r = r; a.partial = S.wg_part[l];
             a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale * inv_gs;       // up_proj.weight [768, r]  (X = g_at carries gs)
             a.out_xsum = gbase + c->off_ub; a.alpha_x = scale * inv_gs;                      // up_proj.bias
             WgradArgs& b = w[1];
-            b.X = tail ? S.ucls_at : L.u_at; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = S.wg_part2[l];
+            b.X = tail ? ucls : Luat; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = S.wg_part2[l];
             b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = inv_gs;      // down_proj.weight [r, 768]  (Y = ddz carries gs)
             b.out_xsum = nullptr; b.alpha_x = 0.f;
             b.out_ysum = gbase + c->off_db; b.alpha_y = inv_gs;                     // down_proj.bias
-            if (c->split16 && c->split_bwd_parts == 1 && c->split_wgrad16) {   // "fp16x3f": gradient products one-part here too
+            if (split16 && c->split_bwd_parts == 1 && c->split_wgrad16) {   // "fp16x3f": gradient products one-part here too
                 a.half_products = b.half_products = true;
                 a.x_scale = c->split_gs;   // X = g (gradient-sized), Y = d_act
                 b.y_scale = c->split_gs;   // X = u, Y = ddz (gradient-sized)
@@ -1270,20 +1405,20 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // ---- 3. MLP dgrad (frozen weights) on the main stream: dZ = (dH W2) * gelu'(z) ; dA2 = dZ W1 ----
         if (!first) {
             {
-                GemmArgs a; a.A = A_g; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = L.z;
+                GemmArgs a; a.A = A_g; a.W = fc2_wT; a.Wp = fc2_wTp; a.M = Mr; a.N = DM; a.K = D; a.m_dev = kdev; a.aux_at = Lz;
                 a.a_map = (dense || tail) ? nullptr : L.row_src; a.out_at = T.dZ;   // kept rows of g (mask = 1 there) gathered by the loader
-                a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; SPLIT_G(a, W.fc2_wT3);
+                a.row_map = (h_by_token && !tail) ? L.row_src : nullptr; if (split16) SPLIT_G(a, W.fc2_wT3);
                 if (g3_ready && !tail) { SPLIT_READY(a, T.g3); a.a3_mapped = true; }   // ln_bwd of the block above wrote g as the split operand
-                if (c->split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; a.out3_hi_only = c->split_bwd_parts == 1; }   // dZ as the split operand of the fc1 dgrad
-                if (dense) POISON(128, T.dZ, (size_t)Mr * DM * c->at);
+                if (split16) { a.out3 = T.h3; a.out3_scale = c->split_gs; a.out3_hi_only = c->split_bwd_parts == 1; }   // dZ as the split operand of the fc1 dgrad
+                if (dense) POISON(128, T.dZ, (size_t)Mr * DM * atb);
                 ISO(8, RUN_GEMM(EPI_GELU_BWD, a););
-                CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * c->at);
+                CK("gelu_bwd dZ", T.dZ, (size_t)Mr * DM * atb);
             }
             {
-                GemmArgs a; a.A = T.dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2; SPLIT_G(a, W.fc1_wT3); SPLIT_READY(a, T.h3);
-                if (dense) POISON(2, T.dA2, (size_t)Mr * D * c->at);
+                GemmArgs a; a.A = T.dZ; a.W = fc1_wT; a.Wp = fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2; if (split16) { SPLIT_G(a, W.fc1_wT3); SPLIT_READY(a, T.h3); }
+                if (dense) POISON(2, T.dA2, (size_t)Mr * D * atb);
                 ISO(8, RUN_GEMM(EPI_STORE_AT, a););
-                CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * c->at);
+                CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * atb);
             }
         }
         JOIN(sb);
@@ -1291,10 +1426,10 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // bf16 mode: stored as a bf16 [M,768] operand that tok_bwd adds (half the bytes of the in-place update)
         const bool dad_at = P != 0 && !tail && !first;
         if (!first) {
-            GemmArgs a; a.A = T.ddz; a.W = at_off(c, c->ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
-            if (dad_at) { a.out_at = T.dad; POISON(4, T.dad, (size_t)Mr * D * c->at); ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
+            GemmArgs a; a.A = T.ddz; a.W = at_offb(ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
+            if (dad_at) { a.out_at = Tdad; POISON(4, Tdad, (size_t)Mr * D * atb); ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
             else { a.out_f32 = gin; a.accumulate = 1; a.scale = inv_gs; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
-            if (dad_at) CK("ad_dgrad_down dad", T.dad, (size_t)Mr * D * c->at);   // g <- g + ddz Wdown
+            if (dad_at) CK("ad_dgrad_down dad", Tdad, (size_t)Mr * D * atb);   // g <- g + ddz Wdown
         }
 
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
@@ -1304,10 +1439,10 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
             a.dmask = tail ? nullptr : T.dmask;
             a.g_cls = tail ? S.gcls : nullptr;
-            a.dad = dad_at ? T.dad : nullptr;
+            a.dad = dad_at ? Tdad : nullptr;
             a.gs = gs; a.inv_gs = inv_gs;
             if (L.h_has_adapter && student && !tail) {
-                a.cat_dact = L.d_act; a.cat_ddz = T.ddz; a.cat_bup = base + c->off_ub;
+                a.cat_dact = Ldact; a.cat_ddz = T.ddz; a.cat_bup = base + c->off_ub;
                 a.cat_scale = scale; a.cat_ddz_scale = 1.0f / (inv_keep * gs);
             }
             a.dtoken_select = dtoken_select ? dtoken_select + (size_t)l * NP : nullptr;
@@ -1316,14 +1451,14 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = S.tok_part[l]; a.M = M; a.write_du = !first;
             if (split_prod && !first) { a.du3 = T.g3; a.du3_scale = c->split_gs; a.du3_hi_only = c->split_bwd_parts == 1; }
             int nblk = 0;
-            if (a.du_at) POISON(8, T.du_at, (size_t)M * D * c->at);
+            if (a.du_at) POISON(8, T.du_at, (size_t)M * D * atb);
             ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s)););
             if (student && !dbg_skip(8)) { int _r = queue_tok_reduce(rq, S.tok_part[l], nblk, gbase + c->off_gw); if (_r) return _r; }
             if (a.write_du) CK("tok_bwd g", g, (size_t)M * D * 4);
             if (a.dmask) CK("tok_in dmask", T.dmask, (size_t)M * 4);          // what tok_bwd consumed (unchanged by it)
-            if (a.dA2) CK("tok_in dA2", T.dA2, (size_t)Mr * D * c->at);
-            if (a.dad) CK("tok_in dad", T.dad, (size_t)Mr * D * c->at);
-            if (a.du_at) CK("tok_bwd du_at", T.du_at, (size_t)M * D * c->at);
+            if (a.dA2) CK("tok_in dA2", T.dA2, (size_t)Mr * D * atb);
+            if (a.dad) CK("tok_in dad", Tdad, (size_t)Mr * D * atb);
+            if (a.du_at) CK("tok_bwd du_at", T.du_at, (size_t)M * D * atb);
             if (student) CK("tok_bwd gate grad", gbase + c->off_gw, (size_t)(D + 1) * 4);
         }
         if (l == split || first || dbg_ck_on()) RUN(2, 0, flush_reductions(rq, s));   // the gradients of blocks >= l are final after this
@@ -1336,32 +1471,32 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         if (first) break;
         // ---- 5. attention branch: proj dgrad, attention backward, qkv dgrad, LN1 backward ----
         {
-            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = W.proj_wT; a.Wp = W.proj_wTp; a.M = M; a.N = D; a.K = D;
-            a.out_at = T.dO; SPLIT_G(a, W.proj_wT3); if (split_prod) SPLIT_READY(a, T.g3);
-            POISON(16, T.dO, (size_t)M * D * c->at);
+            GemmArgs a; a.A = P == 0 ? (const void*)g : (const void*)T.du_at; a.W = proj_wT; a.Wp = proj_wTp; a.M = M; a.N = D; a.K = D;
+            a.out_at = T.dO; if (split16) SPLIT_G(a, W.proj_wT3); if (split_prod) SPLIT_READY(a, T.g3);
+            POISON(16, T.dO, (size_t)M * D * atb);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
-            CK("proj_dgrad dO", T.dO, (size_t)M * D * c->at);
+            CK("proj_dgrad dO", T.dO, (size_t)M * D * atb);
         }
-        POISON(32, T.dqkv, (size_t)M * 3 * D * c->at);
+        POISON(32, T.dqkv, (size_t)M * 3 * D * atb);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
-            launch_attn_bwd(P, L.q, L.k, L.v, L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
-                            c->split16 ? T.dqkv3 : nullptr, c->split_gs, c->split16 && c->split_attn, c->split_bwd_attn_parts, c->split_bwd_parts == 1)););   // teacher tail: du, hence dO, is zero off the cls rows
-        CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * c->at);
+            launch_attn_bwd(P, b16 ? L.q16 : L.q, b16 ? L.k16 : L.k, b16 ? L.v16 : L.v, b16 ? L.o16 : L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
+                            split16 ? T.dqkv3 : nullptr, c->split_gs, split16 && c->split_attn, c->split_bwd_attn_parts, c->split_bwd_parts == 1)););   // teacher tail: du, hence dO, is zero off the cls rows
+        CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * atb);
         {
-            GemmArgs a; a.A = T.dqkv; a.W = W.qkv_wT; a.Wp = W.qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3);
-            POISON(1, T.dxn, (size_t)M * D * c->at);
+            GemmArgs a; a.A = T.dqkv; a.W = qkv_wT; a.Wp = qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; if (split16) { SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3); }
+            POISON(1, T.dxn, (size_t)M * D * atb);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
-            CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * c->at);
+            CK("qkv_dgrad dxn", T.dxn, (size_t)M * D * atb);
         }
         {   // LN1 backward, fused with the next block's prep (AT copy of g, <g, h> for the gate gradient)
             const LayerS& Ln = S.L[l - 1];
-            if (g_at) POISON(256, g_at, (size_t)M * D * c->at);
-            ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? Ln.h : nullptr,
+            if (g_at) POISON(256, g_at, (size_t)M * D * atb);
+            ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? (b16 ? Ln.h16 : Ln.h) : nullptr,
                                     (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, gs, s,
                                     (split_prod && l > 1) ? T.g3 : nullptr, c->split_gs, c->split_bwd_parts == 1)););
             g3_ready = split_prod && l > 1;
             CK("ln_bwd g", g, (size_t)M * D * 4);
-            if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * c->at);
+            if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * atb);
             if (student) CK("ln_bwd dmask", T.dmask, (size_t)M * 4);
             prepped = true;
         }
@@ -1468,6 +1603,7 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
         S0.L[0].u = S0.u0_own; S0.L[0].u_at = S0.u0_at_own;
         S1.L[0].u = share ? S0.u0_own : S1.u0_own;
         S1.L[0].u_at = share ? S0.u0_at_own : S1.u0_at_own;
+        S0.L[0].u16 = S0.u0_16_own; S1.L[0].u16 = share ? S0.u0_16_own : S1.u0_16_own;
     }
     rc = forward_impl(c, 0, images, batch, fl, trainable, g1, g2, keep_mask, seed, ls, token_select, nullptr, false, s,
                       nullptr, share ? c->ev_b0 : nullptr, nullptr);

@@ -10,14 +10,14 @@ import ctypes
 import torch
 
 from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
-                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP32,
+                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
 
 
 def parse_precision(p):
-    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F):
+    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H):
         return p
     p = str(p).lower()
     if p in ("fp32", "float32", "exact"):
@@ -30,7 +30,9 @@ def parse_precision(p):
         return PREC_FP16X3
     if p in ("fp16x3f", "fp16x3-fwd", "split-fwd"):
         return PREC_FP16X3F
-    raise ValueError("precision must be 'fp32', 'fp16x3', 'fp16x3f', 'bf16' or 'fp16', got %r" % (p,))
+    if p in ("fp16x3h", "fp16x3-bwd16", "split-half"):
+        return PREC_FP16X3H
+    raise ValueError("precision must be 'fp32', 'fp16x3', 'fp16x3f', 'fp16x3h', 'bf16' or 'fp16', got %r" % (p,))
 
 
 class DyTEngine:
@@ -43,19 +45,21 @@ class DyTEngine:
         # "fp16" = the second build of the library (IEEE-half operands) in ITS 16-bit mode
         # "fp16x3" = that library's fp32 mode with the frozen-weight GEMMs as three IEEE-half products (DYT_OPT_F32_SPLIT16)
         # "fp16x3f" = the same with the gradient products as the hi * hi term alone (forward bit-identical to "fp16x3")
-        lib_prec = {PREC_FP16: PREC_BF16, PREC_FP16X3: PREC_FP32, PREC_FP16X3F: PREC_FP32}.get(self.precision, self.precision)
+        # "fp16x3h" = the same forward again, the backward pass on 16-bit operands with the fp16 mode's kernels
+        split = {PREC_FP16X3: 1, PREC_FP16X3F: 2, PREC_FP16X3H: 3}.get(self.precision, 0)
+        lib_prec = PREC_BF16 if self.precision == PREC_FP16 else (PREC_FP32 if split else self.precision)
         self.cfg = Config(int(num_classes), int(ffn_num), int(depth), lib_prec,
                           int(max_batch), int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
                           int(frames))
         self.frames = max(1, int(frames))   # > 1: video model, every batch is clips * frames images
-        self.L = lib(fp16=self.precision in (PREC_FP16, PREC_FP16X3, PREC_FP16X3F))
+        self.L = lib(fp16=self.precision == PREC_FP16 or split != 0)
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             self._ck(self.L.dyt_ctx_create(ctypes.byref(self.cfg), ctypes.byref(h)))
         self.h = h
-        if self.precision in (PREC_FP16X3, PREC_FP16X3F):
+        if split:
             with torch.cuda.device(self.device):
-                self._ck(self.L.dyt_ctx_set_option(self.h, OPT_F32_SPLIT16, 2 if self.precision == PREC_FP16X3F else 1))
+                self._ck(self.L.dyt_ctx_set_option(self.h, OPT_F32_SPLIT16, split))
         n = ctypes.c_int64()
         self._ck(self.L.dyt_trainable_numel(self.h, ctypes.byref(n)))
         self.n_train = n.value

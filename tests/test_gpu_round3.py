@@ -134,7 +134,7 @@ def test_fused_attention_backward_is_bitwise_the_two_kernel_form(B):
             assert torch.equal(r, res[0]), (B, fp16, int((r != res[0]).sum()))
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp16x3f"])
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16x3f", "fp16x3h"])
 @pytest.mark.parametrize("mode", ["masked", "compact"])
 def test_split_fp16x3_mode_meets_the_fp32_parity_bars(mode, prec):
     """precision "fp16x3" (DYT_OPT_F32_SPLIT16: the fp32 mode with every frozen-weight GEMM computed on the 16-bit matrix cores as
@@ -176,7 +176,7 @@ def test_split_fp16x3_mode_meets_the_fp32_parity_bars(mode, prec):
     # measured: 71 gradients <= 6e-6; down_proj of blocks 1, 2, 4 0.8-1.5e-4, each from ONE ReLU-mask flip (one row of the gradient
     # carries the whole error: tests/diag_grad_table.py).  fp16x3f: worst 6.3e-4 (gate of block 0), spread over all rows
     print("%s/%s worst gradient rel-L2 %.2e (%s)" % (prec, mode, worst, wname))
-    assert worst < (3e-4 if prec == "fp16x3" else 1.5e-3), (wname, worst)   # ~2x measured
+    assert worst < {"fp16x3": 3e-4, "fp16x3f": 1.5e-3, "fp16x3h": 2e-3}[prec], (wname, worst)   # ~2x measured
 
 
 @pytest.mark.parametrize("B", [16, 128])
@@ -186,7 +186,7 @@ def test_fp16x3f_forward_is_bitwise_the_fp16x3_forward(B):
     (at the 1e-4 level) and stay finite."""
     x, y = synth.make_batch(B, 100, seed=71)
     res = {}
-    for prec in ("fp16x3", "fp16x3f"):
+    for prec in ("fp16x3", "fp16x3f", "fp16x3h"):
         m, _ = _bench_model(prec, "compact", B, 0.85)
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
@@ -197,14 +197,16 @@ def test_fp16x3f_forward_is_bitwise_the_fp16x3_forward(B):
         res[prec] = (ls.clone(), lt.clone(), ts.clone(), losses.clone(), eng.grad.clone())
         del eng, m
         torch.cuda.empty_cache()
-    a, b = res["fp16x3"], res["fp16x3f"]
-    for i, name in enumerate(("student logits", "teacher logits", "token_select")):
-        assert torch.equal(a[i], b[i]), name
-    assert torch.equal(a[3][:5], b[3][:5]), (a[3], b[3])
-    assert torch.isfinite(b[4]).all()
-    rel = float((a[4] - b[4]).norm() / a[4].norm())
-    print("B=%d: fp16x3f vs fp16x3 flat gradient rel-L2 %.2e" % (B, rel))
-    assert 0.0 < rel < 2e-3, rel
+    a = res["fp16x3"]
+    for other in ("fp16x3f", "fp16x3h"):
+        b = res[other]
+        for i, name in enumerate(("student logits", "teacher logits", "token_select")):
+            assert torch.equal(a[i], b[i]), (other, name)
+        assert torch.equal(a[3][:5], b[3][:5]), (other, a[3], b[3])
+        assert torch.isfinite(b[4]).all()
+        rel = float((a[4] - b[4]).norm() / a[4].norm())
+        print("B=%d: %s vs fp16x3 flat gradient rel-L2 %.2e" % (B, other, rel))
+        assert 0.0 < rel < (2e-3 if other == "fp16x3f" else 4e-3), (other, rel)
 
 
 @pytest.mark.parametrize("B", [1, 3, 64])
