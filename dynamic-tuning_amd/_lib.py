@@ -21,6 +21,7 @@ PREC_FP32, PREC_BF16 = 0, 1
 PREC_FP16 = 2   # host-side name only: libdyt_hip_f16.so with its 16-bit mode (DYT_PREC_BF16 = 1 inside that library)
 PREC_FP16X3F = 4  # host-side name only: PREC_FP16X3 with the gradient products as the hi * hi term alone (DYT_OPT_F32_SPLIT16 = 2)
 PREC_FP16X3H = 5  # host-side name only: the PREC_FP16X3 forward bit for bit, the backward pass on 16-bit operands with the fp16 mode's kernels (DYT_OPT_F32_SPLIT16 = 3)
+PREC_FP16F8 = 6   # host-side name only: PREC_FP16X3H with the forward GEMMs' correction products on the fp8 matrix cores (DYT_OPT_F32_SPLIT16 = 4)
 PREC_FP16X3 = 3   # host-side name only: libdyt_hip_f16.so in its fp32 mode with DYT_OPT_F32_SPLIT16 (frozen-weight GEMMs as three IEEE-half products)
 F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED, F_TOKENS_IN, F_TOKENS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2, OPT_FC2_CAT, OPT_ATTN_BWD_FUSED, OPT_F32_SPLIT16 = 1, 2, 3, 4, 5, 6, 7, 8
@@ -116,6 +117,7 @@ SYMBOLS = {
     "dyt_debug_dispatch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dyt_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dyt_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dyt_linear_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dyt_adapter_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _u64, _i, _vp]),
     "dyt_adapter_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _u64, _i, _vp]),

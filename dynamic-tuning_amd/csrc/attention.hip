@@ -936,7 +936,7 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
                                                              const float* __restrict__ v, float* __restrict__ out,
                                                              float* __restrict__ lse, int nheads, bf16* __restrict__ out3,
                                                              bf16* __restrict__ q16, bf16* __restrict__ k16, bf16* __restrict__ v16,
-                                                             bf16* __restrict__ o16) {
+                                                             bf16* __restrict__ o16, int f8) {
     // q16 / k16 / v16 / o16 (optional): the hi parts = the 16-bit roundings of q, k, v and the output, saved for a backward pass that
     // runs on 16-bit operands ("fp16x3h"); `out` may then be null (the proj GEMM reads out3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
                     const float o0 = o[dt][4 * g] * inv, o1 = o[dt][4 * g + 1] * inv, o2 = o[dt][4 * g + 2] * inv, o3 = o[dt][4 * g + 3] * inv;
                     if (op) store4(op + d, o0, o1, o2, o3);
                     if (op16) store4(op16 + d, o0, o1, o2, o3);
-                    if (op3) store4_split3(op3 + d, D, o0, o1, o2, o3);
+                    if (op3) { if (f8) store4_split_f8(op3 - h * HD, D, h * HD + d, o0, o1, o2, o3); else store4_split3(op3 + d, D, o0, o1, o2, o3); }
                 }
         }
         __syncthreads();   // every wave is done with this head's images before they are overwritten
@@ -1372,7 +1372,7 @@ static int g_attn_f32_split = 0;   // process-wide: the split forward kernel for
 void set_attn_f32_split(int on) { g_attn_f32_split = on; }
 
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
-                    hipStream_t s, int split16, void* out3, const AttnSave16* save16) {
+                    hipStream_t s, int split16, void* out3, const AttnSave16* save16, int out3_f8) {
     const int grid = batch * NH;
     if (dbg_skip(2)) return 0;
     if ((save16 || !out) && !(precision == 0 && (split16 || g_attn_f32_split))) { set_error("attention forward: 16-bit copies / no fp32 output need the split kernel"); return -1; }
@@ -1385,7 +1385,7 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         if (!done[dev & 63]) { if (set_lds((const void*)attn_fwd_split_kernel, lds)) return -2; done[dev & 63] = true; }
         hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, lse, grid, (bf16*)out3, save16 ? (bf16*)save16->q : nullptr, save16 ? (bf16*)save16->k : nullptr,
-                           save16 ? (bf16*)save16->v : nullptr, save16 ? (bf16*)save16->o : nullptr);
+                           save16 ? (bf16*)save16->v : nullptr, save16 ? (bf16*)save16->o : nullptr, out3_f8);
     } else if (precision == 0) {
         if (out3) { set_error("attention forward: split output without the split kernel"); return -1; }
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);

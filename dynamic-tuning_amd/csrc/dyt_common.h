@@ -105,6 +105,35 @@ __device__ __forceinline__ void store4_split3(bf16* dst, int K, float a, float b
     const bf16x4 hi = {split2(a).hi, split2(b).hi, split2(c).hi, split2(d).hi};
     *reinterpret_cast<bf16x4*>(dst) = hi;
 }
+// ---- "fp16f8" form of a split operand: hi * hi on the f16 matrix cores, the two correction products hi * lo + lo * hi as fp8 (e4m3)
+// MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4: twice the f16 rate per k) -- they only need ~4 significant bits to keep the result at 2^-15.
+// Row image, 4K bytes like the [hi | lo] form:   A: [hi16 (K halfs) | e4m3(hi) (K bytes) | e4m3(lo * 2^12) (K bytes)]
+//                                                W: [hi16 (K halfs) | e4m3(lo * 2^(ew+11)) | e4m3(hi * 2^ew)]    ew: per-matrix exponent
+// so that the contraction simply continues along the row: k-tiles [0, K/64) are f16 tiles of 64, the next K/64 tiles are fp8 tiles of
+// 128 (A_hi8 x W_lo8, then A_lo8 x W_hi8), descaled by the MFMA's E8M0 scale operand (2^-(ew+11), 2^-(ew+12)).
+// lo = x - hi is taken in fp32 (exact); activation magnitudes up to 224 keep a full-precision lo part, beyond that it saturates (the
+// element then has plain fp16 accuracy); v_cvt_pk_fp8_f32 rounds to nearest even and returns NaN from 480 up, hence the clamp.
+constexpr float F8_LO_SCALE = 4096.0f;   // 2^12 on the activations' lo part
+constexpr int F8_LO_LOG2 = 12;
+__device__ __forceinline__ int pack4_e4m3(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return v;
+}
+// 4 consecutive fp32 values of an A operand row in that form; row = row base of the image, col = first of the 4 columns
+__device__ __forceinline__ void store4_split_f8(bf16* row, int K, int col, float a, float b, float c, float d) {
+    asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));   // see split2: one rounding of ONE value
+    const bf16 ha = (bf16)a, hb = (bf16)b, hc = (bf16)c, hd = (bf16)d;
+    const bf16x4 hi = {ha, hb, hc, hd};
+    *reinterpret_cast<bf16x4*>(row + col) = hi;
+    unsigned char* r8 = reinterpret_cast<unsigned char*>(row) + 2 * (size_t)K + col;
+    *reinterpret_cast<int*>(r8) = pack4_e4m3((float)ha, (float)hb, (float)hc, (float)hd);
+    *reinterpret_cast<int*>(r8 + K) = pack4_e4m3((a - (float)ha) * F8_LO_SCALE, (b - (float)hb) * F8_LO_SCALE, (c - (float)hc) * F8_LO_SCALE,
+                                                 (d - (float)hd) * F8_LO_SCALE);
+}
 __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
     float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;

@@ -115,6 +115,7 @@ template <class AT, bool HAS_GP, class GT = AT>   // GT: type gelu'(z) is saved 
 struct EpiFc1 {
     const float* bias; AT* h; GT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
     bf16* h3;   // split fp32 form: h goes out as the 16-bit hi / hi / lo operand of the fc2 GEMM ([rows, 3 ld]) instead of as fp32
+    int f8 = 0; // ... in the hi16 / fp8 form (store4_split_f8)
     typedef Bias4 Col; typedef NoCtx Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int, int) const { return {}; }
@@ -139,7 +140,11 @@ struct EpiFc1 {
             for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + c.b[i]);
         }
         if constexpr (sizeof(AT) == 4) {
-            if (h3) { store4_split3(h3 + (size_t)row * SPLIT_A * ld + col, ld, hv[0], hv[1], hv[2], hv[3]); return; }
+            if (h3) {
+                if (f8) store4_split_f8(h3 + (size_t)row * SPLIT_A * ld, ld, col, hv[0], hv[1], hv[2], hv[3]);
+                else store4_split3(h3 + (size_t)row * SPLIT_A * ld + col, ld, hv[0], hv[1], hv[2], hv[3]);
+                return;
+            }
         }
         store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
@@ -388,11 +393,17 @@ __device__ unsigned long long g_gemm_dbg[4];
 // gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
-struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; int a_ld; };   // a_ld: row stride of split operands when the contraction runs over fewer than three parts (0: K - a_fold * 64)
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; int a_ld; int f8_begin; const int* w_exp; };   // f8_begin / w_exp: F8 kernels -- first fp8 k-tile, device word with the weight image's exponent   // a_ld: row stride of split operands when the contraction runs over fewer than three parts (0: K - a_fold * 64)
 // a_fold: k-tiles of ONE part of split operands stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads A column tile kt - (kt >= a_fold ? a_fold : 0) and W column tile kt - (kt >= 2 a_fold ? 2 a_fold : 0), i.e. [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]; 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
 // One workgroup = one tile: `bid` of `nwg` logical workgroups that tile rows [m_begin, M).  A device function so that one launch
 // can hold workgroups of two tile shapes (gemm_bf16_rows_kernel below).
-template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT>
+// F8 ("fp16f8" form of the split contraction, dyt_common.h: store4_split_f8): both operand images are [hi16 | 2K bytes of fp8]; k-tiles
+// [0, f8_begin) are f16 tiles of 64, the tiles after them fp8 tiles of 128 (the same 128 B per row and stage, the same fragment reads),
+// multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 -- ONE instruction per fragment pair and k-tile instead of two, at the time of one
+// f16 MFMA per 64 k: the lane's 32 operand bytes are its two 16-B fragment chunks {g, 4 + g} of the row (the same k subset on both
+// sides, so the order inside the tile does not matter).  The E8M0 scale operand takes the images' powers of two back out:
+// 2^-(ew+11) for the A_hi8 x W_lo8 tiles (first half), 2^-(ew+12) for the A_lo8 x W_hi8 tiles.
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT, bool F8 = false>
 __device__ __forceinline__ void gemm_bf16_nt_tile(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, int m_begin, const Epi& epi, const CatArgs& cat, int bid, int nwg) {
@@ -404,6 +415,9 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // 1 KiB (8 rows x 128 B) per wave-instruction
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
     constexpr bool BOTH_KS = (TM + TN) * 2 * 4 <= 72;  // hold both k-substeps' fragments when registers allow
+    static_assert(!(F8 && CAT), "the fp8-correction form has no leading k-tile variant");
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v8i __attribute__((ext_vector_type(8)));
 
     const int Mv = m_dev ? min(*m_dev, M) : M;
     // XCD-aware block remap (bijective): consecutive logical tiles share an A row panel and
@@ -425,22 +439,58 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     const bf16* a_src[A_INSTR];
     const bf16* b_src[B_INSTR];
     const int fold = cat.a_fold, lda = cat.a_ld ? cat.a_ld : K - fold * BK;   // split A operand stored [hi | lo]: the hi part serves the first two thirds of the contraction
+    // F8 kernels: 32-bit byte offsets from the (uniform) operand bases instead of per-lane 64-bit pointers -- 8 VGPRs less where the
+    // accumulators and two fragment generations already fill the register file (operand images stay below 4 GB: M x 4K bytes)
+    unsigned a_o32[A_INSTR], b_o32[B_INSTR];
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lane_o32 = (unsigned)(lrow * lda + chunk * 8) * 2u;
 #pragma unroll
     for (int t = 0; t < A_INSTR; ++t) {
         const int row = (t * NW + wave) * 8 + lrow;
         int grow = min(m0 + row, Mv - 1);
         if (a_map) grow = a_map[grow];  // gathered A rows (compacted MLP backward)
         a_src[t] = A + (size_t)grow * lda + chunk * 8 - (CAT ? BK : 0);
+        a_o32[t] = (unsigned)(((size_t)grow * lda + chunk * 8) * 2);
     }
 #pragma unroll
     for (int t = 0; t < B_INSTR; ++t) {
         const int row = (t * NW + wave) * 8 + lrow;
         b_src[t] = W + (size_t)(n0 + row) * lda + chunk * 8 - (CAT ? BK : 0);   // split form: W stored [hi | lo] like A (same row stride)
+        b_o32[t] = (unsigned)(((size_t)(n0 + row) * lda + chunk * 8) * 2);
     }
     // one 1-KiB DMA piece (idx < A_INSTR: A rows, else W rows) -- issued interleaved with the MFMAs so the
     // in-order wave never sits behind a burst of LDS-DMA issues (each costs ~100+ cycles back-to-back)
     auto stage_one = [&](int buf, int kt, int idx) {
         char* base = smem + buf * STAGE;
+        if constexpr (F8) {   // rows are read straight through: tile kt = bytes [128 kt, 128 kt + 128) of the row image
+            if constexpr (!BOTH_KS) {
+                // 256x256 kernel: everything but the lane's place inside a piece (row lrow of 8, 16-B chunk) is wave-uniform and stays
+                // in scalar registers -- ONE vector register of addressing next to 128 accumulators and two fragment generations
+                // (per-lane row pointers spilled, and a spill reload inside the loop waits for vmcnt(0), i.e. for the DMA in flight).
+                // Hence no row gather and no clamp to the valid row count here: rows past it are read and never stored (the split
+                // operand images are padded to whole 256-row tiles; run_f8 sends gathered launches to the 128x128 kernel).
+                const bool isA = idx < A_INSTR;
+                const int piece = isA ? idx : idx - A_INSTR;
+                const size_t row0 = (size_t)((isA ? m0 : n0) + (piece * NW + wave_s) * 8);
+                const char* g = reinterpret_cast<const char*>(isA ? A : W) + (row0 * (size_t)lda) * 2 + (size_t)kt * 128;
+                unsigned o = lane_o32;
+                asm volatile("" : "+v"(o));   // keeps the zero-extension in this block: "SGPR base + 32-bit VGPR offset" form of the load
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + o),
+                                                 (__attribute__((address_space(3))) void*)(base + (isA ? 0 : A_BYTES) + (piece * NW + wave_s) * 1024), 16, 0, 0);
+                return;
+            }
+            const char* ga = reinterpret_cast<const char*>(A) + (size_t)kt * 128;
+            const char* gw = reinterpret_cast<const char*>(W) + (size_t)kt * 128;
+            unsigned o = idx < A_INSTR ? a_o32[idx] : b_o32[idx - A_INSTR];
+            asm volatile("" : "+v"(o));
+            if (idx < A_INSTR)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + o),
+                                                 (__attribute__((address_space(3))) void*)(base + (idx * NW + wave) * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + o),
+                                                 (__attribute__((address_space(3))) void*)(base + A_BYTES + ((idx - A_INSTR) * NW + wave) * 1024), 16, 0, 0);
+            return;
+        }
         if (idx < A_INSTR)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[idx] + (kt - (kt >= fold ? fold : 0)) * BK),
                                              (__attribute__((address_space(3))) void*)(base + (idx * NW + wave) * 1024),
@@ -452,6 +502,11 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     };
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
+        if constexpr (F8) {
+#pragma unroll
+            for (int t = 0; t < A_INSTR + B_INSTR; ++t) stage_one(buf, kt, t);
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < A_INSTR; ++t)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[t] + (kt - (kt >= fold ? fold : 0)) * BK),
@@ -500,7 +555,156 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
 
     const int nk = K / BK + (CAT ? 1 : 0);
     if (ABL == 9) t_loop0 = __builtin_readcyclecounter();
-    if constexpr (!BOTH_KS) {
+    // fp8 tiles: E8M0 scale operands of the two correction products (the W fragment is the MFMA's A operand: the whole factor goes there)
+    int f8_sc1 = 127, f8_sc2 = 127, f8_half = 0;
+    if constexpr (F8) {
+        const int ew = cat.w_exp ? *cat.w_exp : 0;
+        f8_sc1 = 127 - (ew + 11); f8_sc2 = 127 - (ew + F8_LO_LOG2);
+        f8_half = cat.f8_begin + (nk - cat.f8_begin) / 2;
+    }
+#define DYT_MFMA_F8(w8, a8, c, sc) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4((w8), (a8), (c), 0, 0, 0, (sc), 0, 127)
+#define DYT_LO4(x) __builtin_shufflevector((x), (x), 0, 1, 2, 3)
+#define DYT_HI4(x) __builtin_shufflevector((x), (x), 4, 5, 6, 7)
+#define DYT_CAT8(lo, hi) __builtin_shufflevector((lo), (hi), 0, 1, 2, 3, 4, 5, 6, 7)
+    if constexpr (!BOTH_KS && F8) {
+        // ---- the half-stage pipeline below with 8-register fragments: .lo = k-substep 0 (row chunk g of lane group g), .hi = k-substep 1
+        // (chunk 4 + g).  f16 tiles run exactly the plain schedule on the halves.  An fp8 tile needs BOTH halves per MFMA, so its 32
+        // MFMAs are split by ROW fragments instead: block 1 = rows 0..3 (while rows 4..7 of the tile are read), barrier, block 2 =
+        // rows 4..7, j-major (while rows 0..3 of the NEXT tile, then -- each after its last use -- its W fragments are read and the
+        // DMA of the tile after that goes out).  Same reads, DMA pieces and matrix-pipe cycles per k-tile as an f16 tile.
+        bf16x8 faA[TM], fwA[TN], faB[TM], fwB[TN];   // f16 tiles: the plain kernel's two fragment sets
+        constexpr int NDMA = A_INSTR + B_INSTR;
+        static_assert(TM == 8 && TN == 4 && NDMA == 8, "interleave pattern written for the 128x64 wave tile, 8 DMA pieces");
+#define DYT_LDS4(off) (*reinterpret_cast<const v4i*>(base + (off)))
+        stage_first();
+        stage(1, 1);
+        dma_wait_all();
+        __syncthreads();
+        {
+            const char* base = smem;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) faA[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + fslot0 * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fwA[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + fslot0 * 16);
+        }
+#define DYT_MMA(FW, FA)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)            \
+        acc[i][j] = DYT_MFMA_16x16x32(FW[j], FA[i], acc[i][j]);
+#define DYT_SG3R __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define DYT_SG2R __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define DYT_SGB /* per 8 MFMAs: M2 R M2 R M1 D M2 R M1 D */                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
+        const int n1 = cat.f8_begin;
+        for (int kt = 0; kt < n1; ++kt) {   // f16 tiles: the plain kernel's iteration (a tile kt + 1 always exists: the fp8 tiles follow)
+            {
+                const char* base = smem + (kt & 1) * STAGE;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) faB[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + fslot1 * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fwB[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + fslot1 * 16);
+            }
+            DYT_MMA(fwA, faA)
+            DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R DYT_SG3R
+            DYT_SG2R DYT_SG2R DYT_SG2R DYT_SG2R
+            __builtin_amdgcn_sched_barrier(0);
+            dma_wait_all();
+            __syncthreads();
+            // block B in issue order, fenced (next to the opaque staging offsets the group barriers no longer reproduce the plain
+            // kernel's interleave): per 8 MFMAs  M2 R M2 R M1 D M2 R M1 D
+            const int nxt = min(kt + 2, nk - 1);
+            {
+                const char* base = smem + ((kt + 1) & 1) * STAGE;
+                const int so = fslot0 * 16;
+#define DYT_RA(i) faA[i] = *reinterpret_cast<const bf16x8*>(base + a_off + (i) * 2048 + so);
+#define DYT_RW(j) fwA[j] = *reinterpret_cast<const bf16x8*>(base + b_off + (j) * 2048 + so);
+#define DYT_MB(i, j) acc[i][j] = DYT_MFMA_16x16x32(fwB[j], faB[i], acc[i][j]);
+#define DYT_FN __builtin_amdgcn_sched_barrier(0);
+#define DYT_GRP(g, R0, R1, R2)                                                                     \
+                DYT_MB(2 * g, 0) DYT_MB(2 * g, 1) R0 DYT_FN DYT_MB(2 * g, 2) DYT_MB(2 * g, 3) R1 DYT_FN \
+                DYT_MB(2 * g + 1, 0) stage_one(kt & 1, nxt, 2 * g); DYT_FN                               \
+                DYT_MB(2 * g + 1, 1) DYT_MB(2 * g + 1, 2) R2 DYT_FN DYT_MB(2 * g + 1, 3) stage_one(kt & 1, nxt, 2 * g + 1); DYT_FN
+                DYT_GRP(0, DYT_RA(0), DYT_RA(1), DYT_RA(2))
+                DYT_GRP(1, DYT_RA(3), DYT_RA(4), DYT_RA(5))
+                DYT_GRP(2, DYT_RA(6), DYT_RA(7), DYT_RW(0))
+                DYT_GRP(3, DYT_RW(1), DYT_RW(2), DYT_RW(3))
+#undef DYT_GRP
+#undef DYT_FN
+#undef DYT_MB
+#undef DYT_RA
+#undef DYT_RW
+            }
+        }
+#undef DYT_MMA
+        // fp8 tiles: 8-register fragments (.lo = the k-substep-0 chunk, .hi = the k-substep-1 chunk); they start with rows 0..3 and W of
+        // tile n1 (the f16 loop's last prefetch into its own set is not reused: one exposed LDS round trip per GEMM tile)
+        v8i fa[TM], fw[TN];
+        {
+            const char* base = smem + (n1 & 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = DYT_CAT8(DYT_LDS4(a_off + i * 2048 + fslot0 * 16), DYT_LDS4(a_off + i * 2048 + fslot1 * 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fw[j] = DYT_CAT8(DYT_LDS4(b_off + j * 2048 + fslot0 * 16), DYT_LDS4(b_off + j * 2048 + fslot1 * 16));
+        }
+        // The scheduler's group barriers do not place the scaled MFMAs (the schedule came out as all reads first, then the MFMAs, with
+        // ~250 spilled registers), so the fp8 blocks are written in issue order and fenced with sched_barrier(0) every four MFMAs.
+#define DYT_M8(i, j) acc[i][j] = DYT_MFMA_F8(fw[j], fa[i], acc[i][j], sc);
+#define DYT_FENCE __builtin_amdgcn_sched_barrier(0);
+#define DYT_RA8(i) fa[i] = DYT_CAT8(DYT_LDS4(a_off + (i) * 2048 + fslot0 * 16), DYT_LDS4(a_off + (i) * 2048 + fslot1 * 16));
+#define DYT_RW8(j) fw[j] = DYT_CAT8(DYT_LDS4(b_off + (j) * 2048 + fslot0 * 16), DYT_LDS4(b_off + (j) * 2048 + fslot1 * 16));
+        // block 1: rows 0..3 x all W fragments (16 MFMAs); both halves of rows 4..7 of the same tile are read meanwhile
+#define DYT_F8_BLOCK1(kt_)                                                        \
+        {                                                                         \
+            const char* base = smem + ((kt_) & 1) * STAGE;                        \
+            DYT_M8(0, 0) DYT_M8(0, 1) DYT_RA8(4) DYT_M8(0, 2) DYT_M8(0, 3) DYT_FENCE \
+            DYT_M8(1, 0) DYT_M8(1, 1) DYT_RA8(5) DYT_M8(1, 2) DYT_M8(1, 3) DYT_FENCE \
+            DYT_M8(2, 0) DYT_M8(2, 1) DYT_RA8(6) DYT_M8(2, 2) DYT_M8(2, 3) DYT_FENCE \
+            DYT_M8(3, 0) DYT_M8(3, 1) DYT_RA8(7) DYT_M8(3, 2) DYT_M8(3, 3) DYT_FENCE \
+        }
+        DYT_FENCE
+        for (int kt = n1; kt < nk - 1; ++kt) {
+            const int sc = kt < f8_half ? f8_sc1 : f8_sc2;
+            DYT_F8_BLOCK1(kt)
+            dma_wait_all();   // this wave's pieces of stage kt+1 have landed ...
+            __syncthreads();  // ... everywhere; every wave's reads of slot kt&1 have returned
+            // block 2: rows 4..7, j-major (16 MFMAs); rows 0..3 of tile kt+1, its W fragments (each after the four MFMAs that read
+            // the old one) and the 8 DMA pieces of stage kt+2 -> slot kt&1
+            const int nxt = min(kt + 2, nk - 1);
+            {
+                const char* base = smem + ((kt + 1) & 1) * STAGE;
+                DYT_M8(4, 0) DYT_M8(5, 0) DYT_RA8(0) stage_one(kt & 1, nxt, 0); DYT_FENCE
+                DYT_M8(6, 0) DYT_M8(7, 0) stage_one(kt & 1, nxt, 1); DYT_FENCE
+                DYT_M8(4, 1) DYT_M8(5, 1) DYT_RA8(1) stage_one(kt & 1, nxt, 2); DYT_FENCE
+                DYT_M8(6, 1) DYT_M8(7, 1) DYT_RW8(0) stage_one(kt & 1, nxt, 3); DYT_FENCE
+                DYT_M8(4, 2) DYT_M8(5, 2) DYT_RA8(2) stage_one(kt & 1, nxt, 4); DYT_FENCE
+                DYT_M8(6, 2) DYT_M8(7, 2) DYT_RW8(1) stage_one(kt & 1, nxt, 5); DYT_FENCE
+                DYT_M8(4, 3) DYT_M8(5, 3) DYT_RA8(3) stage_one(kt & 1, nxt, 6); DYT_FENCE
+                DYT_M8(6, 3) DYT_M8(7, 3) DYT_RW8(2) stage_one(kt & 1, nxt, 7); DYT_FENCE
+                DYT_RW8(3) DYT_FENCE
+            }
+        }
+        {   // last tile: nothing left to prefetch
+            const int kt = nk - 1;
+            const int sc = kt < f8_half ? f8_sc1 : f8_sc2;
+            DYT_F8_BLOCK1(kt)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 4; i < TM; ++i) acc[i][j] = DYT_MFMA_F8(fw[j], fa[i], acc[i][j], sc);
+        }
+#undef DYT_M8
+#undef DYT_FENCE
+#undef DYT_RA8
+#undef DYT_RW8
+#undef DYT_F8_BLOCK1
+#undef DYT_SG3R
+#undef DYT_SG2R
+#undef DYT_SGB
+#undef DYT_LDS4
+    } else if constexpr (!BOTH_KS) {
         // ---- big wave tiles (128x64 per wave): half-stage software pipeline.  Two fragment sets, one per
         // k-substep; every LDS fragment read is issued one MFMA block (32 MFMAs) ahead of its use, the
         // single barrier of a stage sits between the two MFMA blocks, and the DMA of stage kt+2 is issued
@@ -600,6 +804,15 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
             for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048 + so);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (F8 && kt >= cat.f8_begin) {   // fp8 tile: one MFMA per fragment pair over both k-substeps' chunks
+            const int sc = kt < f8_half ? f8_sc1 : f8_sc2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = DYT_MFMA_F8(DYT_CAT8(__builtin_bit_cast(v4i, wf[0][j]), __builtin_bit_cast(v4i, wf[1][j])),
+                                            DYT_CAT8(__builtin_bit_cast(v4i, af[0][i]), __builtin_bit_cast(v4i, af[1][i])), acc[i][j], sc);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -607,10 +820,15 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = DYT_MFMA_16x16x32(wf[ks][j], af[ks][i], acc[i][j]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 
     }  // main-loop variants
+#undef DYT_MFMA_F8
+#undef DYT_LO4
+#undef DYT_HI4
+#undef DYT_CAT8
     if (ABL == 9) t_loop1 = __builtin_readcyclecounter();
 
     {
@@ -694,12 +912,12 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false, bool F8 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, int m_begin, Epi epi, CatArgs cat) {
     // rows [m_begin, M) are tiled by this launch
-    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x);
+    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT, F8>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x);
 }
 
 // Narrow-N GEMM (N = 768) in ONE launch: the first n_big workgroups take 256x256 tiles of rows [0, body) -- whole rounds of the
@@ -732,14 +950,14 @@ long long gemm_kernel_launch_count(int reset) {
     return n;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi, bool CAT = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi, bool CAT = false, bool F8 = false>
 static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int m_begin = 0, int m_end = -1) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     if (m_end < 0) m_end = a.M;
     if (m_end <= m_begin) return 0;
     const int grid = ((m_end - m_begin + BM - 1) / BM) * (a.N / BN);
     const size_t lds = 2 * (BM + BN) * 64 * 2;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT, F8>;
     static bool attr_set[64] = {};   // per device: the attribute belongs to the (kernel, device) pair
     int dev = 0;
     DYT_HIP_CHECK(hipGetDevice(&dev));
@@ -748,7 +966,7 @@ static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int
                                           (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold, a.a_ld};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold, a.a_ld, a.f8_begin, a.w_exp};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W),
                        m_end, a.N, a.K, a.m_dev, a.a_map, m_begin, epi, cat);
     ++g_bf16_kernel_launches;
@@ -768,7 +986,7 @@ static int launch_bf16_rows(const GemmArgs& a, const Epi& epi, hipStream_t s, in
         DYT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev & 63] = true;
     }
-    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold, a.a_ld};
+    const CatArgs cat{static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2), a.a2_map, a.out_scale, a.a_fold, a.a_ld, 0, nullptr};
     hipLaunchKernelGGL(kern, dim3(n_big + n_small), dim3(512), lds, s, static_cast<const bf16*>(a.A), static_cast<const bf16*>(a.W), a.M, a.N,
                        a.K, a.m_dev, a.a_map, body, n_big, epi, cat);
     ++g_bf16_kernel_launches;
@@ -801,6 +1019,25 @@ int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s) {
 static int g_big_tile_min_n = 2304;
 static int g_use_bpre = 1;        // wide-N GEMMs with a pre-shuffled frozen weight: 128x256 tiles, 2 workgroups / CU (gemm_bpre.h)
 static int g_split_rows = 1;      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
+
+// the "fp16f8" split contraction (a.K = 2 x the logical K: K / 64 f16 tiles + K / 64 fp8 tiles): tile shapes as for the three-part form
+template <class Epi>
+static int run_f8(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    if (a.K % 256 != 0 || a.M <= 0 || a.N % 128 != 0 || a.f8_begin * 128 != a.K) { set_error("gemm f8 form: K=%d N=%d M=%d", a.K, a.N, a.M); return -1; }
+    if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 2048 && !a.a_map) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true>(a, epi, s);
+    if (a.N % 256 == 0 && !a.a_map) {   // (the 256x256 fp8 kernel takes no row gather)
+        constexpr int NCU = 256;
+        const int tn = a.N / 256, t256 = ((a.M + 255) / 256) * tn, rounds = t256 / NCU, rem = t256 - rounds * NCU;
+        if (rounds >= 1 || rem >= 3 * NCU / 4) {
+            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true>(a, epi, s);
+            const int body = (rounds * NCU / tn) * 256;
+            int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true>(a, epi, s, 0, body);
+            if (rc) return rc;
+            return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true>(a, epi, s, body, a.M);
+        }
+    }
+    return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true>(a, epi, s);
+}
 
 template <class Epi, bool CAT = false>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
@@ -888,9 +1125,20 @@ static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     return launch_f32_cfg<128, 64>(a, epi, s);
 }
 
+// epilogues of the forward GEMMs against frozen weights: the ones the fp8-correction kernels are built for
+template <class Epi> struct F8Epi : std::false_type {};
+template <> struct F8Epi<EpiQKV<float>> : std::true_type {};
+template <class OT> struct F8Epi<EpiBiasResid<float, OT>> : std::true_type {};
+template <bool G, class GT> struct F8Epi<EpiFc1<float, G, GT>> : std::true_type {};
+template <bool P, class HT> struct F8Epi<EpiFc2<float, P, HT>> : std::true_type {};
+template <> struct F8Epi<EpiAdUp<true>> : std::true_type {};    // cls-row proj of the teacher's last block
+template <> struct F8Epi<EpiEmbed> : std::true_type {};
+template <> struct F8Epi<EpiBiasF32> : std::true_type {};       // unit entry dyt_linear_split
 // SPLIT: fp32 epilogue functors on the 16-bit MFMA kernels (the fp32 operands arrive as K-concatenated 16-bit hi / lo parts)
 template <class AT, bool SPLIT, class Epi>
 static int run(const GemmArgs& a, const Epi& epi, hipStream_t s) {
+    if constexpr (SPLIT && F8Epi<Epi>::value) { if (a.f8) return run_f8(a, epi, s); }
+    if (a.f8) { set_error("gemm: this epilogue has no fp8-correction form"); return -1; }
     if constexpr (sizeof(AT) == 2 || SPLIT) return run_bf16(a, epi, s);
     else return run_f32(a, epi, s);
 }
@@ -905,9 +1153,9 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N}, s); }
             return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1:
-            if constexpr (SPLIT) { if (a.save16 && a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, bf16>{a.bias, (AT*)a.out_at, (bf16*)a.out_at2, a.N, (bf16*)a.out3}, s); }
-            if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3}, s);
-            return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3}, s);
+            if constexpr (SPLIT) { if (a.save16 && a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, bf16>{a.bias, (AT*)a.out_at, (bf16*)a.out_at2, a.N, (bf16*)a.out3, a.f8}, s); }
+            if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3, a.f8}, s);
+            return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3, a.f8}, s);
         case EPI_FC2: {
             const float* resid = a.resid ? a.resid : a.out_f32;   // null: in place
             if (a.A2) {   // adapter up-projection as the leading k-tile of the contraction (16-bit kernels only)
@@ -1009,7 +1257,7 @@ int gemm_debug_counters(unsigned long long* out4, int reset) {
 // ---- fp32 operands as 16-bit hi / lo parts ----
 // A [M,K] fp32 (rows optionally gathered) -> out [M, 3K] = [hi | hi | lo]; one thread = 8 consecutive k of a row
 __global__ __launch_bounds__(256) void split3_a_kernel(const float* __restrict__ A, const int* __restrict__ a_map,
-                                                       const int* __restrict__ m_dev, bf16* __restrict__ out, int M, int K, float scale) {
+                                                       const int* __restrict__ m_dev, bf16* __restrict__ out, int M, int K, float scale, int f8) {
     const int kc = K / 8;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(idx / kc), c = (int)(idx - (size_t)row * kc);
@@ -1017,6 +1265,12 @@ __global__ __launch_bounds__(256) void split3_a_kernel(const float* __restrict__
     if (row >= Mv) return;
     const float* src = A + (size_t)(a_map ? a_map[row] : row) * K + c * 8;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(src) * scale, x1 = *reinterpret_cast<const f32x4*>(src + 4) * scale;
+    if (f8) {   // hi16 / fp8 form (store4_split_f8)
+        bf16* rowp = out + (size_t)row * SPLIT_A * K;
+        store4_split_f8(rowp, K, c * 8, x0[0], x0[1], x0[2], x0[3]);
+        store4_split_f8(rowp, K, c * 8 + 4, x1[0], x1[1], x1[2], x1[3]);
+        return;
+    }
     bf16x8 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1039,6 +1293,46 @@ __global__ __launch_bounds__(256) void split3_w_kernel(const float* __restrict__
     bf16* dst = out + row * SPLIT_A * K;
     dst[k] = hi; dst[K + k] = lo;
 }
+// hi16 / fp8 form of a weight: [N][hi16 (K) | e4m3(lo 2^(ew+11)) (K bytes) | e4m3(hi 2^ew) (K bytes)], ew = 7 - ceil(log2 max|w|)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ W, size_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(W[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+}
+__device__ __forceinline__ int weight_exp(unsigned maxbits) {
+    const float m = __uint_as_float(maxbits);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    const float f = frexpf(m, &e);          // m = f 2^e, f in [0.5, 1): ceil(log2 m) = e, or e - 1 when m is a power of two
+    const int cl = f == 0.5f ? e - 1 : e;
+    return max(-60, min(60, 7 - cl));
+}
+__global__ __launch_bounds__(256) void split_w_f8_kernel(const float* __restrict__ W, bf16* __restrict__ out, int N, int K,
+                                                         const unsigned* __restrict__ maxbits, int* __restrict__ ew_out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // 4 consecutive k of a row
+    const int ew = weight_exp(*maxbits);
+    if (idx == 0) *ew_out = ew;
+    if (idx >= (size_t)N * K / 4) return;
+    const size_t row = idx / (K / 4); const int k = (int)(idx - row * (K / 4)) * 4;
+    f32x4 w = *reinterpret_cast<const f32x4*>(W + row * K + k);
+    asm("" : "+v"(w));
+    const bf16 h0 = (bf16)w[0], h1 = (bf16)w[1], h2 = (bf16)w[2], h3 = (bf16)w[3];
+    bf16* rowp = out + row * SPLIT_A * K;
+    *reinterpret_cast<bf16x4*>(rowp + k) = bf16x4{h0, h1, h2, h3};
+    const float sh = ldexpf(1.0f, ew), sl = ldexpf(1.0f, ew + 11);
+    unsigned char* r8 = reinterpret_cast<unsigned char*>(rowp) + 2 * (size_t)K + k;
+    *reinterpret_cast<int*>(r8) = pack4_e4m3((w[0] - (float)h0) * sl, (w[1] - (float)h1) * sl, (w[2] - (float)h2) * sl, (w[3] - (float)h3) * sl);
+    *reinterpret_cast<int*>(r8 + K) = pack4_e4m3((float)h0 * sh, (float)h1 * sh, (float)h2 * sh, (float)h3 * sh);
+}
+int launch_split_w_f8(const float* W, void* W3, int N, int K, int* ew_dev, unsigned* scratch, hipStream_t s) {
+    DYT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(unsigned), s));
+    const size_t n = (size_t)N * K;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, s, W, n, scratch);
+    hipLaunchKernelGGL(split_w_f8_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, W, static_cast<bf16*>(W3), N, K, scratch, ew_dev);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s) {
     hipLaunchKernelGGL(split3_w_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, W, static_cast<bf16*>(W3), N, K);
     DYT_HIP_CHECK(hipGetLastError());
@@ -1051,10 +1345,14 @@ int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
         const size_t tasks = (size_t)a.M * (a.K / 8);
         if (!a.a3_ready)
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,
-                           a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale);
+                           a.m_dev, static_cast<bf16*>(a.a3), a.M, a.K, a.a3_scale, a.f8 ? 1 : 0);
         GemmArgs b = a;
         // a3_parts products of the contraction: 3 = hi*hi + hi*lo + lo*hi, 2 = hi * (hi + lo) (A rounded to half, W exact), 1 = hi*hi
         b.A = a.a3; b.W = a.W3; b.K = a.a3_parts * a.K; b.a_fold = a.K / 64; b.a_ld = 2 * a.K; b.a_map = (a.a3_ready && a.a3_mapped) ? a.a_map : nullptr; b.Wp = nullptr; b.W3 = nullptr; b.out_scale = 1.0f / a.a3_scale;
+        if (a.f8) {   // hi * hi as f16 tiles, then the two correction products as fp8 tiles along the same rows
+            if (a.K % 128 != 0 || a.a3_parts != 3 || a.a3_scale != 1.0f || !a.w_exp) { set_error("gemm f8 form: K=%d %% 128, forward operands only", a.K); return -1; }
+            b.K = 2 * a.K; b.a_fold = 0; b.f8_begin = a.K / 64;
+        }
         return dispatch<float, true>(kind, b, s);
     }
     if (dbg_skip(64) && (a.K == RP || a.N == RP)) return 0;

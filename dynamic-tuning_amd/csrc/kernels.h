@@ -46,6 +46,7 @@ struct GemmArgs {
     int a3_parts = 3;        // products of the split contraction (3: full; 2 / 1: gradient GEMMs of the forward-parity variant)
     int a_ld = 0;            // (internal) row stride of the split operands
     int a_fold = 0;          // (internal) k-tiles per part of a split A operand stored [hi | lo]: set by launch_gemm
+    int f8_begin = 0;        // (internal) F8 kernels: index of the first fp8 k-tile
     bool a3_ready = false;   // a3 already holds the split A (written by the producing kernel): no pre-pass
     bool a3_mapped = false;  // ... one split row per SOURCE row: the GEMM gathers through a_map (the pre-pass compacts instead)
     // FC1 / GELU_BWD in the split form: the result also (instead of out_at) goes out as the split A operand of the NEXT GEMM
@@ -53,6 +54,9 @@ struct GemmArgs {
     // fp32 mode whose backward runs on 16-bit operands ("fp16x3h"): the outputs that exist only for the backward pass -- BIAS_RESID's
     // out_at (copy of u), FC1's out_at2 (gelu'), FC2's h_out, AD_DOWN's out_at2 (copy of d_act) -- are of the 16-bit operand type
     bool save16 = false;
+    // "fp16f8" form of the split contraction: operands in the hi16 / fp8 images (dyt_common.h: store4_split_f8), the correction
+    // products on the fp8 matrix cores; w_exp = the weight image's device-side exponent word.  FC1: out3 is written in that form too
+    bool f8 = false; const int* w_exp = nullptr;
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -78,6 +82,8 @@ struct GemmArgs {
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
 // fp32 W [N,K] -> [N, 3K] 16-bit operands [hi | lo | hi] with hi = rn16(w), lo = rn16(w - hi)
 int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s);
+// ... in the hi16 / fp8 form [N, hi16 | e4m3(lo 2^(ew+11)) | e4m3(hi 2^ew)], ew = 7 - ceil(log2 max|w|) written to ew_dev[0]; scratch: one device word
+int launch_split_w_f8(const float* W, void* W3, int N, int K, int* ew_dev, unsigned* scratch, hipStream_t s);
 // bf16 W [N,K] row-major -> fragment order for the pre-shuffled-weight kernel (N % 16 == 0, K % 32 == 0)
 int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s);
 int gemm_debug_counters(unsigned long long* out4, int reset);
@@ -92,7 +98,7 @@ int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int
 // 16-bit copies of q / k / v (same layout) and of the output [B*197][768] written by the split forward kernel for a 16-bit backward
 struct AttnSave16 { void* q = nullptr; void* k = nullptr; void* v = nullptr; void* o = nullptr; };
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
-                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr, const AttnSave16* save16 = nullptr);   // out may be null when out3 is given   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
+                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr, const AttnSave16* save16 = nullptr, int out3_f8 = 0);   // out may be null when out3 is given   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
 void set_attn_f32_split(int on);   // process-wide version of split16 (unit entries)
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
@@ -108,7 +114,7 @@ void set_attn_bwd_fused(int on);
 // ------------------------------------------------------------------------------------------
 // LayerNorm over 768 channels, one wave per row; stats[row] = {mean, rstd}
 int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats,
-                  int rows, hipStream_t s, void* out3 = nullptr);   // out3 (fp32 mode): the rows as split 16-bit operand [rows, 3*768] instead of out
+                  int rows, hipStream_t s, void* out3 = nullptr, int out3_f8 = 0);   // out3 (fp32 mode): the rows as split 16-bit operand [rows, SPLIT_A*768] instead of out; out3_f8: in the hi16 / fp8 form (store4_split_f8)
 int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* out, int rows, hipStream_t s);
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
@@ -140,7 +146,7 @@ int launch_gate(const GateArgs& a, hipStream_t s);
 // also computes the row offsets (prefix of counts) itself and publishes total[0] = sum(counts)
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
-                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3 = nullptr);
+                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3 = nullptr, int out3_f8 = 0);
 
 // the index half of launch_ln_gather alone (dense forward that is followed by a compacted backward): row_src, dst_of, total
 int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,

@@ -103,6 +103,7 @@ struct LayerW {  // frozen, library-owned
     void *qkv_w3 = nullptr, *qkv_wT3 = nullptr, *proj_w3 = nullptr, *proj_wT3 = nullptr, *fc1_w3 = nullptr, *fc1_wT3 = nullptr, *fc2_w3 = nullptr, *fc2_wT3 = nullptr;
     // fp32 mode with a 16-bit backward ("fp16x3h", dyt_ctx::bwd16): the transposed matrices the dgrad GEMMs multiply by, in the 16-bit
     // operand type, plain [in,out] and in MFMA fragment order (what the 16-bit mode keeps as *_wT / *_wTp)
+    int* w_exp = nullptr;   // "fp16f8": device words with the exponents of the four forward images (qkv, proj, fc1, fc2), launch_split_w_f8
     void *qkv_wT16 = nullptr, *qkv_wTp16 = nullptr, *proj_wT16 = nullptr, *proj_wTp16 = nullptr, *fc1_wT16 = nullptr, *fc1_wTp16 = nullptr,
          *fc2_wT16 = nullptr, *fc2_wTp16 = nullptr;
 };
@@ -171,6 +172,8 @@ struct dyt_ctx {
     char* aux_arena = nullptr;
     size_t aux_size = 0;
     bool aux_bwd16 = false;     // the aux arena holds the bwd16 buffers
+    bool f8 = false;            // "fp16f8": forward GEMMs as hi * hi on the f16 matrix cores + the two correction products on the fp8 ones (DYT_OPT_F32_SPLIT16 = 4; implies bwd16)
+    int* pe_w_exp = nullptr; unsigned* f8_scratch = nullptr;
     bool bwd16 = false;         // "fp16x3h": the fp16x3 forward, the backward on the 16-bit mode's operands and kernels (DYT_OPT_F32_SPLIT16 = 3)
     void *ad_up_wT16 = nullptr, *ad_down_wT16 = nullptr, *ad_scratch16 = nullptr;   // bwd16: per-step 16-bit copies of the adapter matrices the dgrads read
     // frozen
@@ -367,8 +370,11 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
     const size_t B = cf.max_batch, M = B * NT, depth = cf.depth, SA = SPLIT_A;
     c->arena_used = 0;
     c->pe_w3 = carve<uint16_t>(c, SA * D * D, dry);
+    c->pe_w_exp = carve<int>(c, 4, dry);
+    c->f8_scratch = carve<unsigned>(c, 4, dry);
     for (size_t l = 0; l < depth; ++l) {
         LayerW& w = c->W[l];
+        w.w_exp = carve<int>(c, 4, dry);
         w.qkv_w3 = carve<uint16_t>(c, SA * 3 * D * D, dry); w.qkv_wT3 = carve<uint16_t>(c, SA * 3 * D * D, dry);
         w.proj_w3 = carve<uint16_t>(c, SA * D * D, dry); w.proj_wT3 = carve<uint16_t>(c, SA * D * D, dry);
         w.fc1_w3 = carve<uint16_t>(c, SA * DM * D, dry); w.fc1_wT3 = carve<uint16_t>(c, SA * DM * D, dry);
@@ -388,10 +394,11 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
     for (int sl = 0; sl < cf.slots; ++sl) {
         Slot& S = c->slots[sl];
         Transients& T = S.T;
-        T.a3 = carve<uint16_t>(c, M * SA * DM, dry);
-        T.xn3 = carve<uint16_t>(c, M * SA * D, dry);
-        T.g3 = carve<uint16_t>(c, M * SA * D, dry);
-        T.h3 = carve<uint16_t>(c, M * SA * DM, dry);
+        const size_t Mp = (M + 255) / 256 * 256;   // whole 256-row tiles: the fp8-correction kernel reads the rows of its last tile unclamped
+        T.a3 = carve<uint16_t>(c, Mp * SA * DM, dry);
+        T.xn3 = carve<uint16_t>(c, Mp * SA * D, dry);
+        T.g3 = carve<uint16_t>(c, Mp * SA * D, dry);
+        T.h3 = carve<uint16_t>(c, Mp * SA * DM, dry);
         T.dqkv3 = carve<uint16_t>(c, M * SA * 3 * D, dry);
         if (!bwd16) continue;
         T.dad16 = carve<uint16_t>(c, M * D, dry);
@@ -597,6 +604,15 @@ static int set_matrix(dyt_ctx* c, const float* src, void* w, void* wT, int N, in
 // fp32 mode: refresh the 16-bit [hi | lo] images of one layer's (layer < 0: the patch embedding's) frozen matrices
 static int refresh_split(dyt_ctx* c, int layer, hipStream_t s) {
     if (c->prec != 0) return 0;
+    if (c->f8) {   // forward images in the hi16 / fp8 form (the backward of this mode runs on the 16-bit copies: no transposed images)
+        if (layer < 0) return launch_split_w_f8((const float*)c->pe_w, c->pe_w3, D, D, c->pe_w_exp, c->f8_scratch, s);
+        LayerW& w = c->W[layer];
+        int rc = launch_split_w_f8((const float*)w.qkv_w, w.qkv_w3, 3 * D, D, w.w_exp + 0, c->f8_scratch, s);
+        if (!rc) rc = launch_split_w_f8((const float*)w.proj_w, w.proj_w3, D, D, w.w_exp + 1, c->f8_scratch, s);
+        if (!rc) rc = launch_split_w_f8((const float*)w.fc1_w, w.fc1_w3, DM, D, w.w_exp + 2, c->f8_scratch, s);
+        if (!rc) rc = launch_split_w_f8((const float*)w.fc2_w, w.fc2_w3, D, DM, w.w_exp + 3, c->f8_scratch, s);
+        return rc;
+    }
     if (layer < 0) return launch_split3_w((const float*)c->pe_w, c->pe_w3, D, D, s);
     LayerW& w = c->W[layer];
     int rc = launch_split3_w((const float*)w.qkv_w, w.qkv_w3, 3 * D, D, s);
@@ -737,13 +753,16 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_FC2_CAT: c->fc2_cat = value != 0; return DYT_OK;
         case DYT_OPT_F32_SPLIT16: {   // fp32 mode only: the frozen-weight GEMMs as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
             if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
-            if (value < 0 || value > 3) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part, 3 backward on 16-bit operands)", value); return DYT_ERR_ARG; }
-            if (value != 0) { int rc = alloc_aux(c, value == 3); if (rc) return rc; }
+            if (value < 0 || value > 4) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part, 3 backward on 16-bit operands, 4 = 3 with fp8 correction products)", value); return DYT_ERR_ARG; }
+            if (value != 0) { int rc = alloc_aux(c, value >= 3); if (rc) return rc; }
             c->split16 = value != 0;
             // 3 ("fp16x3h"): the forward as in 1 / 2 bit for bit, with what the backward needs saved in the 16-bit operand type (the hi
             // parts the forward computes anyway; ReLU / dropout / gate masks are the exact forward's), and the backward pass on the
             // 16-bit mode's data flow and kernels (fused attention backward, pre-shuffled-weight dgrads, 16-bit weight gradients)
-            c->bwd16 = value == 3;
+            c->bwd16 = value >= 3;
+            // 4 ("fp16f8"): the forward GEMMs' two correction products hi * lo + lo * hi on the fp8 matrix cores (twice the f16 rate per k:
+            // 2K- instead of 3K-equivalent contractions; per-GEMM error ~2^-15 instead of 2^-20, logits ~5e-5 from the fp32 reference)
+            c->f8 = value == 4;
             c->gs = 1.0f;
 #ifdef DYT_FP16
             if (c->bwd16) c->gs = 4096.0f;   // the fixed loss scale of the fp16 mode (dyt_ctx::gs)
@@ -869,7 +888,7 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 #define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
 // forward GEMM class g (0 qkv, 1 proj, 2 fc1, 3 fc2): products of its contraction (measurement knob DYT_SPLIT_FWD_PARTS="qkv,proj,fc1,fc2")
-#define SPLIT_F(a, w3, g) do { SPLIT(a, w3); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; } while (0)
+#define SPLIT_F(a, w3, g) do { SPLIT(a, w3); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; if (c->split16 && c->f8) { (a).f8 = true; (a).w_exp = W.w_exp + (g); } } while (0)
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
@@ -983,6 +1002,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const uint64_t* seed_dev = (flags & DYT_F_DEVICE_SEED) ? c->seed_dev : nullptr;
+    const int f8 = (c->split16 && c->f8) ? 1 : 0;   // split operands in the hi16 / fp8 form
     const bool save16 = save && c->bwd16 && c->split16 && c->split_attn;   // "fp16x3h": what the backward reads is saved in the 16-bit operand type
     Slot& S = c->slots[slot];
     Transients& T = S.T;
@@ -1003,6 +1023,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         {
             GemmArgs a; a.A = T.xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
             a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0]; SPLIT(a, c->pe_w3);
+            if (c->split16 && c->f8) { a.f8 = true; a.w_exp = c->pe_w_exp; }
             RUN_GEMM(EPI_EMBED, a);
         }
         RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
@@ -1017,7 +1038,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
         if (!(share0 && l == 0)) {
-            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr));
+            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr, f8));
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
                 a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT_F(a, W.qkv_w3, 0); SPLIT_READY(a, T.xn3);
@@ -1027,7 +1048,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             // last block of a pass without a gate (teacher / complete model): the proj GEMM runs on the gathered cls rows of the fp32 output
             const bool tail_proj = c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate;
             const AttnSave16 sv16{L.q16, L.k16, L.v16, L.o16};   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, save16 ? &sv16 : nullptr));
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, save16 ? &sv16 : nullptr, f8));
             if (tail_proj) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
@@ -1096,9 +1117,9 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             // nothing: T.xn already holds LN2 of the cls rows
         } else if (!dense) {
             RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.total, L.maskf, T.xn, L.st2,
-                                       L.row_src, L.dst_of, B, s, c->split16 ? T.xn3 : nullptr));
+                                       L.row_src, L.dst_of, B, s, c->split16 ? T.xn3 : nullptr, f8));
         } else {
-            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s, c->split16 ? T.xn3 : nullptr));
+            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s, c->split16 ? T.xn3 : nullptr, f8));
             // reference-style (masked) student pass: the MLP runs on every token, but its backward only has rows for the
             // kept ones (dH = mask * g) and is compacted -- it needs the dispatcher's index arrays too
             if (masked_dense && save) RUN(2, 0, launch_gather_index(L.keep_local, counts, L.total, L.maskf, L.row_src, L.dst_of, B, s));
@@ -1798,6 +1819,25 @@ extern "C" int dyt_linear(const float* a, const float* w, const float* bias, flo
         g.A = a2; g.W = w2;
     }
     int rc = launch_gemm(precision, EPI_BIAS_F32, g, s);
+    if (rc) return rc;
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
+}
+
+// One nn.Linear through the split forms of the fp32 mode (unit tests / probes): form 3 = three IEEE-half products, 8 = hi * hi in f16 +
+// fp8 correction products.  a [M,K], w [N,K], bias [N] or NULL, cmat [M,N] fp32.  Allocates scratch and synchronises: test-only.
+extern "C" int dyt_linear_split(const float* a, const float* w, const float* bias, float* cmat, int M, int N, int K, int form, void* stream) {
+    if (!a || !w || !cmat || M < 1 || (form != 3 && form != 8)) { set_error("bad argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch sc;
+    void* a3 = sc.get((size_t)((M + 255) / 256 * 256) * SPLIT_A * K * 2); void* w3 = sc.get((size_t)N * SPLIT_A * K * 2);
+    int* ew = (int*)sc.get(16); unsigned* scr = (unsigned*)sc.get(16);
+    if (!a3 || !w3 || !ew || !scr) { set_error("scratch alloc failed"); return DYT_ERR_HIP; }
+    int rc = form == 8 ? launch_split_w_f8(w, w3, N, K, ew, scr, s) : launch_split3_w(w, w3, N, K, s);
+    if (rc) return rc;
+    GemmArgs g; g.A = a; g.W = w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out_f32 = cmat; g.W3 = w3; g.a3 = a3;
+    if (form == 8) { g.f8 = true; g.w_exp = ew; }
+    rc = launch_gemm(0, EPI_BIAS_F32, g, s);
     if (rc) return rc;
     DYT_HIP_CHECK(hipStreamSynchronize(s));
     return DYT_OK;

@@ -48,7 +48,7 @@ namespace dyt {
 template <class AT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, AT* __restrict__ out,
-                                                     float2* __restrict__ stats, int rows, bf16* __restrict__ out3) {
+                                                     float2* __restrict__ stats, int rows, bf16* __restrict__ out3, int f8) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (out3) {   // fp32 split form: the row as the 16-bit hi / hi / lo operand of the next GEMM
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            store4_split3(out3 + (size_t)row * SPLIT_A * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
+            if (f8) store4_split_f8(out3 + (size_t)row * SPLIT_A * D, D, i * 256 + lane * 4, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
+            else store4_split3(out3 + (size_t)row * SPLIT_A * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
     } else {
         xr.store(out + (size_t)row * D, lane);
     }
@@ -121,13 +122,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
 }
 
 int launch_ln_fwd(int precision, const float* x, const float* w, const float* b, void* out, float2* stats, int rows,
-                  hipStream_t s, void* out3) {
+                  hipStream_t s, void* out3, int out3_f8) {
     const int grid = (rows + 3) / 4;
     if (dbg_skip(32)) return 0;
     if (precision == 0)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, b, (float*)out, stats, rows, (bf16*)out3);
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, b, (float*)out, stats, rows, (bf16*)out3, out3_f8);
     else
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, x, w, b, (bf16*)out, stats, rows, (bf16*)nullptr);
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, x, w, b, (bf16*)out, stats, rows, (bf16*)nullptr, 0);
     LAUNCH_CHECK();
     return 0;
 }
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
                                                         const int* __restrict__ counts, int* __restrict__ total,
                                                         const float* __restrict__ maskf, AT* __restrict__ out,
                                                         float2* __restrict__ stats, int* __restrict__ row_src,
-                                                        int* __restrict__ dst_of, int batch, bf16* __restrict__ out3) {
+                                                        int* __restrict__ dst_of, int batch, bf16* __restrict__ out3, int f8) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= batch * NT) return;
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
     if (out3) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            store4_split3(out3 + (size_t)dst * SPLIT_A * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
+            if (f8) store4_split_f8(out3 + (size_t)dst * SPLIT_A * D, D, i * 256 + lane * 4, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
+            else store4_split3(out3 + (size_t)dst * SPLIT_A * D + i * 256 + lane * 4, D, xr.v[4 * i], xr.v[4 * i + 1], xr.v[4 * i + 2], xr.v[4 * i + 3]);
     } else {
         xr.store(out + (size_t)dst * D, lane);
     }
@@ -304,14 +306,14 @@ int launch_gather_index(const int* keep_local, const int* counts, int* total, co
 
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
-                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3) {
+                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3, int out3_f8) {
     const int grid = (batch * NT + 3) / 4;
     if (precision == 0)
         hipLaunchKernelGGL(ln_gather_kernel<float>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, total,
-                           maskf, (float*)out, stats, row_src, dst_of, batch, (bf16*)out3);
+                           maskf, (float*)out, stats, row_src, dst_of, batch, (bf16*)out3, out3_f8);
     else
         hipLaunchKernelGGL(ln_gather_kernel<bf16>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, total,
-                           maskf, (bf16*)out, stats, row_src, dst_of, batch, (bf16*)nullptr);
+                           maskf, (bf16*)out, stats, row_src, dst_of, batch, (bf16*)nullptr, 0);
     LAUNCH_CHECK();
     return 0;
 }

@@ -10,14 +10,14 @@ import ctypes
 import torch
 
 from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
-                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H, PREC_FP32,
+                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16F8, PREC_FP16X3F, PREC_FP16X3H, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
 
 
 def parse_precision(p):
-    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H):
+    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H, PREC_FP16F8):
         return p
     p = str(p).lower()
     if p in ("fp32", "float32", "exact"):
@@ -32,7 +32,9 @@ def parse_precision(p):
         return PREC_FP16X3F
     if p in ("fp16x3h", "fp16x3-bwd16", "split-half"):
         return PREC_FP16X3H
-    raise ValueError("precision must be 'fp32', 'fp16x3', 'fp16x3f', 'fp16x3h', 'bf16' or 'fp16', got %r" % (p,))
+    if p in ("fp16f8", "fp16+fp8"):
+        return PREC_FP16F8
+    raise ValueError("precision must be 'fp32', 'fp16x3', 'fp16x3f', 'fp16x3h', 'fp16f8', 'bf16' or 'fp16', got %r" % (p,))
 
 
 class DyTEngine:
@@ -46,7 +48,8 @@ class DyTEngine:
         # "fp16x3" = that library's fp32 mode with the frozen-weight GEMMs as three IEEE-half products (DYT_OPT_F32_SPLIT16)
         # "fp16x3f" = the same with the gradient products as the hi * hi term alone (forward bit-identical to "fp16x3")
         # "fp16x3h" = the same forward again, the backward pass on 16-bit operands with the fp16 mode's kernels
-        split = {PREC_FP16X3: 1, PREC_FP16X3F: 2, PREC_FP16X3H: 3}.get(self.precision, 0)
+        # "fp16f8" = "fp16x3h" with the two correction products of every forward GEMM on the fp8 matrix cores (not bit-identical to fp16x3)
+        split = {PREC_FP16X3: 1, PREC_FP16X3F: 2, PREC_FP16X3H: 3, PREC_FP16F8: 4}.get(self.precision, 0)
         lib_prec = PREC_BF16 if self.precision == PREC_FP16 else (PREC_FP32 if split else self.precision)
         self.cfg = Config(int(num_classes), int(ffn_num), int(depth), lib_prec,
                           int(max_batch), int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),

@@ -295,6 +295,12 @@ int dyt_adapter_bwd(const float* x, const float* down_w, const float* down_b, co
 int dyt_mlp_gathered_fwd(dyt_ctx* ctx, int layer, const float* u, const float* mask, float* x, int batch, int32_t* total_out,
                          void* stream);
 
+/* One nn.Linear (c = a w^T + bias; a [M,K], w [N,K], bias [N] or NULL, c [M,N], fp32 device pointers) through the split forms of the
+ * fp32 mode: form 3 = every product as three IEEE-half products (hi*hi + hi*lo + lo*hi), form 8 = hi*hi on the f16 matrix cores plus
+ * the two correction products on the fp8 (e4m3) matrix cores ("fp16f8").  K % 128 == 0, N % 128 == 0.  Unit-test entry: allocates
+ * scratch and synchronises.  Reference op: nn.Linear of models/vision_transformer_IN21K.py:56,73 and timm Mlp (:124-129). */
+int dyt_linear_split(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int form, void* stream);
+
 /* ---- single-kernel entry points (unit tests; also the building blocks of the sub-module API) ---- */
 /* nn.LayerNorm(768, eps=1e-6) forward; out fp32 */
 int dyt_layernorm(const float* x, const float* w, const float* b, float* out, int rows, void* stream);
