@@ -22,7 +22,27 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402  (installs the third-party stand-ins, puts the reference on sys.path)
 
 synth = mg.synth
-from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k as video_vit  # noqa: E402
+
+
+def _reference_video_module():
+    """The REFERENCE's video_models/video_vision_transformer_IN21K.py, loaded by path: /root/reference/video_models is a namespace
+    package (no __init__.py), so a plain import would pick this repository's mirror package of the same name
+    (dynamic-tuning_amd/video_models/, a regular package on sys.path for `synth`) ahead of it."""
+    import importlib.util
+    pkg_dir = os.path.join(mg.REF, "video_models")
+    pkg = types.ModuleType("video_models")
+    pkg.__path__ = [pkg_dir]
+    sys.modules["video_models"] = pkg
+    name = "video_models.video_vision_transformer_IN21K"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "video_vision_transformer_IN21K.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    assert os.path.realpath(mod.__file__).startswith(os.path.realpath(mg.REF)), mod.__file__
+    return mod
+
+
+video_vit = _reference_video_module().vit_base_patch16_224_in21k
 
 BIG = ("cross_attn.q.weight", "cross_attn.k.weight", "cross_attn.v.weight", "cross_attn.proj.weight")
 ROW_STRIDE = 96   # 8 of the 768 rows of each 768x768 pooling-head gradient are stored

@@ -55,8 +55,17 @@ def D_adamw(eng, lr, wd):
 # (fp32 = the parity mode: north_star's own bars; fp16 = IEEE-half operands, the reference's autocast dtype; bf16).
 #   logits: max abs error; flips: gate decisions that differ (eval fixture 9408 decisions / training fixture 4704);
 #   tok_logits: eval token_logits (a flipped token changes every later block's gate input); loss: relative
+GRAD_H = 5e-3
+SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16f8")
+ALL_PRECS = ("fp32",) + SPLIT_MODES + ("fp16", "bf16")
 TOL = {
     "fp32": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4),
+    # the at-tolerance split modes (fp32 data flow, frozen-weight GEMMs and attention as IEEE-half / fp8 products): north_star's bars; `grad`
+    # = bound on the worst of all gradient tensors (16-bit backward passes: the goldens' B = 2 averages less round-off than B = 16)
+    "fp16x3": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=2e-3),
+    "fp16x3f": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=2e-3),
+    "fp16x3h": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=GRAD_H),
+    "fp16f8": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=2e-4, grad=GRAD_H),
     "fp16": dict(logits=5e-3, eval_flips=6, step_flips=2, tok_logits=0.5, loss=3e-3, vlogits=2e-3, vflips=6, vstep_flips=4, vloss=5e-3),
     "bf16": dict(logits=0.03, eval_flips=30, step_flips=8, tok_logits=1.0, loss=0.02, vlogits=8e-3, vflips=30, vstep_flips=12, vloss=0.05),
 }
@@ -76,12 +85,12 @@ def report_grads(tag, prec, items):
     worst = {}
     for n, got, ref, floor in items:
         e = float((got - ref).norm() / max(float(ref.norm()), floor))
-        k = grad_kind(n) if prec != "fp32" else "all"
+        k = grad_kind(n) if prec in ("fp16", "bf16") else "all"
         if e > worst.get(k, (0.0, ""))[0]:
             worst[k] = (e, n)
     for k, (e, n) in sorted(worst.items()):
         report("step grads (rel L2, worst %s tensor) %s" % (k, tag), e,
-               2e-3 if prec == "fp32" else (FP16_GRAD_TOL_SMALL_B if prec == "fp16" else BF16_GRAD_TOL_SMALL_B)[k], n)
+               2e-3 if prec == "fp32" else (TOL[prec]["grad"] if prec in SPLIT_MODES else (FP16_GRAD_TOL_SMALL_B if prec == "fp16" else BF16_GRAD_TOL_SMALL_B)[k]), n)
 
 
 def relerr(a, b):
@@ -212,7 +221,7 @@ def t_eval_golden():
     g = dict(np.load(os.path.join(ROOT, "tests/golden/eval_r64.npz")))
     B, C = int(g["meta_batch"]), int(g["meta_num_classes"])
     x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
-    for prec in ("fp32", "fp16", "bf16"):   # measured: fp16 ~1.5e-3, bf16 0.012
+    for prec in ALL_PRECS:   # measured: fp16 ~1.5e-3, bf16 0.012
         tol = TOL[prec]["logits"]
         model, sd = build_model(g, prec)
         model.eval()
@@ -232,7 +241,7 @@ def t_step_golden():
     x, y = synth.make_batch(B, C, seed=seed)
     keep = synth.make_dropout_masks(B, r, seed=seed + 3)
     g1, g2 = torch.from_numpy(g["s0_g1"]), torch.from_numpy(g["s0_g2"])
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ALL_PRECS:
         for mode in ("masked", "compact"):
             model, sd = build_model(g, prec, mode)
             model.train()
@@ -301,7 +310,7 @@ def t_video_golden():
     keep = synth.make_dropout_masks(B, r, seed=seed + 3)
     g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
     stride = int(g["meta_row_stride"])
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ALL_PRECS:
         ltol = TOL[prec]["vlogits"]      # bf16 measured: 3e-4 .. 2e-3
         model, sd = build_video_model(g, prec, "masked")
         model.eval()
@@ -343,7 +352,7 @@ def t_video_golden():
                     got = got[::st]
                 # norm_k.bias has an exactly-zero true gradient (a constant added to every key of a clip shifts all
                 # scores equally; the reference's own value is 1e-9 round-off), hence the absolute floor
-                items.append((n, got, gr, 1e-4 if prec == "fp32" else (3e-4 if prec == "fp16" else 1e-3)))
+                items.append((n, got, gr, 1e-4 if prec in ("fp32", "fp16x3") else (1e-3 if prec == "bf16" else 3e-4)))
             report_grads(tag, prec, items)
             if prec == "fp32" and mode == "masked":
                 D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))

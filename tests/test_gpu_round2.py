@@ -43,16 +43,21 @@ BF16_GRAD_TOL = {"mlp_token_select": 0.05, "adaptmlp.down_proj": 0.15, "adaptmlp
 FP16_GRAD_TOL = {"mlp_token_select": 0.01, "adaptmlp.down_proj": 0.25, "adaptmlp.up_proj": 0.005, "head": 0.003}   # VTAB shapes (r=16): down_proj up to 0.115, gate 0.003
 
 
+SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16f8")   # fp32 data flow, frozen-weight GEMMs / attention as IEEE-half (+ fp8) products
+
+
 def _grad_tol(name, precision):
-    if precision == "fp32":
+    if precision in ("fp32", "fp16x3", "fp16x3f"):
         return 2e-3
+    if precision in ("fp16x3h", "fp16f8"):   # 16-bit backward pass on the exact forward's masks: measured <= 2.0e-3 at B=16 over five seeds
+        return 4e-3
     for k, v in (FP16_GRAD_TOL if precision == "fp16" else BF16_GRAD_TOL).items():
         if k in name:
             return v
     return 0.1
 
 
-def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
+def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16", precs=("fp32", "fp16x3h", "fp16f8", "fp16", "bf16")):
     """One fused step (logits, masks, the five loss components, all 74 gradients) against the oracle on the same seeded inputs
     and draws, in both precisions."""
     x, y = synth.make_batch(B, C, seed=seed)
@@ -62,7 +67,7 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
     d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
     ref_ls, ref_lt, ref_ts = ref_ls.detach(), ref_lt.detach(), tok["token_select"].detach()
     z = ((tok["token_logits"].detach()[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0).abs()   # decision margins [12,B,196]
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in precs:
         m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
@@ -72,13 +77,19 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
         losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
                                   g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
                                   token_select=ts).cpu()
-        ltol = {"fp32": 1e-3, "fp16": 0.015, "bf16": 0.03}[prec]       # measured at B=16, C=100: 4e-6 / 1.6e-3 / 0.012; fp16 at B=64, C=397: 8.8e-3
+        ltol = {"fp16": 0.015, "bf16": 0.03}.get(prec, 1e-3)       # measured at B=16, C=100: 4e-6 / 1.6e-3 / 0.012; fp16 at B=64, C=397: 8.8e-3
         assert float((ls.cpu() - ref_ls).abs().max()) < ltol, (prec, float((ls.cpu() - ref_ls).abs().max()))
         assert float((lt.cpu() - ref_lt).abs().max()) < ltol
         flip = ts.cpu() != ref_ts[..., 0].float()
-        if prec == "fp32":   # bit-exact wherever the decision is not within fp32 round-off of the threshold
-            assert int((flip & (z.permute(1, 0, 2) > 2e-5)).sum()) == 0, int(flip.sum())
+        if prec == "fp32" or prec in SPLIT_MODES:   # bit-exact wherever the decision is not within round-off of the threshold
+            assert int((flip & (z.permute(1, 0, 2) > (1e-4 if prec == "fp16f8" else 2e-5))).sum()) == 0, int(flip.sum())
             assert int(flip.sum()) <= 2
+            print("%s %s/%s: logits %.2e / %.2e, %d of %d decisions differ" % (label, prec, mode, float((ls.cpu() - ref_ls).abs().max()),
+                                                                              float((lt.cpu() - ref_lt).abs().max()), int(flip.sum()), flip.numel()))
+            if int(flip.sum()):   # a near-tie went the other way: the later blocks see another token set
+                del m, eng
+                torch.cuda.empty_cache()
+                continue
         elif prec == "fp16":
             print("%s fp16 gate flips: %d of %d" % (label, int(flip.sum()), flip.numel()))
             assert int(flip.sum()) <= max(6, B // 4), int(flip.sum())       # measured: 0 of 37 632 at B=16 (scale 0.1); 3 of 18 816 at the VTAB shape B=8, scale 1
@@ -86,7 +97,7 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16"):
             assert int(flip.sum()) <= max(8, B * 3 // 2), int(flip.sum())   # of B*2352 decisions (measured: a handful at B=16)
         for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
             ref = float(d_ref[k])
-            assert abs(float(losses[i]) - ref) < {"fp32": 1e-4, "fp16": 3e-3, "bf16": 0.02}[prec] * max(1.0, abs(ref)), (prec, k, float(losses[i]), ref)
+            assert abs(float(losses[i]) - ref) < {"fp16": 3e-3, "bf16": 0.02, "fp16f8": 2e-4}.get(prec, 1e-4) * max(1.0, abs(ref)), (prec, k, float(losses[i]), ref)
         worst, scalars = {}, {}
         for n, gr in g_ref.items():
             got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
@@ -122,7 +133,8 @@ def test_vtab_task_shapes_vs_oracle(B, C):
     _step_vs_oracle(B, C, 16, "masked", 0.5, seed=131, label="VTAB B=%d C=%d" % (B, C))
 
 
-@pytest.mark.parametrize("precision,mode", [("fp32", "compact"), ("bf16", "compact"), ("bf16", "masked")])
+@pytest.mark.parametrize("precision,mode", [("fp32", "compact"), ("bf16", "compact"), ("bf16", "masked"), ("fp16", "compact"), ("fp16x3h", "compact"),
+                                            ("fp16f8", "compact")])
 def test_full_size_backward_is_additive_over_sub_batches(precision, mode):
     """B=128 (the bench size): the gradient of the full batch for an injected upstream gradient equals the sum over 8
     sub-batches of 16 images (images never interact; only the summation order of the weight-gradient reductions differs).
@@ -151,12 +163,13 @@ def test_full_size_backward_is_additive_over_sub_batches(precision, mode):
                                  g1=g1[:, sl].contiguous(), g2=g2[:, sl].contiguous(),
                                  keep_mask=keep.view(12, B, 197, r)[:, sl].reshape(12, SB * 197, r).contiguous())
         assert torch.equal(tsi, ts[sl])                                        # same decisions
-        assert float((lg - logits[sl]).abs().max()) <= (1e-5 if precision == "fp32" else 1e-6)   # bf16 kernels accumulate rows identically
+        assert float((lg - logits[sl]).abs().max()) <= (1e-5 if precision == "fp32" else 1e-6)   # the 16-bit MFMA kernels accumulate rows identically
         part = torch.zeros_like(eng.flat)
         eng.backward(0, dl[sl].contiguous(), part, dtok=dtok)
         acc += part
     assert float(full.abs().max()) > 0
     tol = 1e-5 if precision == "fp32" else 2e-3
+    assert torch.isfinite(full).all()
     names = [n for n, p in m.named_parameters() if synth.is_trainable(n)]
     for n in names:
         off, num = eng.trainable_slice(n)

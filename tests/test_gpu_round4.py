@@ -88,3 +88,39 @@ def test_parity_modes_vs_oracle_over_seeds(prec, seed):
     # measured over the five draws: fp16x3h 7.6e-4 ... 1.4e-3; fp16f8 6.8e-4 ... 2.0e-3 -- the lowest blocks' adapter / gate gradients carry
     # the round-off of the whole 16-bit backward chain above them (the fp16 mode itself: 1e-3 ... 4e-2, test_gpu_round2.py)
     assert worst < (2e-3 if prec == "fp16x3h" else 3e-3), (wname, worst)
+
+
+@pytest.mark.parametrize("prec", ["fp16x3h", "fp16f8"])
+def test_parity_modes_match_the_fp32_mode_at_bench_size(prec):
+    """B = 128 (BASELINE configs[1], what bench.py times): student and teacher training-mode forward of the at-tolerance modes against
+    the exact-fp32 mode on the same images, injected Gumbel noise and dropout masks -- logits within 1e-3, token-keep decisions equal
+    wherever |(logit + g) / tau| exceeds the mode's gate-logit round-off, token logits within 1e-3 of the fp32 mode's."""
+    B, C, r = 128, 100, 64
+    x, _ = synth.make_batch(B, C, seed=81)
+    g1, g2 = synth.make_noise(B, seed=82)
+    keep = synth.make_dropout_masks(B, r, seed=83)
+    res = {}
+    for p in ("fp32", prec):
+        m, _ = _bench_model(p, "compact", B, 0.85)
+        m.train()
+        eng = m.engine(B, torch.device("cuda", 0))
+        ls, ts, tl = eng.forward(x.cuda(), slot=0, training=True, save=True, g1=g1[0].cuda().contiguous(), g2=g2[0].cuda().contiguous(),
+                                 keep_mask=keep[0].cuda().contiguous())
+        lt, _, _ = eng.forward(x.cuda(), slot=1, training=True, complete_model=True, save=True, g1=g1[1].cuda().contiguous(),
+                               g2=g2[1].cuda().contiguous(), keep_mask=keep[1].cuda().contiguous())
+        torch.cuda.synchronize()
+        res[p] = (ls.cpu(), lt.cpu(), ts.cpu(), tl.cpu())
+        del m, eng
+        torch.cuda.empty_cache()
+    a, b = res["fp32"], res[prec]
+    z = ((a[3] + (g1[0] - g2[0]).permute(1, 0, 2)) / 5.0).abs()   # [B,12,196] decision margins of the fp32 mode
+    flip = a[2] != b[2]
+    es, et = float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max())
+    print("B=128 %s vs fp32 mode: logits %.2e / %.2e, %d of %d decisions differ (largest margin of one %.1e)" % (
+        prec, es, et, int(flip.sum()), flip.numel(), float(z[flip].max()) if int(flip.sum()) else 0.0))
+    assert et < 1e-3, et
+    assert int((flip & (z > (2e-5 if prec == "fp16x3h" else 1e-4))).sum()) == 0, int(flip.sum())
+    assert int(flip.sum()) <= (2 if prec == "fp16x3h" else 8), int(flip.sum())
+    if not int(flip.sum()):
+        assert es < 1e-3, es
+        assert float((a[3] - b[3]).abs().max()) < 1e-3
