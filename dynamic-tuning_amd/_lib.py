@@ -22,6 +22,7 @@ PREC_FP16 = 2   # host-side name only: libdyt_hip_f16.so with its 16-bit mode (D
 PREC_FP16X3F = 4  # host-side name only: PREC_FP16X3 with the gradient products as the hi * hi term alone (DYT_OPT_F32_SPLIT16 = 2)
 PREC_FP16X3H = 5  # host-side name only: the PREC_FP16X3 forward bit for bit, the backward pass on 16-bit operands with the fp16 mode's kernels (DYT_OPT_F32_SPLIT16 = 3)
 PREC_FP16F8 = 6   # host-side name only: PREC_FP16X3H with the forward GEMMs' correction products on the fp8 matrix cores (DYT_OPT_F32_SPLIT16 = 4)
+PREC_FP16X3Q = 7  # host-side name only: PREC_FP16X3H with the attention branch's GEMMs (qkv, proj) in the fp8-correction form, the MLP three-part (DYT_OPT_F32_SPLIT16 = 5)
 PREC_FP16X3 = 3   # host-side name only: libdyt_hip_f16.so in its fp32 mode with DYT_OPT_F32_SPLIT16 (frozen-weight GEMMs as three IEEE-half products)
 F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED, F_TOKENS_IN, F_TOKENS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2, OPT_FC2_CAT, OPT_ATTN_BWD_FUSED, OPT_F32_SPLIT16 = 1, 2, 3, 4, 5, 6, 7, 8
@@ -107,6 +108,7 @@ SYMBOLS = {
     "dyt_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dyt_loss": (_i, [_vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "dyt_adamw": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "dyt_adamw_guarded": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     "dyt_step_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _u64, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
                               _vp, _vp]),
     "dyt_seed": (_i, [_vp, _u64, _vp]),

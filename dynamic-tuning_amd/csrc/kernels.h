@@ -55,8 +55,9 @@ struct GemmArgs {
     // out_at (copy of u), FC1's out_at2 (gelu'), FC2's h_out, AD_DOWN's out_at2 (copy of d_act) -- are of the 16-bit operand type
     bool save16 = false;
     // "fp16f8" form of the split contraction: operands in the hi16 / fp8 images (dyt_common.h: store4_split_f8), the correction
-    // products on the fp8 matrix cores; w_exp = the weight image's device-side exponent word.  FC1: out3 is written in that form too
+    // products on the fp8 matrix cores; w_exp = the weight image's device-side exponent word
     bool f8 = false; const int* w_exp = nullptr;
+    bool out3_f8 = false;   // FC1: out3 (the fc2 GEMM's operand) in that form
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -195,6 +196,11 @@ int launch_seed_advance(uint64_t* seed_dev, hipStream_t s);
 int launch_clip_grad_norm(float* g, int64_t n, float max_norm, float pre_scale, float* scratch, float* norm_out, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2, float gscale, hipStream_t s);
+
+// ... guarded: skipped (and counted) when the gradient holds inf / NaN; state = device int[4] {applied, skipped, flag, -}; bias corrections
+// from the device-side applied count
+int launch_adamw_guarded(float* p, const float* g, float* m, float* v, int64_t n, int* state, float lr, float b1, float b2,
+                         float eps, float wd, float gscale, hipStream_t s);
 
 // backward prep for one block: g_at = AT(g) ; dH[dst_of[t]] = AT(g[t] * mask) ;
 // dmask[token] = <g[token], h[r]> for kept rows (0 elsewhere)

@@ -172,6 +172,7 @@ struct dyt_ctx {
     char* aux_arena = nullptr;
     size_t aux_size = 0;
     bool aux_bwd16 = false;     // the aux arena holds the bwd16 buffers
+    int f8_mask = 0;            // classes of forward GEMMs in that form: 1 qkv, 2 proj, 4 fc1, 8 fc2, 16 patch embedding (DYT_F8_CLASSES; "fp16f8" = 31, "fp16x3q" = 3)
     bool f8 = false;            // "fp16f8": forward GEMMs as hi * hi on the f16 matrix cores + the two correction products on the fp8 ones (DYT_OPT_F32_SPLIT16 = 4; implies bwd16)
     int* pe_w_exp = nullptr; unsigned* f8_scratch = nullptr;
     bool bwd16 = false;         // "fp16x3h": the fp16x3 forward, the backward on the 16-bit mode's operands and kernels (DYT_OPT_F32_SPLIT16 = 3)
@@ -604,13 +605,17 @@ static int set_matrix(dyt_ctx* c, const float* src, void* w, void* wT, int N, in
 // fp32 mode: refresh the 16-bit [hi | lo] images of one layer's (layer < 0: the patch embedding's) frozen matrices
 static int refresh_split(dyt_ctx* c, int layer, hipStream_t s) {
     if (c->prec != 0) return 0;
-    if (c->f8) {   // forward images in the hi16 / fp8 form (the backward of this mode runs on the 16-bit copies: no transposed images)
-        if (layer < 0) return launch_split_w_f8((const float*)c->pe_w, c->pe_w3, D, D, c->pe_w_exp, c->f8_scratch, s);
+    if (c->f8) {   // forward images per class in the hi16 / fp8 or the [hi | lo] form (the backward of these modes runs on the 16-bit copies: no transposed images)
+        const int fm = c->f8_mask;
+        auto one = [&](int bit, const void* src, void* dst, int N, int K, int* ew) {
+            return (fm & bit) ? launch_split_w_f8((const float*)src, dst, N, K, ew, c->f8_scratch, s) : launch_split3_w((const float*)src, dst, N, K, s);
+        };
+        if (layer < 0) return one(16, c->pe_w, c->pe_w3, D, D, c->pe_w_exp);
         LayerW& w = c->W[layer];
-        int rc = launch_split_w_f8((const float*)w.qkv_w, w.qkv_w3, 3 * D, D, w.w_exp + 0, c->f8_scratch, s);
-        if (!rc) rc = launch_split_w_f8((const float*)w.proj_w, w.proj_w3, D, D, w.w_exp + 1, c->f8_scratch, s);
-        if (!rc) rc = launch_split_w_f8((const float*)w.fc1_w, w.fc1_w3, DM, D, w.w_exp + 2, c->f8_scratch, s);
-        if (!rc) rc = launch_split_w_f8((const float*)w.fc2_w, w.fc2_w3, D, DM, w.w_exp + 3, c->f8_scratch, s);
+        int rc = one(1, w.qkv_w, w.qkv_w3, 3 * D, D, w.w_exp + 0);
+        if (!rc) rc = one(2, w.proj_w, w.proj_w3, D, D, w.w_exp + 1);
+        if (!rc) rc = one(4, w.fc1_w, w.fc1_w3, DM, D, w.w_exp + 2);
+        if (!rc) rc = one(8, w.fc2_w, w.fc2_w3, D, DM, w.w_exp + 3);
         return rc;
     }
     if (layer < 0) return launch_split3_w((const float*)c->pe_w, c->pe_w3, D, D, s);
@@ -753,7 +758,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_FC2_CAT: c->fc2_cat = value != 0; return DYT_OK;
         case DYT_OPT_F32_SPLIT16: {   // fp32 mode only: the frozen-weight GEMMs as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
             if (c->prec != 0) { set_error("DYT_OPT_F32_SPLIT16 applies to the fp32 mode"); return DYT_ERR_ARG; }
-            if (value < 0 || value > 4) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part, 3 backward on 16-bit operands, 4 = 3 with fp8 correction products)", value); return DYT_ERR_ARG; }
+            if (value < 0 || value > 5) { set_error("DYT_OPT_F32_SPLIT16: value %d (0 off, 1 every product three-part, 2 gradient products one-part, 3 backward on 16-bit operands, 4 = 3 with fp8 correction products)", value); return DYT_ERR_ARG; }
             if (value != 0) { int rc = alloc_aux(c, value >= 3); if (rc) return rc; }
             c->split16 = value != 0;
             // 3 ("fp16x3h"): the forward as in 1 / 2 bit for bit, with what the backward needs saved in the 16-bit operand type (the hi
@@ -762,7 +767,11 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             c->bwd16 = value >= 3;
             // 4 ("fp16f8"): the forward GEMMs' two correction products hi * lo + lo * hi on the fp8 matrix cores (twice the f16 rate per k:
             // 2K- instead of 3K-equivalent contractions; per-GEMM error ~2^-15 instead of 2^-20, logits ~5e-5 from the fp32 reference)
-            c->f8 = value == 4;
+            c->f8 = value >= 4;
+            // 5 ("fp16x3q"): only the attention branch's GEMMs (qkv, proj) that way -- the MLP's K = 3072 contractions and the GELU
+            // between them carry most of the fp8 form's error: gate logits stay at the three-part level (emulated 1.0e-5 vs 4.4e-6 / 4.7e-5)
+            c->f8_mask = value == 4 ? 31 : (value == 5 ? 3 : 0);
+            if (const char* e = getenv("DYT_F8_CLASSES")) { if (c->f8) c->f8_mask = atoi(e) & 31; }   // measurement knob
             c->gs = 1.0f;
 #ifdef DYT_FP16
             if (c->bwd16) c->gs = 4096.0f;   // the fixed loss scale of the fp16 mode (dyt_ctx::gs)
@@ -888,7 +897,7 @@ static int branch_stream(dyt_ctx* c, Slot& S, hipStream_t* out) {
 static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return static_cast<char*>(base) + elems * c->at; }
 #define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
 // forward GEMM class g (0 qkv, 1 proj, 2 fc1, 3 fc2): products of its contraction (measurement knob DYT_SPLIT_FWD_PARTS="qkv,proj,fc1,fc2")
-#define SPLIT_F(a, w3, g) do { SPLIT(a, w3); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; if (c->split16 && c->f8) { (a).f8 = true; (a).w_exp = W.w_exp + (g); } } while (0)
+#define SPLIT_F(a, w3, g) do { SPLIT(a, w3); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; if (c->split16 && ((c->f8_mask >> (g)) & 1)) { (a).f8 = true; (a).w_exp = W.w_exp + (g); } } while (0)
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
@@ -1002,7 +1011,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const uint64_t* seed_dev = (flags & DYT_F_DEVICE_SEED) ? c->seed_dev : nullptr;
-    const int f8 = (c->split16 && c->f8) ? 1 : 0;   // split operands in the hi16 / fp8 form
+    const int fm = c->split16 ? c->f8_mask : 0;   // classes (qkv 1, proj 2, fc1 4, fc2 8, embed 16) whose split operands are in the hi16 / fp8 form
     const bool save16 = save && c->bwd16 && c->split16 && c->split_attn;   // "fp16x3h": what the backward reads is saved in the 16-bit operand type
     Slot& S = c->slots[slot];
     Transients& T = S.T;
@@ -1023,7 +1032,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         {
             GemmArgs a; a.A = T.xn; a.W = c->pe_w; a.M = B * NP; a.N = D; a.K = D;
             a.bias = c->pe_b; a.pos = c->pos; a.out_f32 = S.xs[0]; SPLIT(a, c->pe_w3);
-            if (c->split16 && c->f8) { a.f8 = true; a.w_exp = c->pe_w_exp; }
+            if (fm & 16) { a.f8 = true; a.w_exp = c->pe_w_exp; }
             RUN_GEMM(EPI_EMBED, a);
         }
         RUN(2, 0, launch_cls_rows(c->cls, c->pos, S.xs[0], B, s));
@@ -1038,7 +1047,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
         if (!(share0 && l == 0)) {
-            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr, f8));
+            RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr, fm & 1));
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
                 a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT_F(a, W.qkv_w3, 0); SPLIT_READY(a, T.xn3);
@@ -1048,7 +1057,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             // last block of a pass without a gate (teacher / complete model): the proj GEMM runs on the gathered cls rows of the fp32 output
             const bool tail_proj = c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate;
             const AttnSave16 sv16{L.q16, L.k16, L.v16, L.o16};   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, save16 ? &sv16 : nullptr, f8));
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, save16 ? &sv16 : nullptr, (fm >> 1) & 1));
             if (tail_proj) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
@@ -1117,9 +1126,9 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             // nothing: T.xn already holds LN2 of the cls rows
         } else if (!dense) {
             RUN(2, 0, launch_ln_gather(P, L.u, W.ln2_w, W.ln2_b, L.keep_local, counts, L.total, L.maskf, T.xn, L.st2,
-                                       L.row_src, L.dst_of, B, s, c->split16 ? T.xn3 : nullptr, f8));
+                                       L.row_src, L.dst_of, B, s, c->split16 ? T.xn3 : nullptr, (fm >> 2) & 1));
         } else {
-            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s, c->split16 ? T.xn3 : nullptr, f8));
+            RUN(2, 0, launch_ln_fwd(P, L.u, W.ln2_w, W.ln2_b, T.xn, L.st2, M, s, c->split16 ? T.xn3 : nullptr, (fm >> 2) & 1));
             // reference-style (masked) student pass: the MLP runs on every token, but its backward only has rows for the
             // kept ones (dH = mask * g) and is compacted -- it needs the dispatcher's index arrays too
             if (masked_dense && save) RUN(2, 0, launch_gather_index(L.keep_local, counts, L.total, L.maskf, L.row_src, L.dst_of, B, s));
@@ -1131,7 +1140,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.out_at = T.h1; a.out_at2 = save ? L.z : nullptr; SPLIT_F(a, W.fc1_w3, 2);
             if (save16) { a.out_at2 = L.z16; a.save16 = true; }
             if (!tail) SPLIT_READY(a, T.xn3);   // (the cls tail's LN2 rows come from ln_cls in fp32: pre-pass)
-            if (c->split16) a.out3 = T.h3;
+            if (c->split16) { a.out3 = T.h3; a.out3_f8 = (fm >> 3) & 1; }
             RUN_GEMM(EPI_FC1, a);
         }
         JOIN(sb);  // x_out now holds u + adapter(u) (two-launch form) / d_act is complete
@@ -1563,6 +1572,17 @@ extern "C" int dyt_adamw(float* param, const float* grad, float* exp_avg, float*
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     return launch_adamw(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
                         static_cast<hipStream_t>(stream));
+}
+
+// The same update, guarded like the reference's GradScaler.step (misc.py:256-272): if grad holds an inf / NaN (a 16-bit operand
+// overflowed somewhere in the step) parameters and moments are left untouched and the skip is counted.  Nothing returns to the host:
+// state (device int32[4], zero-initialised by the caller, owned by the optimizer) = {updates applied, updates skipped, flag of this
+// call, reserved}; the bias corrections use state[0] + 1 as the step.
+extern "C" int dyt_adamw_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int32_t* state,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || numel < 1) { set_error("bad argument"); return DYT_ERR_ARG; }
+    return launch_adamw_guarded(param, grad, exp_avg, exp_avg_sq, numel, state, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* targets, int batch, int flags,

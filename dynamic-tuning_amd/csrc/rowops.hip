@@ -11,6 +11,7 @@
 //   CE + KL + AdaLoss                           engine_finetune.py:52-63, models/losses.py:48-84
 //   torch.optim.AdamW                           main_image.py:285
 #include <stdlib.h>
+#include <algorithm>
 #include "kernels.h"
 #include "rowhelp.h"
 
@@ -663,6 +664,43 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
+}
+// ---- overflow-guarded update (the reference's GradScaler.step / update, misc.py:256-272: an update whose gradient holds inf / NaN is
+// ---- skipped and counted; everything stays on the device: state = {updates applied, updates skipped, non-finite flag of this call, -}
+__global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n, int* __restrict__ state) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.0e38f);   // inf and NaN
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(state + 2, 1);
+}
+__global__ void adamw_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                     float gscale, const int* __restrict__ state) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || state[2] != 0) return;   // non-finite gradient somewhere: parameters and moments stay as they are
+    const float step = (float)(state[0] + 1);
+    const float bc1 = 1.0f - powf(b1, step), rsqrt_bc2 = 1.0f / sqrtf(1.0f - powf(b2, step));
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+__global__ void adamw_count_kernel(int* __restrict__ state) {
+    if (threadIdx.x == 0) { if (state[2]) state[1] += 1; else state[0] += 1; }
+}
+int launch_adamw_guarded(float* p, const float* g, float* m, float* v, int64_t n, int* state, float lr, float b1, float b2, float eps,
+                         float wd, float gscale, hipStream_t s) {
+    if (hipMemsetAsync(state + 2, 0, sizeof(int), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return -2; }
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3((unsigned)std::min<int64_t>(256, (n + 255) / 256)), dim3(256), 0, s, g, n, state);
+    hipLaunchKernelGGL(adamw_guarded_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, gscale, state);
+    hipLaunchKernelGGL(adamw_count_kernel, dim3(1), dim3(64), 0, s, state);
+    LAUNCH_CHECK();
+    return 0;
 }
 __global__ void seed_set_kernel(uint64_t* seed_dev, uint64_t value, int advance) {
     if (threadIdx.x == 0) seed_dev[0] = advance ? seed_dev[0] + 1 : value;

@@ -55,6 +55,12 @@ class FusedAdamW:
         self.exp_avg_sq = None
         self._pending = None        # per-parameter state loaded before an engine existed
         self._synced = None         # engine whose trainables were broadcast from rank 0
+        # Overflow guard (the reference trains under fp16 autocast with a GradScaler that skips an update whose gradient holds
+        # inf / NaN, misc.py:256-272): device int32[4] = {updates applied, updates skipped, flag of the last call, -}.  The update
+        # kernel reads it, so a 16-bit overflow anywhere in a step never reaches the parameters or the moments, without a host sync.
+        self.guard = True
+        self.opt_state = None
+        self._skips_seen = 0
 
     def zero_grad(self, set_to_none=True):
         pass  # dyt_step_fwd_bwd zeroes the flat gradient buffer itself
@@ -67,6 +73,8 @@ class FusedAdamW:
             self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         elif self.exp_avg.device != eng.device:
             self.exp_avg, self.exp_avg_sq = self.exp_avg.to(eng.device), self.exp_avg_sq.to(eng.device)
+        if self.opt_state is None or self.opt_state.device != eng.device:
+            self.opt_state = torch.tensor([self.step_count, 0, 0, 0], device=eng.device, dtype=torch.int32)
         if self._pending is not None:
             for name, st in self._pending.items():
                 off, num = eng.trainable_slice(name)
@@ -96,12 +104,35 @@ class FusedAdamW:
         if max_norm is not None and max_norm > 0:
             eng.clip_grad_norm(max_norm, grad_scale)
         self.step_count += 1
-        eng.adamw(m, v, self.step_count, g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"], grad_scale)
+        if self.guard:   # a gradient with inf / NaN (NaN also after clipping by a NaN norm) leaves parameters and moments untouched
+            eng.adamw_guarded(m, v, self.opt_state, g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"], grad_scale)
+        else:
+            eng.adamw(m, v, self.step_count, g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"], grad_scale)
+
+    def applied_and_skipped(self):
+        """(updates applied, updates skipped because of a non-finite gradient) -- reads the device-side counters (a host sync)."""
+        if self.opt_state is None:
+            return self.step_count, 0
+        a, k = self.opt_state[:2].tolist()
+        return int(a), int(k)
+
+    def overflow_backoff(self, eng):
+        """GradScaler.update's back-off (misc.py:272), at the loop's own sync points: if updates were skipped since the last call the
+        library's fixed gradient scale (2^12 on the 16-bit gradient operands) is halved; returns the number of new skips."""
+        applied, skipped = self.applied_and_skipped()
+        self.step_count = applied
+        new = skipped - self._skips_seen
+        self._skips_seen = skipped
+        if new > 0 and getattr(eng, "grad_scale_log2", None) is not None and eng.grad_scale_log2 > 0:
+            eng.set_grad_scale_log2(eng.grad_scale_log2 - 1)
+        return new
 
     def state_dict(self):
         names = _trainable_names(self.model)
         eng = self.model._engine
         state = {}
+        if self.guard and self.opt_state is not None:
+            self.step_count = self.applied_and_skipped()[0]   # skipped updates do not count (GradScaler.step does not call optimizer.step)
         if self.step_count > 0 or self._pending is not None:
             if eng is not None:
                 m, v = self._state(eng)
@@ -136,6 +167,7 @@ class FusedAdamW:
             pending[name] = dict(exp_avg=st["exp_avg"].detach(), exp_avg_sq=st["exp_avg_sq"].detach())
             step = max(step, int(float(st["step"])))
         self.step_count = step
+        self.opt_state = None   # re-created with the loaded step count
         self._pending = pending if pending else None
         if self._pending is not None and self.model._engine is not None:
             self._state(self.model._engine)
@@ -256,6 +288,10 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         pending += 1
         if (it + 1) % print_freq == 0 or it + 1 == nsteps:
             host = acc.tolist()  # the only host<->device sync of the loop
+            new_skips = optimizer.overflow_backoff(m._engine) if optimizer.guard and not use_graph else 0
+            if new_skips and logger is not None:
+                logger.info("%d update(s) skipped: non-finite gradient (16-bit overflow); gradient scale now 2^%s" % (
+                    new_skips, getattr(m._engine, "grad_scale_log2", "?")))
             acc.zero_()
             for i, k in enumerate(LOSS_KEYS):
                 sums[k] += host[i]

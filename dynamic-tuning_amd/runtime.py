@@ -10,14 +10,14 @@ import ctypes
 import torch
 
 from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
-                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16F8, PREC_FP16X3F, PREC_FP16X3H, PREC_FP32,
+                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16F8, PREC_FP16X3F, PREC_FP16X3H, PREC_FP16X3Q, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
 
 
 def parse_precision(p):
-    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H, PREC_FP16F8):
+    if p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X3F, PREC_FP16X3H, PREC_FP16F8, PREC_FP16X3Q):
         return p
     p = str(p).lower()
     if p in ("fp32", "float32", "exact"):
@@ -34,7 +34,9 @@ def parse_precision(p):
         return PREC_FP16X3H
     if p in ("fp16f8", "fp16+fp8"):
         return PREC_FP16F8
-    raise ValueError("precision must be 'fp32', 'fp16x3', 'fp16x3f', 'fp16x3h', 'fp16f8', 'bf16' or 'fp16', got %r" % (p,))
+    if p in ("fp16x3q",):
+        return PREC_FP16X3Q
+    raise ValueError("precision must be 'fp32', 'fp16x3', 'fp16x3f', 'fp16x3h', 'fp16x3q', 'fp16f8', 'bf16' or 'fp16', got %r" % (p,))
 
 
 class DyTEngine:
@@ -49,7 +51,7 @@ class DyTEngine:
         # "fp16x3f" = the same with the gradient products as the hi * hi term alone (forward bit-identical to "fp16x3")
         # "fp16x3h" = the same forward again, the backward pass on 16-bit operands with the fp16 mode's kernels
         # "fp16f8" = "fp16x3h" with the two correction products of every forward GEMM on the fp8 matrix cores (not bit-identical to fp16x3)
-        split = {PREC_FP16X3: 1, PREC_FP16X3F: 2, PREC_FP16X3H: 3, PREC_FP16F8: 4}.get(self.precision, 0)
+        split = {PREC_FP16X3: 1, PREC_FP16X3F: 2, PREC_FP16X3H: 3, PREC_FP16F8: 4, PREC_FP16X3Q: 5}.get(self.precision, 0)
         lib_prec = PREC_BF16 if self.precision == PREC_FP16 else (PREC_FP32 if split else self.precision)
         self.cfg = Config(int(num_classes), int(ffn_num), int(depth), lib_prec,
                           int(max_batch), int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
@@ -74,6 +76,8 @@ class DyTEngine:
         self._rccl_comm = None     # ncclComm_t of dyt_allreduce_grads (created on first use)
         self.generation = [0] * int(slots)   # bumped by every saving forward into a slot (stale-backward detection)
         self.depth, self.num_classes, self.ffn_num = int(depth), int(num_classes), int(ffn_num)
+        # power of two the gradient carries wherever the library holds it in 16 bits (IEEE-half builds: 2^12, dyt_ctx::gs); None: no scaling
+        self.grad_scale_log2 = 12 if self.precision in (PREC_FP16, PREC_FP16X3H, PREC_FP16F8, PREC_FP16X3Q) else None
 
     def _ck(self, rc):
         check(rc, self.L)
@@ -252,6 +256,13 @@ class DyTEngine:
             self._ck(self.L.dyt_adamw(ptr(self.flat), ptr(self.grad), ptr(exp_avg), ptr(exp_avg_sq), self.n_train,
                                    int(step), lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr()))
 
+    def adamw_guarded(self, exp_avg, exp_avg_sq, state, lr, weight_decay=0.01, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """The same update, skipped (and counted in `state`, a device int32[4]) when the gradient holds inf / NaN: GradScaler.step
+        semantics (misc.py:256-272) without a host sync; the step count of the bias corrections lives in state[0]."""
+        with torch.cuda.device(self.device):
+            self._ck(self.L.dyt_adamw_guarded(ptr(self.flat), ptr(self.grad), ptr(exp_avg), ptr(exp_avg_sq), self.n_train, ptr(state),
+                                           lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr()))
+
     def clip_grad_norm(self, max_norm, pre_scale=1.0, norm_out=None):
         """torch.nn.utils.clip_grad_norm_ on the flat gradient (misc.py:262-266); pre_scale = the factor AdamW applies."""
         with torch.cuda.device(self.device):
@@ -293,6 +304,13 @@ class DyTEngine:
             self._ck(self.L.dyt_debug_dispatch(self.h, int(slot), int(layer), ptr(row_src), ptr(dst_of), ptr(counts), ptr(total),
                                             stream_ptr()))
         return row_src, dst_of, counts, total
+
+    def set_grad_scale_log2(self, k):
+        """DYT_OPT_GRAD_SCALE_LOG2: the fixed loss scale of the 16-bit gradient operands (never visible in a returned gradient)."""
+        from _lib import OPT_GRAD_SCALE_LOG2
+        self.set_option(OPT_GRAD_SCALE_LOG2, int(k))
+        self.grad_scale_log2 = int(k)
+        self._graphs = {}   # captured steps carry the old factor in their kernel arguments
 
     def set_option(self, option, value):
         """_lib.OPT_STREAM_OVERLAP / OPT_CLS_TAIL / OPT_SHARE_BLOCK0 (scheduling only; results do not change);

@@ -233,6 +233,13 @@ int dyt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq
               int step, float lr, float beta1, float beta2, float eps, float weight_decay,
               float grad_scale, void* stream);
 
+/* The same update guarded like the reference's NativeScaler / GradScaler.step (misc.py:256-272; the reference trains under fp16 autocast):
+ * when grad holds an inf or NaN -- a 16-bit operand overflowed somewhere in the step -- parameters and moments are left untouched and
+ * the skip is counted, without a host round trip.  state = device int32[4], zero-initialised and owned by the caller's optimizer:
+ * {updates applied, updates skipped, non-finite flag of this call, reserved}; the bias corrections use state[0] + 1 as the step. */
+int dyt_adamw_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int32_t* state,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
 /* One whole fine-tune step body (engine_finetune.py:47-79 without the host syncs): student +
  * teacher forward, loss, one backward over both passes into grad_flat (zeroed first).  The caller
  * all-reduces grad_flat (DDP, main_image.py:280-282) and then calls dyt_adamw. */

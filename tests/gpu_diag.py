@@ -56,7 +56,7 @@ def D_adamw(eng, lr, wd):
 #   logits: max abs error; flips: gate decisions that differ (eval fixture 9408 decisions / training fixture 4704);
 #   tok_logits: eval token_logits (a flipped token changes every later block's gate input); loss: relative
 GRAD_H = 5e-3
-SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16f8")
+SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16x3q", "fp16f8")
 ALL_PRECS = ("fp32",) + SPLIT_MODES + ("fp16", "bf16")
 TOL = {
     "fp32": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4),
@@ -65,6 +65,7 @@ TOL = {
     "fp16x3": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=2e-3),
     "fp16x3f": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=2e-3),
     "fp16x3h": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=GRAD_H),
+    "fp16x3q": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=GRAD_H),
     "fp16f8": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=2e-4, grad=GRAD_H),
     "fp16": dict(logits=5e-3, eval_flips=6, step_flips=2, tok_logits=0.5, loss=3e-3, vlogits=2e-3, vflips=6, vstep_flips=4, vloss=5e-3),
     "bf16": dict(logits=0.03, eval_flips=30, step_flips=8, tok_logits=1.0, loss=0.02, vlogits=8e-3, vflips=30, vstep_flips=12, vloss=0.05),
@@ -83,6 +84,14 @@ def grad_kind(name):
 def report_grads(tag, prec, items):
     """items: (name, got, ref, floor).  fp32: one line, worst tensor vs 2e-3.  bf16: one line per tensor kind vs its own bound."""
     worst = {}
+    if prec in SPLIT_MODES and prec != "fp16x3":
+        # one-part / 16-bit gradient products: the 12 gate BIAS gradients (each one number, a sum of signed per-token terms) are judged as
+        # one 12-vector, as tests/test_gpu_round2.py does -- the relative error of a single cancelling sum is ill-conditioned
+        sc = [(n, got, ref, floor) for n, got, ref, floor in items if ref.numel() == 1]
+        items = [it for it in items if it[2].numel() > 1]
+        if sc:
+            items.append(("mlp_token_select.mlp_head.bias (12 blocks)", torch.stack([g.reshape(()) for _, g, _, _ in sc]),
+                          torch.stack([r.reshape(()) for _, _, r, _ in sc]), max(f for _, _, _, f in sc)))
     for n, got, ref, floor in items:
         e = float((got - ref).norm() / max(float(ref.norm()), floor))
         k = grad_kind(n) if prec in ("fp16", "bf16") else "all"

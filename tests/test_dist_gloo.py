@@ -66,6 +66,14 @@ def _worker(rank, world, port, q):
             p, m2, v2 = O.adamw_update(self.flat, self.grad * grad_scale, m, v, step, lr, wd, b1, b2, eps)
             self.flat.copy_(p); m.copy_(m2); v.copy_(v2)
 
+        def adamw_guarded(self, m, v, state, lr, wd, b1, b2, eps, grad_scale):   # dyt_adamw_guarded's contract on the CPU stand-in
+            if not bool(torch.isfinite(self.grad).all()):
+                state[1] += 1; state[2] = 1
+                return
+            state[2] = 0
+            self.adamw(m, v, int(state[0]) + 1, lr, wd, b1, b2, eps, grad_scale)
+            state[0] += 1
+
     model = Model()
     model._engine = eng = CpuEngine(rank)
     opt = E.FusedAdamW(model, lr=1e-2, weight_decay=0.1)
@@ -77,6 +85,15 @@ def _worker(rank, world, port, q):
         opt.step(grad_scale=scale)
     out["flat"] = eng.flat.clone()
     out["opt_sd_step"] = int(opt.state_dict()["state"][1]["step"])
+    # an overflowed step on ONE rank: the SUM all-reduce carries the NaN to every rank, every rank skips the update (GradScaler.step)
+    eng.grad.copy_(shard_grads[rank])
+    if rank == 1:
+        eng.grad[3] = float("inf")
+    scale = E.allreduce_grads(eng)
+    opt.step(grad_scale=scale)
+    out["flat_after_overflow"] = eng.flat.clone()
+    out["applied_skipped"] = opt.applied_and_skipped()
+    out["sd_step_after_overflow"] = int(opt.state_dict()["state"][1]["step"])
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -110,6 +127,9 @@ def test_gather_and_grad_allreduce_world2():
     assert torch.equal(res[0]["flat"], res[1]["flat"])
     assert float((res[0]["flat"] - p).abs().max()) < 1e-6
     assert res[0]["opt_sd_step"] == 2
+    for r in (0, 1):
+        assert torch.equal(res[r]["flat_after_overflow"], res[r]["flat"]) and res[r]["applied_skipped"] == (2, 1)
+        assert res[r]["sd_step_after_overflow"] == 2
 
 
 def test_single_process_is_a_noop():

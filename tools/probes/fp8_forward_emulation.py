@@ -49,6 +49,9 @@ def emu_linear(x, w, b=None):
     frozen = w.shape[0] in (2304, 3072) or (w.shape[0] == 768 and w.shape[1] in (768, 3072))
     if kind == "exact" or not frozen:
         return _linear(x, w, b)
+    if ":" in kind:   # "fp8c:qkv,fc1" = fp8 corrections for the named classes, three half products for the others
+        cls = {(2304, 768): "qkv", (768, 768): "proj", (3072, 768): "fc1", (768, 3072): "fc2"}[tuple(w.shape)]
+        kind = "fp8c" if cls in kind.split(":")[1].split(",") else "fp16x3"
     xh, xl = split16(x)
     wh, wl = split16(w)
     mm = lambda a, c: (a.double() @ c.double().T).float()
@@ -76,13 +79,14 @@ keep = synth.make_dropout_masks(B, r, seed=33)
 sd = synth.make_state_dict(C, r, seed=0, kind="test", gate_bias=0.85)
 res = {}
 with torch.no_grad():
-    for kind in ("exact", "fp16", "fp16x3", "fp8c", "fp6c", "fp4c"):
+    KINDS = ("fp16", "fp16x3", "fp8c", "fp6c", "fp4c") if len(sys.argv) < 3 else tuple(sys.argv[2:])
+    for kind in ("exact",) + KINDS:
         MODE["kind"] = kind
         ls, tok = O.forward(sd, x, g1[0], g2[0], keep[0], scale=0.1, complete_model=False, training=True)[:2]
         lt = O.forward(sd, x, g1[1], g2[1], keep[1], scale=0.1, complete_model=True, training=True)[0]
         res[kind] = (ls, lt, tok["token_select"], tok["token_logits"])
 ref = res["exact"]
-for kind in ("fp16", "fp16x3", "fp8c", "fp6c", "fp4c"):
+for kind in KINDS:
     a = res[kind]
     flips = int((a[2] != ref[2]).sum())
     print("%-7s logits student %.2e teacher %.2e   gate logits %.2e   flips %d of %d" % (
