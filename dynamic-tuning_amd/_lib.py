@@ -124,6 +124,7 @@ SYMBOLS = {
     "dyt_adapter_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _u64, _i, _vp]),
     "dyt_adapter_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _u64, _i, _vp]),
     "dyt_mlp_gathered_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "dyt_mlp_gathered_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dyt_gate_compact": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dyt_gemm_bf16_raw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_gemm_f32_raw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -2049,6 +2049,61 @@ extern "C" int dyt_mlp_gathered_fwd(dyt_ctx* c, int layer, const float* u, const
     return DYT_OK;
 }
 
+// Its backward for an upstream gradient dy [B*197,768] (the gradient w.r.t. x of dyt_mlp_gathered_fwd): du [B*197,768] += the gradient that
+// reaches u THROUGH the gathered MLP (LN2 backward of fc1^T (gelu'(z) * (fc2^T dy)) for the kept tokens, nothing for the dropped ones;
+// the residual path du += dy is the caller's).  Recomputes the forward up to gelu'(z); frozen weights: no weight gradients.
+extern "C" int dyt_mlp_gathered_bwd(dyt_ctx* c, int layer, const float* u, const float* mask, const float* dy, float* du, int batch,
+                                    void* stream) {
+    if (!c || !u || !mask || !dy || !du || layer < 0 || layer >= c->cfg.depth || batch < 1 || batch > c->cfg.max_batch) { set_error("bad argument"); return DYT_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int P = c->prec, M = batch * NT;
+    const float gs = P == 0 ? 1.0f : c->gs;
+    const LayerW& W = c->W[layer];
+    Scratch sc;
+    int* keep_local = (int*)sc.get((size_t)M * 4); int* counts = (int*)sc.get((size_t)batch * 4); int* total = (int*)sc.get(16);
+    int* row_src = (int*)sc.get((size_t)M * 4); int* dst_of = (int*)sc.get((size_t)M * 4);
+    float2* st = (float2*)sc.get((size_t)M * sizeof(float2));
+    void* xn = sc.get((size_t)M * D * c->at); void* h1 = sc.get((size_t)M * DM * c->at); void* gp = sc.get((size_t)M * DM * c->at);
+    void* g_at = P == 0 ? nullptr : sc.get((size_t)M * D * c->at);
+    void* dZ = sc.get((size_t)M * DM * c->at); void* dA2 = sc.get((size_t)M * D * c->at);
+    float* partial = (float*)sc.get((size_t)((M + 31) / 32) * (D + 1) * sizeof(float));
+    if (!keep_local || !counts || !total || !row_src || !dst_of || !st || !xn || !h1 || !gp || (P != 0 && !g_at) || !dZ || !dA2 || !partial) {
+        set_error("scratch alloc failed");
+        return DYT_ERR_HIP;
+    }
+    hipLaunchKernelGGL(mask_to_keep_kernel, dim3(batch), dim3(256), 0, s, mask, keep_local, counts);
+    DYT_HIP_CHECK(hipGetLastError());
+    int rc = launch_ln_gather(P, u, W.ln2_w, W.ln2_b, keep_local, counts, total, mask, xn, st, row_src, dst_of, batch, s);
+    if (rc) return rc;
+    {
+        GemmArgs a; a.A = xn; a.W = W.fc1_w; a.Wp = W.fc1_wp; a.M = M; a.N = DM; a.K = D; a.m_dev = total; a.bias = W.fc1_b; a.out_at = h1; a.out_at2 = gp;
+        rc = launch_gemm(P, EPI_FC1, a, s); if (rc) return rc;
+    }
+    if (P != 0) {
+        BwdPrepArgs a; a.g = dy; a.h = nullptr; a.dst_of = nullptr; a.row_mask = nullptr; a.g_at = g_at; a.dH = nullptr; a.dmask = nullptr; a.M = M; a.gs = gs;
+        rc = launch_bwd_prep(P, a, s); if (rc) return rc;
+    }
+    {
+        GemmArgs a; a.A = P == 0 ? (const void*)dy : (const void*)g_at; a.W = W.fc2_wT; a.Wp = W.fc2_wTp; a.M = M; a.N = DM; a.K = D; a.m_dev = total;
+        a.aux_at = gp; a.a_map = row_src; a.out_at = dZ;
+        rc = launch_gemm(P, EPI_GELU_BWD, a, s); if (rc) return rc;
+    }
+    {
+        GemmArgs a; a.A = dZ; a.W = W.fc1_wT; a.Wp = W.fc1_wTp; a.M = M; a.N = D; a.K = DM; a.m_dev = total; a.out_at = dA2;
+        rc = launch_gemm(P, EPI_STORE_AT, a, s); if (rc) return rc;
+    }
+    {
+        TokBwdArgs a;
+        a.du = du; a.dA2 = dA2; a.dst_of = dst_of; a.u = u; a.stats2 = st; a.ln2_w = W.ln2_w; a.gate_w = nullptr; a.soft = nullptr; a.maskf = mask;
+        a.dmask = nullptr; a.dtoken_select = nullptr; a.dtoken_logits = nullptr; a.dtok = nullptr; a.out_stride = 0; a.training = 0; a.tau = 1.0f;
+        a.du_at = nullptr; a.partial = partial; a.M = M; a.write_du = 1; a.gs = gs; a.inv_gs = 1.0f / gs;
+        int nblk = 0;
+        rc = launch_tok_bwd(P, a, &nblk, s); if (rc) return rc;
+    }
+    DYT_HIP_CHECK(hipStreamSynchronize(s));
+    return DYT_OK;
+}
+
 extern "C" int dyt_gate_compact(const float* u, const float* w, const float* b, const float* g1, const float* g2, int batch,
                                 int training, float tau, float threshold, float* mask, float* logits, int32_t* keep_idx,
                                 int32_t* counts, int32_t* total, void* stream) {

@@ -191,8 +191,8 @@ class VisionTransformer(nn.Module):
         if drop_path_rate:
             raise NotImplementedError("drop_path_rate=%r: train_IN21K.sh / train_vtab.sh run with drop_path 0.0" % drop_path_rate)
         assert tuning_config is not None and select_config is not None
-        if not (select_config.open and select_config.keep_layers == 0):
-            raise NotImplementedError("select_config must be open with keep_layers=0 (main_image.py:196-198)")
+        # select_config.open / keep_layers reach the reference's Block only as its `select` argument (:311), which Block.__init__ never
+        # reads (:106, :138: every block gets its TokenSelect): they change nothing there, so every value is accepted here as well
         if _cfg_get(tuning_config, "ffn_option", "parallel") != "parallel":
             raise NotImplementedError("ffn_option must be 'parallel'")
         self.tuning_config = tuning_config

@@ -301,6 +301,11 @@ int dyt_adapter_bwd(const float* x, const float* down_w, const float* down_b, co
  * may be NULL) = number of gathered tokens */
 int dyt_mlp_gathered_fwd(dyt_ctx* ctx, int layer, const float* u, const float* mask, float* x, int batch, int32_t* total_out,
                          void* stream);
+/* Its backward (dyt_mlp_gathered_bwd): for dy = the gradient w.r.t. x above, du [B*197,768] += the gradient that reaches u
+ * through the gathered MLP of block `layer` -- LN2 backward of fc1^T (gelu'(z) * (fc2^T dy)) scattered back to the kept tokens, nothing
+ * for the dropped ones (the residual path du += dy is the caller's; frozen weights: no weight gradients).  Autograd of
+ * models/model_speed_test.py:297-305.  Unit-test entry: recomputes the forward, allocates scratch and synchronises. */
+int dyt_mlp_gathered_bwd(dyt_ctx* ctx, int layer, const float* u, const float* mask, const float* dy, float* du, int batch, void* stream);
 
 /* One nn.Linear (c = a w^T + bias; a [M,K], w [N,K], bias [N] or NULL, c [M,N], fp32 device pointers) through the split forms of the
  * fp32 mode: form 3 = every product as three IEEE-half products (hi*hi + hi*lo + lo*hi), form 8 = hi*hi on the f16 matrix cores plus

@@ -819,9 +819,26 @@ def test_block_submodule_forward_vs_oracle(precision):
     u = x.reshape(B * 197, 768).contiguous().cuda()
     out = u.clone()
     total = torch.zeros(1, dtype=torch.int32, device="cuda")
-    _lib.check(_lib.lib().dyt_mlp_gathered_fwd(eng.h, 0, _lib.ptr(u), _lib.ptr(mask.reshape(-1).contiguous().cuda()), _lib.ptr(out), B,
+    _lib.check(eng.L.dyt_mlp_gathered_fwd(eng.h, 0, _lib.ptr(u), _lib.ptr(mask.reshape(-1).contiguous().cuda()), _lib.ptr(out), B,
                                                 _lib.ptr(total), _lib.stream_ptr()))
     assert int(total.item()) == int(mask.sum())
     h = O.mlp(osd, "blocks.0.", O.layer_norm(x, osd["blocks.0.norm2.weight"], osd["blocks.0.norm2.bias"])) * mask.unsqueeze(-1)
     want = (x + h).reshape(B * 197, 768)
     assert float((out.cpu() - want).abs().max()) < ltol * max(1.0, float(want.abs().max()))
+    # ... and its backward (dyt_mlp_gathered_bwd): du += d/du <dy, scatter(mlp(LN2(gather(u))))> against autograd of the oracle's twin
+    dy = torch.randn(B * 197, 768, generator=g) * 1e-2
+    xr = x.clone().requires_grad_(True)
+    hr = O.mlp(osd, "blocks.0.", O.layer_norm(xr, osd["blocks.0.norm2.weight"], osd["blocks.0.norm2.bias"])) * mask.unsqueeze(-1)
+    (hr.reshape(B * 197, 768) * dy).sum().backward()
+    base = torch.randn(B * 197, 768, generator=g) * 1e-3
+    du = base.clone().cuda()
+    lib = blk._block_engine(B, torch.device("cuda", 0)).L
+    _lib.check(lib.dyt_mlp_gathered_bwd(eng.h, 0, _lib.ptr(u), _lib.ptr(mask.reshape(-1).contiguous().cuda()), _lib.ptr(dy.cuda().contiguous()),
+                                        _lib.ptr(du), B, _lib.stream_ptr()), lib)
+    got_du = du.cpu() - base
+    ref_du = xr.grad.reshape(B * 197, 768)
+    dropped = mask.reshape(-1) == 0
+    assert float(got_du[dropped].abs().max()) == 0.0                      # no gradient reaches a dropped token through the MLP
+    e = float((got_du - ref_du).norm() / ref_du.norm())
+    print("dyt_mlp_gathered_bwd %s: rel-L2 %.2e" % (precision, e))
+    assert e < (1e-4 if precision == "fp32" else 2e-2), e

@@ -160,3 +160,41 @@ def test_overflowed_step_is_skipped_on_the_device():
         torch.cuda.empty_cache()
     assert res["clean"][2] == (1, 0) and res["overflow_first"][2] == (1, 1)
     assert torch.equal(res["clean"][0], res["overflow_first"][0]) and torch.equal(res["clean"][1], res["overflow_first"][1])
+
+
+def test_upper_gradient_allreduce_really_overlaps_the_backward():
+    """Multi-GPU path on one GPU (1-rank RCCL): the all-reduce of part 0 of the flat gradient (head + blocks >= 6, final half-way
+    through the backward pass) is issued on the communication stream behind dyt_stream_wait_grads' event and must COMPLETE while
+    the frozen-backbone backward of the lower blocks is still running on the step's stream -- device timestamps, not equality of
+    results (what DDP's bucket hooks do inside loss.backward(), misc.py:258-259 / main_image.py:280-282)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 64
+        m, _ = _bench_model("fp16", "compact", B, 0.85)
+        m.train()
+        x, y = synth.make_batch(B, 100, seed=95)
+        x, y = x.cuda(), y.cuda()
+        eng = m.engine(B, torch.device("cuda", 0))
+        gaps = []
+        for it in range(4):
+            t0, bwd_end, comm_end = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            t0.record()
+            eng.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, seed=10 + it)
+            bwd_end.record()                                   # the step's stream: after the last backward kernel and the gradient sums
+            eng.allreduce_native(overlap=True)                 # part 0 on the comm stream (waits for the device-side event), part 1 here
+            comm_end.record(eng.comm_stream())                 # the comm stream: after the part-0 all-reduce
+            torch.cuda.synchronize()
+            gaps.append((t0.elapsed_time(comm_end), t0.elapsed_time(bwd_end)))
+        print("part-0 all-reduce done / backward done, ms after the step's start:", ["%.2f / %.2f" % g for g in gaps])
+        for done_comm, done_bwd in gaps[1:]:                   # (the first iteration creates the communicator)
+            assert done_comm < done_bwd - 0.5, gaps            # finished at least 0.5 ms before the backward did
+            assert done_comm > 0.3 * done_bwd, gaps            # ... and not before the upper blocks' backward can have run
+    finally:
+        dist.destroy_process_group()

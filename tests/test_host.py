@@ -81,6 +81,12 @@ def test_unsupported_configs_are_rejected():
     from models.dynamic_adapter import Adapter
     with pytest.raises(NotImplementedError):
         Adapter(d_model=768, bottleneck=8, adapter_layernorm_option="in")
+    # select_config.keep_layers / open: the reference hands them to Block as `select`, which Block.__init__ never reads
+    # (models/vision_transformer_IN21K.py:106,138,311) -- every value builds the same model there, and here
+    a = VisionTransformer(tuning_config=tuning, select_config=Cfg(open=True, keep_layers=4))
+    b = VisionTransformer(tuning_config=tuning, select_config=Cfg(open=False, keep_layers=0))
+    assert [k for k, _ in a.named_parameters()] == [k for k, _ in b.named_parameters()] and len(a.blocks) == 12
+    assert all(blk.mlp_token_select is not None for blk in a.blocks)
 
 
 def test_key_mapping_covers_state_dict():
