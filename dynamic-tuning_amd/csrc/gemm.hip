@@ -111,7 +111,9 @@ struct EpiBiasResid {
     }
 };
 
-template <class AT, bool HAS_GP, class GT = AT>   // GT: type gelu'(z) is saved in (GemmArgs::save16: 16 bits under fp32 arithmetic)
+// FAST (fp32 functor of the split forms): Phi by Abramowitz-Stegun 26.2.17 (the 16-bit functor's: |h err| 4e-7, |gelu' err| 3e-7 absolute,
+// one v_exp + one v_rcp per element, packed fp32) instead of erff + expf -- below the split GEMMs' own 1e-6 and a tenth of the VALU work
+template <class AT, bool HAS_GP, class GT = AT, bool FAST = false>   // GT: type gelu'(z) is saved in (GemmArgs::save16: 16 bits under fp32 arithmetic)
 struct EpiFc1 {
     const float* bias; AT* h; GT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
     bf16* h3;   // split fp32 form: h goes out as the 16-bit hi / hi / lo operand of the fc2 GEMM ([rows, 3 ld]) instead of as fp32
@@ -123,7 +125,7 @@ struct EpiFc1 {
         const size_t o = (size_t)row * ld + col;
         float hv[4], gv[4];
         if (HAS_GP) {
-            if constexpr (sizeof(AT) == 2) {   // two elements per packed-fp32 issue slot
+            if constexpr (sizeof(AT) == 2 || FAST) {   // two elements per packed-fp32 issue slot
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
                     f32x2 h2, g2;
@@ -137,7 +139,7 @@ struct EpiFc1 {
             store4_nt(gp + o, gv[0], gv[1], gv[2], gv[3]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = gelu_fwd<AT>(a[i] + c.b[i]);
+            for (int i = 0; i < 4; ++i) hv[i] = FAST ? gelu_fwd<bf16>(a[i] + c.b[i]) : gelu_fwd<AT>(a[i] + c.b[i]);
         }
         if constexpr (sizeof(AT) == 4) {
             if (h3) {
@@ -1129,7 +1131,7 @@ static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
 template <class Epi> struct F8Epi : std::false_type {};
 template <> struct F8Epi<EpiQKV<float>> : std::true_type {};
 template <class OT> struct F8Epi<EpiBiasResid<float, OT>> : std::true_type {};
-template <bool G, class GT> struct F8Epi<EpiFc1<float, G, GT>> : std::true_type {};
+template <bool G, class GT, bool F> struct F8Epi<EpiFc1<float, G, GT, F>> : std::true_type {};
 template <bool P, class HT> struct F8Epi<EpiFc2<float, P, HT>> : std::true_type {};
 template <> struct F8Epi<EpiAdUp<true>> : std::true_type {};    // cls-row proj of the teacher's last block
 template <> struct F8Epi<EpiEmbed> : std::true_type {};
@@ -1153,7 +1155,11 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N}, s); }
             return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1:
-            if constexpr (SPLIT) { if (a.save16 && a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, bf16>{a.bias, (AT*)a.out_at, (bf16*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s); }
+            if constexpr (SPLIT) {   // the split forms take the A&S GELU (EpiFc1<FAST>): 42.7 vs 43.1 ms/step, logits vs the oracle unchanged (2.4e-5 / 6e-6)
+                if (a.save16 && a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, bf16, true>{a.bias, (AT*)a.out_at, (bf16*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s);
+                if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s);
+                return run<AT, SPLIT>(a, EpiFc1<AT, false, AT, true>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3, a.out3_f8}, s);
+            }
             if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s);
             return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3, a.out3_f8}, s);
         case EPI_FC2: {
