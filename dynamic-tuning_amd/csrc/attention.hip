@@ -932,11 +932,13 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
         hi[4 + i] = s1.hi; lo[4 + i] = s1.lo;
     }
 }
+template <bool PLANES>   // PLANES: q / k / v arrive as 16-bit hi (q16 / k16 / v16) + lo planes written by the QKV epilogue: staged without conversion
 __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, float* __restrict__ out,
                                                              float* __restrict__ lse, int nheads, bf16* __restrict__ out3,
                                                              bf16* __restrict__ q16, bf16* __restrict__ k16, bf16* __restrict__ v16,
-                                                             bf16* __restrict__ o16, int f8) {
+                                                             bf16* __restrict__ o16, int f8, const bf16* __restrict__ qlo,
+                                                             const bf16* __restrict__ klo, const bf16* __restrict__ vlo) {
     // q16 / k16 / v16 / o16 (optional): the hi parts = the 16-bit roundings of q, k, v and the output, saved for a backward pass that
     // runs on 16-bit operands ("fp16x3h"); `out` may then be null (the proj GEMM reads out3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -955,6 +957,14 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int t = tid + u * 448, pr = t >> 3, c = t & 7, r0 = pr * 2;
+            bf16x8 ah, al, bhh, bl, vah, val, vbh, vbl;
+            if constexpr (PLANES) {
+                const size_t o0 = ((size_t)bh * NT + min(r0, NT - 1)) * HD + c * 8, o1 = ((size_t)bh * NT + min(r0 + 1, NT - 1)) * HD + c * 8;
+                ah = *reinterpret_cast<const bf16x8*>(k16 + o0); al = *reinterpret_cast<const bf16x8*>(klo + o0);
+                bhh = *reinterpret_cast<const bf16x8*>(k16 + o1); bl = *reinterpret_cast<const bf16x8*>(klo + o1);
+                vah = *reinterpret_cast<const bf16x8*>(v16 + o0); val = *reinterpret_cast<const bf16x8*>(vlo + o0);
+                vbh = *reinterpret_cast<const bf16x8*>(v16 + o1); vbl = *reinterpret_cast<const bf16x8*>(vlo + o1);
+            } else {
             const float* k0 = kb + (size_t)min(r0, NT - 1) * HD + c * 8;
             const float* k1 = kb + (size_t)min(r0 + 1, NT - 1) * HD + c * 8;
             const float* v0 = vb + (size_t)min(r0, NT - 1) * HD + c * 8;
@@ -963,22 +973,23 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
             const f32x4 kb0 = *reinterpret_cast<const f32x4*>(k1), kb1 = *reinterpret_cast<const f32x4*>(k1 + 4);
             const f32x4 va0 = *reinterpret_cast<const f32x4*>(v0), va1 = *reinterpret_cast<const f32x4*>(v0 + 4);
             const f32x4 vb0 = *reinterpret_cast<const f32x4*>(v1), vb1 = *reinterpret_cast<const f32x4*>(v1 + 4);
-            bf16x8 ah, al, bhh, bl;
             split8(ka0, ka1, ah, al); split8(kb0, kb1, bhh, bl);
+            split8(va0, va1, vah, val); split8(vb0, vb1, vbh, vbl);
+            }
             if (r0 >= NT) { ah = zero8(); al = zero8(); }
             if (r0 + 1 >= NT) { bhh = zero8(); bl = zero8(); }
             *reinterpret_cast<bf16x8*>(Kh + r0 * RLD + c * 8) = ah;
             *reinterpret_cast<bf16x8*>(Kl + r0 * RLD + c * 8) = al;
             *reinterpret_cast<bf16x8*>(Kh + (r0 + 1) * RLD + c * 8) = bhh;
             *reinterpret_cast<bf16x8*>(Kl + (r0 + 1) * RLD + c * 8) = bl;
-            if (k16) {
+            if (!PLANES && k16) {
                 if (r0 < NT) *reinterpret_cast<bf16x8*>(k16 + ((size_t)bh * NT + r0) * HD + c * 8) = ah;
                 if (r0 + 1 < NT) *reinterpret_cast<bf16x8*>(k16 + ((size_t)bh * NT + r0 + 1) * HD + c * 8) = bhh;
             }
-            split8(va0, va1, ah, al); split8(vb0, vb1, bhh, bl);
+            ah = vah; al = val; bhh = vbh; bl = vbl;
             if (r0 >= NT) { ah = zero8(); al = zero8(); }
             if (r0 + 1 >= NT) { bhh = zero8(); bl = zero8(); }
-            if (v16) {
+            if (!PLANES && v16) {
                 if (r0 < NT) *reinterpret_cast<bf16x8*>(v16 + ((size_t)bh * NT + r0) * HD + c * 8) = ah;
                 if (r0 + 1 < NT) *reinterpret_cast<bf16x8*>(v16 + ((size_t)bh * NT + r0 + 1) * HD + c * 8) = bhh;
             }
@@ -993,9 +1004,14 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
         bf16x8 qh[4], ql[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (PLANES) {
+                const size_t o = ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8;
+                qh[ks] = *reinterpret_cast<const bf16x8*>(q16 + o); ql[ks] = *reinterpret_cast<const bf16x8*>(qlo + o);
+            } else {
             const float* qp = q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8;
             split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[ks], ql[ks]);
             if (q16 && qrow < NT) *reinterpret_cast<bf16x8*>(q16 + ((size_t)bh * NT + qrow) * HD + ks * 16 + hi * 8) = qh[ks];
+            }
         }
         __syncthreads();
         f32x16 st[7];
@@ -1382,10 +1398,18 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         static bool done[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-        if (!done[dev & 63]) { if (set_lds((const void*)attn_fwd_split_kernel, lds)) return -2; done[dev & 63] = true; }
-        hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const float*)q, (const float*)k,
+        if (!done[dev & 63]) {
+            if (set_lds((const void*)attn_fwd_split_kernel<false>, lds) || set_lds((const void*)attn_fwd_split_kernel<true>, lds)) return -2;
+            done[dev & 63] = true;
+        }
+        if (save16 && save16->q_lo)
+            hipLaunchKernelGGL(attn_fwd_split_kernel<true>, dim3(min(grid, 256)), dim3(448), lds, s, nullptr, nullptr, nullptr, (float*)out, lse, grid,
+                               (bf16*)out3, (bf16*)save16->q, (bf16*)save16->k, (bf16*)save16->v, (bf16*)save16->o, out3_f8,
+                               (const bf16*)save16->q_lo, (const bf16*)save16->k_lo, (const bf16*)save16->v_lo);
+        else
+        hipLaunchKernelGGL(attn_fwd_split_kernel<false>, dim3(min(grid, 256)), dim3(448), lds, s, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, lse, grid, (bf16*)out3, save16 ? (bf16*)save16->q : nullptr, save16 ? (bf16*)save16->k : nullptr,
-                           save16 ? (bf16*)save16->v : nullptr, save16 ? (bf16*)save16->o : nullptr, out3_f8);
+                           save16 ? (bf16*)save16->v : nullptr, save16 ? (bf16*)save16->o : nullptr, out3_f8, nullptr, nullptr, nullptr);
     } else if (precision == 0) {
         if (out3) { set_error("attention forward: split output without the split kernel"); return -1; }
         const size_t lds = F_IMG + NPAD * HD * sizeof(float);

@@ -93,6 +93,36 @@ struct EpiQKV {
     }
 };
 
+// q / k / v of the split forms as two 16-bit planes each (hi = rn16(x), lo = rn16(x - hi), layout [B*12][197][64] like the fp32 tensors they
+// replace, the same bytes): the split attention kernel stages them without conversion work and the hi planes ARE the 16-bit q / k / v a
+// 16-bit backward pass reads (dyt_ctx::bwd16)
+struct EpiQKVPlanes {
+    const float* bias; bf16 *qh, *kh, *vh, *ql, *kl, *vl;
+    struct Col { Bias4 b; bf16* bh; bf16* bl; float s; };
+    typedef NoCtx Pre;
+    __device__ __forceinline__ Col col_init(int col) const {
+        const int which = col / D;
+        const int c = col - which * D;
+        const int h = c >> 6, d = c & 63;
+        Col r;
+        r.b = load_bias4(bias, col);
+        r.s = which == 0 ? 0.125f : 1.0f;
+        const size_t off = (((size_t)h * NT) << 6) + d;
+        r.bh = (which == 0 ? qh : (which == 1 ? kh : vh)) + off;
+        r.bl = (which == 0 ? ql : (which == 1 ? kl : vl)) + off;
+        return r;
+    }
+    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
+    __device__ __forceinline__ void apply(int row, int, const float (&a)[4], const Col& c, const Pre&) const {
+        const int b = row / NT, n = row - b * NT;
+        const size_t o = ((size_t)b * NH * NT + n) << 6;
+        const Split2 s0 = split2((a[0] + c.b.b[0]) * c.s), s1 = split2((a[1] + c.b.b[1]) * c.s), s2 = split2((a[2] + c.b.b[2]) * c.s),
+                     s3 = split2((a[3] + c.b.b[3]) * c.s);
+        *reinterpret_cast<bf16x4*>(c.bh + o) = bf16x4{s0.hi, s1.hi, s2.hi, s3.hi};
+        *reinterpret_cast<bf16x4*>(c.bl + o) = bf16x4{s0.lo, s1.lo, s2.lo, s3.lo};
+    }
+};
+
 // OT: type of the optional operand copy (the 16-bit type in the fp32 split form whose backward runs on 16-bit operands: GemmArgs::save16)
 template <class AT, class OT = AT>
 struct EpiBiasResid {
@@ -1130,6 +1160,7 @@ static int run_f32(const GemmArgs& a, const Epi& epi, hipStream_t s) {
 // epilogues of the forward GEMMs against frozen weights: the ones the fp8-correction kernels are built for
 template <class Epi> struct F8Epi : std::false_type {};
 template <> struct F8Epi<EpiQKV<float>> : std::true_type {};
+template <> struct F8Epi<EpiQKVPlanes> : std::true_type {};
 template <class OT> struct F8Epi<EpiBiasResid<float, OT>> : std::true_type {};
 template <bool G, class GT, bool F> struct F8Epi<EpiFc1<float, G, GT, F>> : std::true_type {};
 template <bool P, class HT> struct F8Epi<EpiFc2<float, P, HT>> : std::true_type {};
@@ -1150,6 +1181,10 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
     switch (kind) {
         case EPI_BIAS_F32: return run<AT, SPLIT>(a, EpiBiasF32{a.bias, a.out_f32, a.N}, s);
         case EPI_QKV:
+            if constexpr (SPLIT) {
+                if (a.qkv_lo[0]) return run<AT, SPLIT>(a, EpiQKVPlanes{a.bias, (bf16*)a.out_at, (bf16*)a.out_at2, (bf16*)a.out_at3, (bf16*)a.qkv_lo[0],
+                                                                     (bf16*)a.qkv_lo[1], (bf16*)a.qkv_lo[2]}, s);
+            }
             return run<AT, SPLIT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
         case EPI_BIAS_RESID:
             if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N}, s); }

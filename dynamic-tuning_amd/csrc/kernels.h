@@ -57,6 +57,7 @@ struct GemmArgs {
     // "fp16f8" form of the split contraction: operands in the hi16 / fp8 images (dyt_common.h: store4_split_f8), the correction
     // products on the fp8 matrix cores; w_exp = the weight image's device-side exponent word
     bool f8 = false; const int* w_exp = nullptr;
+    void* qkv_lo[3] = {nullptr, nullptr, nullptr};   // QKV in the split forms: q / k / v as 16-bit hi planes (out_at, out_at2, out_at3) + these lo planes
     bool out3_f8 = false;   // FC1: out3 (the fc2 GEMM's operand) in that form
     const float* bias = nullptr;
     float* out_f32 = nullptr;
@@ -97,7 +98,9 @@ int launch_gemm_f32_raw(const void* A, const void* W, void* C, int M, int N, int
 // ------------------------------------------------------------------------------------------
 // q,k,v: [B*12][197][64] AT ; out: [B*197][768] AT ; lse: [B*12][197] f32
 // 16-bit copies of q / k / v (same layout) and of the output [B*197][768] written by the split forward kernel for a 16-bit backward
-struct AttnSave16 { void* q = nullptr; void* k = nullptr; void* v = nullptr; void* o = nullptr; };
+struct AttnSave16 { void* q = nullptr; void* k = nullptr; void* v = nullptr; void* o = nullptr;
+                    // planes: q / k / v above are INPUT hi planes (written by the QKV epilogue) and these the lo planes; the fp32 q / k / v arguments are unused
+                    const void* q_lo = nullptr; const void* k_lo = nullptr; const void* v_lo = nullptr; };
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
                     int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr, const AttnSave16* save16 = nullptr, int out3_f8 = 0);   // out may be null when out3 is given   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
 void set_attn_f32_split(int on);   // process-wide version of split16 (unit entries)

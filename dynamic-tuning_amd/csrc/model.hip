@@ -126,6 +126,7 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
     void* g3 = nullptr;   // [M, 3*768]: the gradient stream as a split operand, written by ln_bwd (next block's GELU' dgrad) and tok_bwd (proj dgrad); attention output in the forward pass
     void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
+    void *qlo = nullptr, *klo = nullptr, *vlo = nullptr;   // dyt_ctx::bwd16: lo planes of q / k / v (the hi planes are LayerS::q16 / k16 / v16), QKV epilogue -> split attention forward
     void* dad16 = nullptr;   // dyt_ctx::bwd16: the adapter dgrad as a 16-bit [M,768] operand of tok_bwd (T.dad of the 16-bit modes)
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
@@ -403,6 +404,7 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
         T.dqkv3 = carve<uint16_t>(c, M * SA * 3 * D, dry);
         if (!bwd16) continue;
         T.dad16 = carve<uint16_t>(c, M * D, dry);
+        T.qlo = carve<uint16_t>(c, M * D, dry); T.klo = carve<uint16_t>(c, M * D, dry); T.vlo = carve<uint16_t>(c, M * D, dry);
         S.ucls16 = carve<uint16_t>(c, B * D, dry);
         for (size_t l = 0; l < depth; ++l) {
             LayerS& L = S.L[l];
@@ -1012,7 +1014,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const uint64_t* seed_dev = (flags & DYT_F_DEVICE_SEED) ? c->seed_dev : nullptr;
     const int fm = c->split16 ? c->f8_mask : 0;   // classes (qkv 1, proj 2, fc1 4, fc2 8, embed 16) whose split operands are in the hi16 / fp8 form
-    const bool save16 = save && c->bwd16 && c->split16 && c->split_attn;   // "fp16x3h": what the backward reads is saved in the 16-bit operand type
+    const bool planes = c->bwd16 && c->split16 && c->split_attn;   // q / k / v as 16-bit hi + lo planes (QKV epilogue -> split attention kernel; hi = what a 16-bit backward reads)
+    const bool save16 = save && planes;   // "fp16x3h": what the backward reads is saved in the 16-bit operand type
     Slot& S = c->slots[slot];
     Transients& T = S.T;
     S.valid = false;
@@ -1051,13 +1054,15 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             {
                 GemmArgs a; a.A = T.xn; a.W = W.qkv_w; a.Wp = W.qkv_wp; a.M = M; a.N = 3 * D; a.K = D; a.bias = W.qkv_b;
                 a.out_at = L.q; a.out_at2 = L.k; a.out_at3 = L.v; SPLIT_F(a, W.qkv_w3, 0); SPLIT_READY(a, T.xn3);
+                if (planes) { a.out_at = L.q16; a.out_at2 = L.k16; a.out_at3 = L.v16; a.qkv_lo[0] = T.qlo; a.qkv_lo[1] = T.klo; a.qkv_lo[2] = T.vlo; }
                 RUN_GEMM(EPI_QKV, a);
             }
             void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? T.g3 : nullptr;   // the split attention kernel also writes the proj GEMM's operand
             // last block of a pass without a gate (teacher / complete model): the proj GEMM runs on the gathered cls rows of the fp32 output
             const bool tail_proj = c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate;
-            const AttnSave16 sv16{L.q16, L.k16, L.v16, L.o16};   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, save16 ? &sv16 : nullptr, (fm >> 1) & 1));
+            AttnSave16 sv16{L.q16, L.k16, L.v16, save16 ? L.o16 : nullptr};
+            if (planes) { sv16.q_lo = T.qlo; sv16.k_lo = T.klo; sv16.v_lo = T.vlo; }   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, (save16 || planes) ? &sv16 : nullptr, (fm >> 1) & 1));
             if (tail_proj) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
