@@ -32,9 +32,19 @@ extern "C" {
 #define DYT_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define DYT_ERR_STATE (-3)   /* call order violated (e.g. backward without a saved forward) */
 
-/* arithmetic mode of the dense contractions */
+/* arithmetic mode of the dense contractions (dyt_config::precision).  The library is built twice from the same sources:
+ * libdyt_hip.so (16-bit operand type bfloat16) and libdyt_hip_f16.so (-DDYT_FP16: IEEE half; dyt_operand_type() tells which).
+ * Together with DYT_OPT_F32_SPLIT16 (below) that gives the eight host-side precision names of dynamic-tuning_amd/runtime.py:
+ *   "fp32"     either library, DYT_PREC_FP32                      exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32)
+ *   "bf16"     libdyt_hip.so,     DYT_PREC_BF16                   bf16 MFMA operands, fp32 accumulate / residual stream / statistics
+ *   "fp16"     libdyt_hip_f16.so, DYT_PREC_BF16 (its 16-bit mode) IEEE-half operands, gradient operands x 2^12 (the default)
+ *   "fp16x3"   libdyt_hip_f16.so, DYT_PREC_FP32 + SPLIT16 = 1     every frozen-weight product as three half products, fp32 data flow
+ *   "fp16x3f"  ... SPLIT16 = 2                                    the same forward, gradient products hi * hi (fp32-width backward)
+ *   "fp16x3h"  ... SPLIT16 = 3                                    the same forward, backward pass on 16-bit operands (fp16 mode's kernels)
+ *   "fp16x3q"  ... SPLIT16 = 5                                    as 3 with qkv / proj as hi * hi + two fp8 correction products
+ *   "fp16f8"   ... SPLIT16 = 4                                    as 3 with every forward GEMM in that fp8-correction form */
 #define DYT_PREC_FP32 0 /* exact: fp32 operands, fp32 accumulate -- the parity mode */
-#define DYT_PREC_BF16 1 /* fast: bf16 MFMA operands, fp32 accumulate, fp32 residual stream */
+#define DYT_PREC_BF16 1 /* fast: 16-bit MFMA operands (bfloat16 or IEEE half by build), fp32 accumulate, fp32 residual stream */
 
 /* dyt_forward flags */
 #define DYT_F_TRAINING 1       /* model.train(): Gumbel noise + adapter dropout (dynamic_adapter.py:29-42,127) */
@@ -168,7 +178,23 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           are those of value 1 bit for bit -- while every GRADIENT product takes the hi*hi term alone (the
  *                           frozen-weight dgrad GEMMs contract dY_hi * W_hi; the attention backward's dP / dQ / dK / dV likewise, its
  *                           score recomputation keeps three products): gradients within 7e-4 relative L2 of the fp32 oracle
- *                           (value 1: 1.5e-4; the bar of the exact mode's test: 2e-3) at 0.81x the step time of value 1. */
+ *                           (value 1: 1.5e-4; the bar of the exact mode's test: 2e-3) at 0.81x the step time of value 1.
+ *                           3 ("fp16x3h"): the forward as in 1 bit for bit, with what the backward pass reads saved in the 16-bit
+ *                           operand type next to / instead of the fp32 tensors (q / k / v as hi + lo planes from the QKV epilogue, the
+ *                           attention output, u, gelu'(z), the MLP output and the adapter bottleneck from their producers; ReLU /
+ *                           dropout / gate masks are the exact forward's), and the BACKWARD pass on the 16-bit mode's data flow and
+ *                           kernels (gradient operands x 2^12): gradients within 1.4e-3 of the oracle over five seeds, 0.85x the
+ *                           step time of value 2.
+ *                           4 ("fp16f8"): as 3, every forward GEMM as hi * hi on the f16 matrix cores + the two correction products
+ *                           hi * lo + lo * hi on the fp8 (e4m3) ones (v_mfma_scale_f32_16x16x128_f8f6f4, twice the f16 rate per k: a
+ *                           2K- instead of a 3K-equivalent contraction; operand images [hi16 | e4m3 hi | e4m3 lo 2^12], weights with a
+ *                           per-matrix power of two, descaled by the MFMA's E8M0 scale operand): per GEMM 2e-5 of max|C| (three-part
+ *                           1-2e-6, plain half 4e-4), logits ~5e-5, gate logits ~5e-5 from the fp32 reference -- inside the 1e-3 logit
+ *                           bar, but token-keep decisions within ~1e-5 of the threshold can differ.
+ *                           5 ("fp16x3q"): as 3 with only the attention branch's GEMMs (qkv, proj) in the form of 4, the MLP's
+ *                           three-part: gate logits ~1e-5 (0 differing decisions over five seeds at B=16 and at B=128).
+ *                           Values >= 1 allocate a second arena (the [hi | lo] weight images, split-operand scratch, the 16-bit
+ *                           tensors of 3..5) the first time they are set; plain fp32 contexts do not carry it. */
 #define DYT_OPT_F32_SPLIT16 8
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 /* the process-wide options (DYT_OPT_ATTN_BWD_FUSED) without a context: unit entries such as dyt_attention() see them too */

@@ -14,5 +14,5 @@ env "${envs[@]}" rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o $tag --ou
     python "$root/bench.py" "$@" > "$root/gpurun_out/${tag}_bench.log" 2>&1 || { tail -20 "$root/gpurun_out/${tag}_bench.log"; exit 1; }
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 cp "$f" "$root/gpurun_out/${tag}_kernel_stats.csv"
-grep '^{' "$root/gpurun_out/${tag}_bench.log" > "$root/gpurun_out/${tag}_bench.json" || true
+grep '^{' "$root/gpurun_out/${tag}_bench.log" > "$root/gpurun_out/${tag}_rocprof_bench.json" || true
 head -25 "$root/gpurun_out/${tag}_kernel_stats.csv" | cut -c1-170
