@@ -250,3 +250,28 @@ def rccl_comm_create(device, group=None):
     if rc != 0:
         raise DyTError("ncclCommInitRank: %s" % R.ncclGetErrorString(rc).decode())
     return comm
+
+
+_shared_comms = {}
+
+
+def rccl_comm_shared(device):
+    """The process's communicator for `device` over the default group: created on first use (a re-created engine -- a larger eval
+    batch -- reuses it instead of running another ncclCommInitRank mid-training), destroyed at interpreter exit."""
+    import atexit
+    import torch
+    key = torch.device(device).index or 0
+    if key not in _shared_comms:
+        _shared_comms[key] = rccl_comm_create(device)
+        if len(_shared_comms) == 1:
+            atexit.register(rccl_comm_destroy_all)
+    return _shared_comms[key]
+
+
+def rccl_comm_destroy_all():
+    for comm in list(_shared_comms.values()):
+        try:
+            rccl().ncclCommDestroy(comm)
+        except Exception:
+            pass
+    _shared_comms.clear()

@@ -1320,6 +1320,10 @@ static int dbg_iso_leave(int slot, hipStream_t* s, hipStream_t keep) {
 // stream right before the kernel that produces them.  A consumer that reads a row before its producer's store is visible then
 // turns the final gradient into NaN instead of a 1e-6 difference.   1 dxn  2 dA2  4 dad  8 du_at  16 dO  32 dqkv  64 ddz  128 dZ  256 g_at
 static int dbg_poison(int bit, void* p, size_t bytes, hipStream_t s) {
+#ifndef DYT_DEBUG_HOOKS
+    (void)bit; (void)p; (void)bytes; (void)s;
+    return 0;   // measurement builds only (-DDYT_DEBUG_HOOKS)
+#endif
     static int mask = -1;
     if (mask < 0) { const char* e = getenv("DYT_DBG_POISON"); mask = e ? atoi(e) : 0; }
     if (!(mask & bit) || !p) return 0;

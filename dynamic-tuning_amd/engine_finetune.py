@@ -173,6 +173,9 @@ class FusedAdamW:
             self._state(self.model._engine)
 
 
+_native_rccl_failed = False
+
+
 def allreduce_grads(engine, group=None, overlap=True):
     """Sum the flat trainable-gradient buffer over ranks (RCCL over xGMI); the 1/world factor is folded into the AdamW
     kernel.  Returns that factor.  With `overlap` the head + upper-blocks half of the buffer (final half-way through the
@@ -181,9 +184,18 @@ def allreduce_grads(engine, group=None, overlap=True):
     if not is_dist_avail_and_initialized():
         return 1.0
     if engine.grad.is_cuda and group is None and os.environ.get("DYT_NATIVE_RCCL", "1") != "0" and hasattr(engine, "allreduce_native"):
-        # the collective behind the C ABI (dyt_allreduce_grads): RCCL called by the library on a communicator of its own
-        engine.allreduce_native(overlap=overlap)
-        return 1.0 / dist.get_world_size()
+        # the collective behind the C ABI (dyt_allreduce_grads): RCCL called by the library on a communicator of its own (one per
+        # process).  If that communicator cannot be made (no librccl, several ranks on one GPU) the torch.distributed path below runs.
+        global _native_rccl_failed
+        if not _native_rccl_failed:
+            try:
+                engine.allreduce_native(overlap=overlap)
+                return 1.0 / dist.get_world_size()
+            except DyTError as e:
+                if getattr(engine, "_rccl_comm", None) is not None:
+                    raise                                  # the communicator exists: a failing collective is an error, not a missing feature
+                _native_rccl_failed = True
+                print("[dyt] native RCCL all-reduce unavailable (%s): using torch.distributed.all_reduce" % e)
     if overlap and engine.grad.is_cuda:
         off, num = engine.grad_part(0)
         comm, cur = engine.comm_stream(), torch.cuda.current_stream(engine.device)

@@ -92,7 +92,7 @@ class Block(nn.Module):
         self.count_flops = None
         self.token_select_num = None
 
-        self.precision = "bf16"     # arithmetic mode of a stand-alone call (inside a model the model's precision applies)
+        self.precision = os.environ.get("DYT_PRECISION", "fp16")   # arithmetic mode of a stand-alone call: the model's default (inside a model the model's precision applies)
         self._engine = None
         self._engine_state = None
 
@@ -129,8 +129,30 @@ class Block(nn.Module):
         km = None if keep_mask is None else keep_mask.to(x.device).to(torch.uint8).reshape(1, B * 197, -1).contiguous()
         out, ts, tl = eng.forward_tokens(x.detach().float().contiguous(), training=self.training, complete_model=complete_model,
                                          masked_dense=True, g1=g1, g2=g2, keep_mask=km, seed=seed)
+        if self.count_flops:   # the reference's forward_count_flops returns the bare tensor (:167-185; block_flops_dict.py uses it that way)
+            return out
         sel = torch.cat([ts.new_ones(B, 1, 1), ts[:, 0].unsqueeze(-1)], dim=1)
         return out, dict(sub_token_select=sel, token_logits=tl[:, 0].unsqueeze(-1))
+
+    def __getstate__(self):   # the cached ctypes context of stand-alone calls is neither copied nor pickled (copy.deepcopy / torch.save of a model)
+        d = self.__dict__.copy()
+        d["_engine"] = None
+        d["_engine_state"] = None
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        eng, st = self._engine, self._engine_state
+        self._engine = self._engine_state = None
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            self._engine, self._engine_state = eng, st
+        return new
 
 
 class _DyTFunction(torch.autograd.Function):

@@ -283,8 +283,8 @@ class DyTEngine:
         """dyt_allreduce_grads: SUM of the flat gradient over the ranks on the library's own RCCL communicator (created on
         first use over the default torch.distributed group); the upper part on the communication stream when `overlap`."""
         if self._rccl_comm is None:
-            from _lib import rccl_comm_create
-            self._rccl_comm = rccl_comm_create(self.device)
+            from _lib import rccl_comm_shared
+            self._rccl_comm = rccl_comm_shared(self.device)   # one communicator per process and device, shared by every engine
         cs = ctypes.c_void_p(self.comm_stream().cuda_stream) if overlap else None
         with torch.cuda.device(self.device):
             self._ck(self.L.dyt_allreduce_grads(self.h, self._rccl_comm, ptr(self.grad), cs, stream_ptr()))

@@ -810,8 +810,13 @@ def test_block_submodule_forward_vs_oracle(precision):
     blk.eval()
     blk.count_flops, blk.token_select_num = True, 57               # what get_block_flops sets with apply(setattr)
     want, _, _ = O.block(osd, 0, x, 0.0, 0.0, None, scale, False, False, "masked", count_flops_tokens=57)
-    got, _ = blk(x.cuda())
+    got = blk(x.cuda())                                           # the bare tensor, as the reference's forward_count_flops returns
+    assert torch.is_tensor(got)
     assert float((got.cpu() - want).abs().max()) < ltol * max(1.0, float(want.abs().max()))
+    blk.count_flops = None
+    import copy
+    blk2 = copy.deepcopy(blk)                                     # the cached ctypes context is not copied
+    assert blk2._engine is None and blk._engine is not None
     # the gathered MLP alone (C ABI): out = u + scatter(mlp(LN2(gather(u, mask))))
     eng = blk._block_engine(B, torch.device("cuda", 0))
     mask = (torch.rand(B, 197, generator=g) > 0.4).float()

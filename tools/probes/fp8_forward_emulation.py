@@ -44,8 +44,36 @@ def mx_block(x, mant_bits, emax, block=32):
     return (v * s).reshape(sh).float()
 
 
+_layer_norm = O.layer_norm
+
+
+def tagged_layer_norm(x, w, b):
+    t = _layer_norm(x, w, b)
+    t._ln = (x, w, b)   # what a GEMM with the LayerNorm folded into it would read instead (kind "fp16fold")
+    return t
+
+
+O.layer_norm = tagged_layer_norm
+
+
 def emu_linear(x, w, b=None):
     kind = MODE["kind"]
+    if kind == "fp16fold":
+        # LayerNorm folded into the GEMM that follows it: A = the 16-bit copy of the UN-normalised residual stream,
+        # W' = half(gamma * W); y = rstd (A W'^T - mean colsum(W')) + (W beta + b), statistics from the fp32 stream
+        ln = getattr(x, "_ln", None)
+        frozen = w.shape[0] in (2304, 3072) or (w.shape[0] == 768 and w.shape[1] in (768, 3072))
+        if not frozen:
+            return _linear(x, w, b)
+        if ln is None:
+            return (x.half().double() @ w.half().double().T).float() + b
+        xs, g, be = ln
+        mu = xs.mean(dim=-1, keepdim=True)
+        rstd = (xs.var(dim=-1, unbiased=False, keepdim=True) + 1e-6).rsqrt()
+        wg = (w * g).half().double()
+        acc = xs.half().double() @ wg.T
+        y = rstd.double() * (acc - mu.double() * wg.sum(dim=1)) + (w.double() @ be.double() + b.double())
+        return y.float()
     frozen = w.shape[0] in (2304, 3072) or (w.shape[0] == 768 and w.shape[1] in (768, 3072))
     if kind == "exact" or not frozen:
         return _linear(x, w, b)
