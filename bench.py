@@ -52,7 +52,11 @@ TRAFFIC_JSON = os.path.join("round4", "gemm_traffic.json")
 
 
 class Cfg(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):   # AttributeError (not KeyError) for a missing key: copy / pickle probe attributes
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
 
 def build_model(args, device):

@@ -134,25 +134,12 @@ class Block(nn.Module):
         sel = torch.cat([ts.new_ones(B, 1, 1), ts[:, 0].unsqueeze(-1)], dim=1)
         return out, dict(sub_token_select=sel, token_logits=tl[:, 0].unsqueeze(-1))
 
-    def __getstate__(self):   # the cached ctypes context of stand-alone calls is neither copied nor pickled (copy.deepcopy / torch.save of a model)
+    def __getstate__(self):   # the cached ctypes context of stand-alone calls is neither copied nor pickled (copy.deepcopy and pickle both go through here)
         d = self.__dict__.copy()
         d["_engine"] = None
         d["_engine_state"] = None
         return d
 
-    def __deepcopy__(self, memo):
-        import copy
-        eng, st = self._engine, self._engine_state
-        self._engine = self._engine_state = None
-        try:
-            cls = self.__class__
-            new = cls.__new__(cls)
-            memo[id(self)] = new
-            for k, v in self.__dict__.items():
-                new.__dict__[k] = copy.deepcopy(v, memo)
-        finally:
-            self._engine, self._engine_state = eng, st
-        return new
 
 
 class _DyTFunction(torch.autograd.Function):

@@ -38,7 +38,11 @@ def run(fn):
 
 
 class Cfg(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):   # AttributeError (not KeyError) for a missing key: copy / pickle probe attributes
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
 
 def D_adamw(eng, lr, wd):

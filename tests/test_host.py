@@ -15,7 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class Cfg(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):   # AttributeError (not KeyError) for a missing key: copy / pickle probe attributes
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
 
 def _model(**kw):
