@@ -374,7 +374,7 @@ def _video_full_size_reference():
     return _VIDEO_REF[0]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16", "bf16"])
 def test_video_training_step_at_train_video_sh_size(precision):
     """BASELINE.json configs[4] at FULL size (train_video.sh:19-31: --batch_size 16 per GPU, 8 frames per clip
     (video_datasets/video_datasets.py:28), K400 = 400 classes, r = 64, scale 0.1, token_target_ratio 0.5): one fused training
@@ -403,14 +403,14 @@ def test_video_training_step_at_train_video_sh_size(precision):
     losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=True, g1=g1.cuda().contiguous(),
                               g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt,
                               token_select=ts).cpu()
-    ltol = {"fp32": 1e-3, "fp16": 4e-3, "bf16": 0.02}[precision]            # bf16 measured 2e-3 on the 2 x 2 golden
+    ltol = {"fp32": 1e-3, "fp16x3q": 1e-3, "fp16": 4e-3, "bf16": 0.02}[precision]            # bf16 measured 2e-3 on the 2 x 2 golden
     assert float((ls.cpu() - ref_ls).abs().max()) < ltol, float((ls.cpu() - ref_ls).abs().max())
     assert float((lt.cpu() - ref_lt).abs().max()) < ltol, float((lt.cpu() - ref_lt).abs().max())
     flips = int((ts.cpu() != ref_ts).sum())
-    assert flips <= {"fp32": 4, "fp16": B // 4, "bf16": B * 3}[precision], flips     # of B * 2352 = 301 056 decisions (fp32: ties only)
+    assert flips <= {"fp32": 4, "fp16x3q": 4, "fp16": B // 4, "bf16": B * 3}[precision], flips     # of B * 2352 = 301 056 decisions (fp32: ties only)
     for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
         ref = float(d_ref[k])
-        assert abs(float(losses[i]) - ref) < {"fp32": 1e-4, "fp16": 3e-3, "bf16": 0.02}[precision] * max(1.0, abs(ref)), (k, float(losses[i]), ref)
+        assert abs(float(losses[i]) - ref) < {"fp32": 1e-4, "fp16x3q": 1e-4, "fp16": 3e-3, "bf16": 0.02}[precision] * max(1.0, abs(ref)), (k, float(losses[i]), ref)
     worst = {}
     scal = []
     for n, gr in g_ref.items():
@@ -419,9 +419,11 @@ def test_video_training_step_at_train_video_sh_size(precision):
             scal.append((float(got), float(gr)))
             continue
         # norm_k.bias has an exactly-zero true gradient (a constant added to every key shifts all scores equally): absolute floor
-        e = float((got - gr).norm() / max(float(gr.norm()), {"fp32": 1e-4, "fp16": 3e-4, "bf16": 1e-3}[precision]))
+        e = float((got - gr).norm() / max(float(gr.norm()), {"fp32": 1e-4, "fp16x3q": 3e-4, "fp16": 3e-4, "bf16": 1e-3}[precision]))
         kind = n.split(".", 2)[-1] if n.startswith("blocks.") else n
-        tol = _grad_tol(n, precision) if n.startswith("blocks.") or n.startswith("head") else {"fp32": 2e-3, "fp16": 0.01, "bf16": 0.05}[precision]
+        tol = _grad_tol(n, precision) if n.startswith("blocks.") or n.startswith("head") else {"fp32": 2e-3, "fp16x3q": 4e-3, "fp16": 0.01, "bf16": 0.05}[precision]
+        if e >= tol and precision in SPLIT_MODES and "down_proj" in n:
+            e = _without_relu_side_units(got, gr, e, "video 16x8 %s %s" % (precision, n))
         assert e < tol, (precision, n, e)
         worst[kind] = max(worst.get(kind, 0.0), e)
     a, b = torch.tensor(scal, dtype=torch.float64).unbind(1)

@@ -222,3 +222,30 @@ def test_upper_gradient_allreduce_really_overlaps_the_backward():
         assert all(c < b - 0.5 and c > 0.3 * b for c, b in gaps[1:]), seen
     finally:
         dist.destroy_process_group()
+
+
+def test_fp8_correction_form_with_out_of_range_activations():
+    """The fp8-correction GEMM on activations the fixed scales were not sized for: channels at |x| ~ 300 (the lo part x 2^12 saturates the
+    e4m3 range above 224) and ~3 000 (the hi part saturates above 448) next to channels at 1e-3.  Nothing may turn into NaN / inf
+    (v_cvt_pk_fp8_f32 returns NaN from 480 up: the clamp in pack4_e4m3), and the error must degrade gracefully: never worse than plain
+    half operands, still 2^-15-class where only the lo part saturates."""
+    from _lib import check, lib, ptr, stream_ptr
+    L = lib(fp16=True)
+    M, N, K = 3152, 768, 768
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(N, K, generator=g) * 0.02
+    for big, bar in ((300.0, 1.0), (3000.0, 1.2)):
+        a = torch.randn(M, K, generator=g)
+        a[:, :8] *= big
+        a[:, 8:16] *= 1e-3
+        ref = a.double() @ w.double().t()
+        scale = float(ref.abs().max())
+        c = torch.full((M, N), float("nan"), device="cuda")
+        ad, wd = a.cuda(), w.cuda()
+        check(L.dyt_linear_split(ptr(ad), ptr(wd), None, ptr(c), M, N, K, 8, stream_ptr()), L)
+        torch.cuda.synchronize()
+        assert torch.isfinite(c).all()
+        e8 = float((c.cpu().double() - ref).abs().max()) / scale
+        plain = float(((a.half().double() @ w.half().double().t()) - ref).abs().max()) / scale
+        print("activations up to %g sigma: fp8-corrected %.2e, plain half operands %.2e (of max|C|)" % (big, e8, plain))
+        assert e8 < bar * plain, (big, e8, plain)
