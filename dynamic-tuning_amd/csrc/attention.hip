@@ -216,7 +216,8 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_bf16_kernel(const bf16* __res
                                                                const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ dout,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
-                                                               bf16* __restrict__ dqkv, int nheads) {
+                                                               bf16* __restrict__ dqkv, int nheads, int o_ld) {
+    // o_ld: row stride of `o` in elements (768; 1536 when o is the hi plane of a [M][hi | ...] split operand image)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);
     bf16* Vs = reinterpret_cast<bf16*>(smem + ROW_IMG);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(448) void attn_bwd_dq_bf16_kernel(const bf16* __res
         for (int ks = 0; ks < 4; ++ks) {
             qn[ks] = *reinterpret_cast<const bf16x8*>(q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8);
             don[ks] = *reinterpret_cast<const bf16x8*>(dout + trow + ks * 16 + hi * 8);
-            on[ks] = *reinterpret_cast<const bf16x8*>(o + trow + ks * 16 + hi * 8);
+            on[ks] = *reinterpret_cast<const bf16x8*>(o + ((size_t)b * NT + qr) * o_ld + h * HD + ks * 16 + hi * 8);
         }
         Ln = lse[(size_t)bh * NT + qr];
     };
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16_kernel(const bf16* __
                                                                   const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                                   const bf16* __restrict__ dout,
                                                                   const float* __restrict__ lse, float* __restrict__ delta,
-                                                                  bf16* __restrict__ dqkv, int nheads, int nq) {
+                                                                  bf16* __restrict__ dqkv, int nheads, int nq, int o_ld) {
     // nq: query tiles (of 32 rows) that can carry a non-zero dO -- 7, or 1 when only the cls rows have an upstream gradient
     // (last block, cls-only tail): rows with dO = 0 have dP = delta = 0, hence dS = 0 and no contribution to dK / dV / dQ, so
     // phase B walks nq query tiles and only the first nq waves run phase A (the others store their zero dQ rows)
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16_kernel(const bf16* __
         for (int ks = 0; ks < 4; ++ks) {
             kfr[ks] = *reinterpret_cast<const bf16x8*>(k + hrow + ks * 16 + hi * 8);
             vfr[ks] = *reinterpret_cast<const bf16x8*>(v + hrow + ks * 16 + hi * 8);
-            on[ks] = *reinterpret_cast<const bf16x8*>(o + trow + ks * 16 + hi * 8);
+            on[ks] = *reinterpret_cast<const bf16x8*>(o + ((size_t)b * NT + qr) * o_ld + h * HD + ks * 16 + hi * 8);
         }
         Ln = lse[(size_t)bh * NT + qr];
     };
@@ -1430,7 +1431,10 @@ static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV 
 void set_attn_bwd_fused(int on) { g_attn_bwd_fused = on; }
 
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out, const void* dout,
-                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16, int grad_parts, int out_hi_only) {
+                    const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles, void* dqkv3, float s3, int split16, int grad_parts, int out_hi_only,
+                    int out_ld) {
+    if (out_ld <= 0) out_ld = D;
+    if (out_ld != D && precision == 0) { set_error("attention backward: a strided `out` is a 16-bit-kernel feature"); return -1; }
     const int grid = batch * NH;
     if (dbg_skip(1)) return 0;
     if (precision == 0 && (split16 || g_attn_f32_split)) {
@@ -1480,15 +1484,15 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
         if (g_attn_bwd_fused) {
             if (g_attn_bwd_fused == 2)
                 hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<true>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
-                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, q_tiles);
+                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, q_tiles, out_ld);
             else
                 hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<false>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
-                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, q_tiles);
+                                   (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, q_tiles, out_ld);
             DYT_HIP_CHECK(hipGetLastError());
             return 0;
         }
         hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds1, s, (const bf16*)q, (const bf16*)k,
-                           (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
+                           (const bf16*)v, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid, out_ld);
         hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,
                            (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dqkv, grid);
     }

@@ -107,7 +107,7 @@ void set_attn_f32_split(int on);   // process-wide version of split16 (unit entr
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,
                     const void* dout, const float* lse, float* delta, void* dqkv, int batch, hipStream_t s, int q_tiles = 7,
-                    void* dqkv3 = nullptr, float s3 = 1.f, int split16 = 0, int grad_parts = 3, int out_hi_only = 0);   // out_hi_only: dqkv3 without its lo half (the qkv dgrad contracts one part)
+                    void* dqkv3 = nullptr, float s3 = 1.f, int split16 = 0, int grad_parts = 3, int out_hi_only = 0, int out_ld = 0);   // out_ld: row stride of `out` (0 = 768; 16-bit kernels: the hi plane of a split operand image)   // out_hi_only: dqkv3 without its lo half (the qkv dgrad contracts one part)
       // split16 (fp32 mode): the split backward kernels; grad_parts = 1: their dP / dQ / dK / dV products as hi * hi alone   // dqkv3 (fp32 mode): dqkv * s3 as split 16-bit operand [M, 3 * 2304] instead of fp32
 // q_tiles: 32-row query tiles that can carry a non-zero dout (1: only the cls rows do); honoured by the fused 16-bit kernel, exact
 // 16-bit modes: 1 (default) = dQ and dK/dV of a head in one persistent kernel, 0 = the two separate kernels (process-wide)

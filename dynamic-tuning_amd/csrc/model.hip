@@ -117,6 +117,7 @@ struct LayerS {  // saved activations of one pass
     // dyt_ctx::bwd16: what the backward pass reads, in the 16-bit operand type (written by the exact forward next to / instead of
     // the fp32 tensors above: q16 / k16 / v16 / o16 by the split attention kernel, u16 by the proj epilogue, z16 = gelu'(z) by the
     // fc1 epilogue, dact16 by the down-projection epilogue, h16 by the fc2 epilogue)
+    void* ao3 = nullptr;   // bwd16: the attention output as the proj GEMM's split operand image, kept per layer: its hi plane (row stride SPLIT_A * 768) IS the 16-bit output the backward reads (no separate o16 write: 14 of the forward kernel's 125 us)
     void *q16 = nullptr, *k16 = nullptr, *v16 = nullptr, *o16 = nullptr, *u16 = nullptr, *z16 = nullptr, *dact16 = nullptr, *h16 = nullptr;
 };
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
@@ -409,7 +410,7 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
         for (size_t l = 0; l < depth; ++l) {
             LayerS& L = S.L[l];
             L.q16 = carve<uint16_t>(c, M * D, dry); L.k16 = carve<uint16_t>(c, M * D, dry); L.v16 = carve<uint16_t>(c, M * D, dry);
-            L.o16 = carve<uint16_t>(c, M * D, dry); L.u16 = carve<uint16_t>(c, M * D, dry); L.h16 = carve<uint16_t>(c, M * D, dry);
+            L.o16 = nullptr; L.ao3 = carve<uint16_t>(c, M * SA * D, dry); L.u16 = carve<uint16_t>(c, M * D, dry); L.h16 = carve<uint16_t>(c, M * D, dry);
             L.z16 = carve<uint16_t>(c, M * DM, dry); L.dact16 = carve<uint16_t>(c, M * RP, dry);
         }
         if (!dry) S.u0_16_own = S.L[0].u16;
@@ -788,6 +789,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             if (const char* e = getenv("DYT_SPLIT_WGRAD16")) c->split_wgrad16 = atoi(e) != 0;
             if (const char* e = getenv("DYT_SPLIT_ATTN")) c->split_attn = atoi(e) != 0;
             if (const char* e = getenv("DYT_SPLIT_PROD")) c->split_prod = atoi(e) != 0;
+            if (c->bwd16) c->split_attn = c->split_prod = true;   // the 16-bit backward reads what the split attention kernel / producers write (planes, the per-layer proj operand image)
             for (auto& S : c->slots) S.valid = false;
             if (c->split16) {   // parts of the weights uploaded so far (later dyt_set_frozen calls refresh theirs)
                 DYT_HIP_CHECK(hipDeviceSynchronize());   // uploads may be in flight on the caller's streams
@@ -1057,10 +1059,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 if (planes) { a.out_at = L.q16; a.out_at2 = L.k16; a.out_at3 = L.v16; a.qkv_lo[0] = T.qlo; a.qkv_lo[1] = T.klo; a.qkv_lo[2] = T.vlo; }
                 RUN_GEMM(EPI_QKV, a);
             }
-            void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? T.g3 : nullptr;   // the split attention kernel also writes the proj GEMM's operand
+            void* ao3 = (c->split16 && c->split_attn && c->split_prod) ? ((save16 && L.ao3) ? L.ao3 : T.g3) : nullptr;   // the split attention kernel also writes the proj GEMM's operand
             // last block of a pass without a gate (teacher / complete model): the proj GEMM runs on the gathered cls rows of the fp32 output
             const bool tail_proj = c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate;
-            AttnSave16 sv16{L.q16, L.k16, L.v16, save16 ? L.o16 : nullptr};
+            AttnSave16 sv16{L.q16, L.k16, L.v16, nullptr};   // (the output's 16-bit copy is the hi plane of ao3)
             if (planes) { sv16.q_lo = T.qlo; sv16.k_lo = T.klo; sv16.v_lo = T.vlo; }   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
             RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, (save16 || planes) ? &sv16 : nullptr, (fm >> 1) & 1));
             if (tail_proj) {
@@ -1518,8 +1520,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         }
         POISON(32, T.dqkv, (size_t)M * 3 * D * atb);
         ISO(1, RUN(1, 14.0 * B * NH * (double)NT * NT * HD,
-            launch_attn_bwd(P, b16 ? L.q16 : L.q, b16 ? L.k16 : L.k, b16 ? L.v16 : L.v, b16 ? L.o16 : L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
-                            split16 ? T.dqkv3 : nullptr, c->split_gs, split16 && c->split_attn, c->split_bwd_attn_parts, c->split_bwd_parts == 1)););   // teacher tail: du, hence dO, is zero off the cls rows
+            launch_attn_bwd(P, b16 ? L.q16 : L.q, b16 ? L.k16 : L.k, b16 ? L.v16 : L.v, b16 ? L.ao3 : L.attn_o, T.dO, L.lse, T.delta, T.dqkv, B, s, (tail && !student) ? 1 : 7,
+                            split16 ? T.dqkv3 : nullptr, c->split_gs, split16 && c->split_attn, c->split_bwd_attn_parts, c->split_bwd_parts == 1, b16 ? SPLIT_A * D : 0)););   // teacher tail: du, hence dO, is zero off the cls rows
         CK("attn_bwd delta", T.delta, (size_t)B * NH * NT * 4); CK("attn_bwd dqkv", T.dqkv, (size_t)M * 3 * D * atb);
         {
             GemmArgs a; a.A = T.dqkv; a.W = qkv_wT; a.Wp = qkv_wTp; a.M = M; a.N = D; a.K = 3 * D; a.out_at = T.dxn; if (split16) { SPLIT_G(a, W.qkv_wT3); SPLIT_READY(a, T.dqkv3); }
