@@ -46,7 +46,7 @@ PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3,   # TFLOP/s dense MFMA, M
         "fp16x3": 2500.0 / 3,   # three half-precision products per fp32-class product: the USEFUL-FLOP ceiling of the split form
         "fp16x3f": 2500.0 / 2,  # forward GEMMs three products, gradient GEMMs one (equal useful FLOPs either side): two on average
         "fp16x3h": 2500.0 / 2,
-        "fp16x3q": 2500.0 / 1.85,  # qkv / proj in the fp8-correction form (two f16-equivalents), the MLP three-part
+        "fp16x3q": 2500.0 / 1.75,  # qkv / proj (both passes) and the teacher pass's MLP in the fp8-correction form (two f16-equivalents), the student's MLP three-part
         "fp16f8": 2500.0 / 1.5}  # forward: one f16 product + two fp8 products at twice the rate = two f16-equivalents; backward one  # the same product counts; the backward runs on 16-bit operands with the fp16 mode's kernels
 TRAFFIC_JSON = os.path.join("round4", "gemm_traffic.json")
 
