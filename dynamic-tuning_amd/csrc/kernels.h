@@ -36,8 +36,9 @@ struct GemmArgs {
     // K-concatenated form (16-bit kernels, EPI_FC2): C = A2 W2^T + A W^T, A2 [rows,64] (row r read from A2[a2_map[r]]), W2 [N,64];
     // bias2 / scale: the second pair's bias enters as scale * bias2 (A2 is expected to carry `scale` already)
     const void* A2 = nullptr; const void* W2 = nullptr; const int* a2_map = nullptr; const float* bias2 = nullptr;
-    // fp32 mode, "split" form: W3 = the fp32 weight as [N, 3K] 16-bit operands [hi | lo | hi] (launch_split3_w); the fp32 A is split
-    // on the fly into a3 [M, 3K] = [hi | hi | lo] and the GEMM runs as ONE 16-bit MFMA contraction over 3K (hi*hi + hi*lo + lo*hi)
+    // fp32 mode, "split" form: W3 = the fp32 weight as a [N, 2K] 16-bit image [hi | lo] (launch_split3_w); the fp32 A likewise as a3
+    // [M, 2K] = [hi | lo] (written by its producer or split on the fly) and the GEMM runs as ONE 16-bit MFMA contraction over 3K k-tiles
+    // (hi*hi + hi*lo + lo*hi: the loaders fold the tile index onto the two stored parts)
     // with the fp32 epilogue: the accuracy of the exact-fp32 MFMA kernel at ~2.7x its speed (tools/probes/split_precision_probe.py)
     const void* W3 = nullptr; void* a3 = nullptr;
     float a3_scale = 1.f;   // power of two the fp32 A is multiplied by before it is split (gradients: keeps the lo part out of the fp16
@@ -82,7 +83,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
-// fp32 W [N,K] -> [N, 3K] 16-bit operands [hi | lo | hi] with hi = rn16(w), lo = rn16(w - hi)
+// fp32 W [N,K] -> [N, 2K] 16-bit image [hi | lo] with hi = rn16(w), lo = rn16(w - hi)
 int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s);
 // ... in the hi16 / fp8 form [N, hi16 | e4m3(lo 2^(ew+11)) | e4m3(hi 2^ew)], ew = 7 - ceil(log2 max|w|) written to ew_dev[0]; scratch: one device word
 int launch_split_w_f8(const float* W, void* W3, int N, int K, int* ew_dev, unsigned* scratch, hipStream_t s);
