@@ -202,6 +202,15 @@ def main():
                  "roofline_frac": om["roofline"]["frac"] if om["roofline"] else None,
                  "parity": "vs the CPU oracle at B=16 (tests/test_gpu_round2.py, tools/probes/precision_table.py): fp16 logits 1.6e-3 / 0 of "
                            "37 632 gate decisions differ / gradients 1e-3 (down_proj 0.04); bf16 logits 0.012 / 13 flips / 8e-3 (0.07)"}
+        # A/B: the headline mode with LayerNorm-2 as its own kernel (DYT_LN_FOLD=0; the default folds it into the fc1 GEMM)
+        torch.cuda.empty_cache()
+        os.environ["DYT_LN_FOLD"] = "0"
+        try:
+            fv = measure(args, args.precision, args.mode, max(2, min(args.steps, 10)), 2, device, world, rank)
+        finally:
+            os.environ.pop("DYT_LN_FOLD", None)
+        other["headline_with_ln2_as_kernel"] = {"dtype": args.precision, "value": fv["value"], "unit": "images/s", "ms_per_step": fv["ms_per_step"],
+                                                "steps": fv["steps"]}
     exact = None
     if world == 1 and args.video_frames <= 1 and args.precision in ("fp16", "bf16") and not args.no_parity_mode:
         # the same step in the fastest mode that meets north_star's parity bars (logits <= 1e-3, gate masks bit-exact): "fp16x3" =

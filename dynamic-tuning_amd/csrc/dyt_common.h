@@ -177,6 +177,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 #endif
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15): every lane of the row receives it
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return v;
+}
+// LayerNorm folded into the GEMM behind it (GemmArgs::ln_part): the producer epilogue leaves LN_PARTS (sum, M2 about the group's own mean)
+// pairs per row, one per 64 columns; merged here in a fixed order (Chan et al.: M2 = sum M2_i + 64 sum (mean_i - mean)^2) -> (mean, rstd)
+constexpr int LN_PARTS = 12;
+__device__ __forceinline__ float2 ln_merge_parts(const float2* __restrict__ part, int row) {
+    const float4* p = reinterpret_cast<const float4*>(part + (size_t)row * LN_PARTS);
+    float4 v[LN_PARTS / 2];
+#pragma unroll
+    for (int i = 0; i < LN_PARTS / 2; ++i) v[i] = p[i];
+    float sum = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_PARTS / 2; ++i) { sum += v[i].x; sum += v[i].z; m2 += v[i].y; m2 += v[i].w; }
+    const float mean = sum * (1.0f / 768.0f);
+#pragma unroll
+    for (int i = 0; i < LN_PARTS / 2; ++i) {
+        const float d0 = v[i].x * (1.0f / 64.0f) - mean, d1 = v[i].z * (1.0f / 64.0f) - mean;
+        m2 = fmaf(64.0f * d0, d0, m2);
+        m2 = fmaf(64.0f * d1, d1, m2);
+    }
+    return make_float2(mean, 1.0f / sqrtf(m2 * (1.0f / 768.0f) + LN_EPS));
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f32<0xB1>(v));
     v = fmaxf(v, dpp_f32<0x4E>(v));

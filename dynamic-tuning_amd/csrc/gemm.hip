@@ -124,9 +124,13 @@ struct EpiQKVPlanes {
 };
 
 // OT: type of the optional operand copy (the 16-bit type in the fp32 split form whose backward runs on 16-bit operands: GemmArgs::save16)
-template <class AT, class OT = AT>
+// STATS: LayerNorm statistics of the row just produced, for the GEMM that consumes LN(row) in the folded form (GemmArgs::ln_part).  The
+// epilogue sweep gives 16 consecutive lanes 64 consecutive columns of one row (ch = tid % (BN / 4), BN / 4 a multiple of 16), so a
+// group's (sum, sum of squares about its own mean) is two 4-step DPP reductions inside the lane row -- no LDS, no atomics, fixed order
+template <class AT, class OT = AT, bool STATS = false>
 struct EpiBiasResid {
     const float* bias; const float* resid; float* out; OT* out_at; int ld;
+    float2* part = nullptr;
     typedef Bias4 Col; typedef Raw4<float> Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(resid + (size_t)row * ld + col); }
@@ -138,38 +142,69 @@ struct EpiBiasResid {
         const float v2 = a[2] + c.b[2] + r[2], v3 = a[3] + c.b[3] + r[3];
         store4(out + o, v0, v1, v2, v3);
         if (out_at) store4(out_at + o, v0, v1, v2, v3);
+        if constexpr (STATS) {
+            const float sum = row16_sum((v0 + v1) + (v2 + v3));
+            const float m = sum * (1.0f / 64.0f);
+            const float d0 = v0 - m, d1 = v1 - m, d2 = v2 - m, d3 = v3 - m;
+            const float m2 = row16_sum(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3));
+            if ((col & 63) == 0) part[(size_t)row * LN_PARTS + (col >> 6)] = make_float2(sum, m2);
+        }
     }
 };
 
 // FAST (fp32 functor of the split forms): Phi by Abramowitz-Stegun 26.2.17 (the 16-bit functor's: |h err| 4e-7, |gelu' err| 3e-7 absolute,
 // one v_exp + one v_rcp per element, packed fp32) instead of erff + expf -- below the split GEMMs' own 1e-6 and a tenth of the VALU work
-template <class AT, bool HAS_GP, class GT = AT, bool FAST = false>   // GT: type gelu'(z) is saved in (GemmArgs::save16: 16 bits under fp32 arithmetic)
+// LNF: LayerNorm folded in (GemmArgs::ln_st): the accumulator is u16 . (gamma W)^T of the un-normalised row; z = rstd (acc - mean cs) + bias'
+template <class AT, bool HAS_GP, class GT = AT, bool FAST = false, bool LNF = false>   // GT: type gelu'(z) is saved in (GemmArgs::save16: 16 bits under fp32 arithmetic)
 struct EpiFc1 {
     const float* bias; AT* h; GT* gp; int ld;   // gp: gelu'(z), kept for the backward pass (training only)
     bf16* h3;   // split fp32 form: h goes out as the 16-bit hi / hi / lo operand of the fc2 GEMM ([rows, 3 ld]) instead of as fp32
     int f8 = 0; // ... in the hi16 / fp8 form (store4_split_f8)
-    typedef Bias4 Col; typedef NoCtx Pre;
-    __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
-    __device__ __forceinline__ Pre pre(int, int) const { return {}; }
-    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre&) const {
+    // LNF: column sums of W'; (mean, rstd) per LOGICAL row from ln_st (tile shapes without a statistics prologue: a pre-pass filled it), or --
+    // RowStats kernels (gemm_bpre.h) -- merged from the producer's partials ln_part in the kernel prologue, which also leaves them in st_out
+    const float* ln_cs = nullptr; const float2* ln_st = nullptr; const float2* ln_part = nullptr; float2* st_out = nullptr;
+    struct ColF { float b[4]; float cs[4]; };
+    typedef typename std::conditional<LNF, ColF, Bias4>::type Col;
+    typedef typename std::conditional<LNF, float2, NoCtx>::type Pre;
+    __device__ __forceinline__ Col col_init(int col) const {
+        if constexpr (LNF) {
+            ColF c;
+            const Bias4 b4 = load_bias4(bias, col), c4 = load_bias4(ln_cs, col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c.b[i] = b4.b[i]; c.cs[i] = c4.b[i]; }
+            return c;
+        } else {
+            return load_bias4(bias, col);
+        }
+    }
+    __device__ __forceinline__ Pre pre(int row, int) const {
+        if constexpr (LNF) return ln_st[row];   // (RowStats kernels do not call this)
+        else return {};
+    }
+    __device__ __forceinline__ void apply(int row, int col, const float (&a)[4], const Col& c, const Pre& p) const {
         const size_t o = (size_t)row * ld + col;
-        float hv[4], gv[4];
+        float hv[4], gv[4], z[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (LNF) z[i] = fmaf(p.y, fmaf(-p.x, c.cs[i], a[i]), c.b[i]);
+            else z[i] = a[i] + c.b[i];
+        }
         if (HAS_GP) {
             if constexpr (sizeof(AT) == 2 || FAST) {   // two elements per packed-fp32 issue slot
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
                     f32x2 h2, g2;
-                    gelu_both_x2(f32x2{a[i], a[i + 1]} + f32x2{c.b[i], c.b[i + 1]}, h2, g2);
+                    gelu_both_x2(f32x2{z[i], z[i + 1]}, h2, g2);
                     hv[i] = h2[0]; hv[i + 1] = h2[1]; gv[i] = g2[0]; gv[i + 1] = g2[1];
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gelu_both<AT>(a[i] + c.b[i], hv[i], gv[i]);
+                for (int i = 0; i < 4; ++i) gelu_both<AT>(z[i], hv[i], gv[i]);
             }
             store4_nt(gp + o, gv[0], gv[1], gv[2], gv[3]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = FAST ? gelu_fwd<bf16>(a[i] + c.b[i]) : gelu_fwd<AT>(a[i] + c.b[i]);
+            for (int i = 0; i < 4; ++i) hv[i] = FAST ? gelu_fwd<bf16>(z[i]) : gelu_fwd<AT>(z[i]);
         }
         if constexpr (sizeof(AT) == 4) {
             if (h3) {
@@ -181,6 +216,20 @@ struct EpiFc1 {
         store4(h + o, hv[0], hv[1], hv[2], hv[3]);
     }
 };
+
+// functors whose Pre is a per-row float2 that a kernel with a statistics prologue provides from LDS instead of calling pre()
+template <class E> struct RowStats : std::false_type {};
+template <class AT, bool G, class GT, bool F> struct RowStats<EpiFc1<AT, G, GT, F, true>> : std::true_type {};
+// pre-pass for the other tile shapes: (mean, rstd) of logical row r = source row a_map[r] into st[r] and st_src[source row]
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, const int* __restrict__ a_map, float2* __restrict__ st,
+                                                          float2* __restrict__ st_src, int rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int t = a_map ? a_map[r] : r;
+    const float2 v = ln_merge_parts(part, t);
+    st[r] = v;
+    if (st_src) st_src[t] = v;
+}
 
 // PLAIN = no row map and no row mask (teacher pass / dense rows): the per-chunk context is then just the 16 B of the residual,
 // small enough for the kernels to issue a whole pass of residual loads ahead of the staging barriers (PRE_ALL); with the
@@ -1071,6 +1120,10 @@ static int run_f8(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true>(a, epi, s);
 }
 
+// wide-N GEMM against a pre-shuffled frozen weight -> gemm_bf16_bpre_kernel (see run_bf16)
+static bool takes_bpre(const GemmArgs& a, bool k768 = false) {
+    return a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && (a.N >= g_big_tile_min_n || k768) && a.M >= 2048;
+}
 template <class Epi, bool CAT = false>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
@@ -1088,7 +1141,7 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     static const int bpre_k768 = getenv("DYT_BPRE_K768") ? atoi(getenv("DYT_BPRE_K768")) : 2;
     static const int bpre_maxk = getenv("DYT_BPRE_STORE_MAXK") ? atoi(getenv("DYT_BPRE_STORE_MAXK")) : D;   // measurement knob: plain-store N = 768 GEMMs up to this K
     const bool k768 = (a.K == D && bpre_k768 == 1) || (bpre_k768 == 2 && std::is_same<Epi, EpiStoreAT<bf16>>::value && a.K <= bpre_maxk);
-    if (a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && (a.N >= g_big_tile_min_n || k768) && a.M >= 2048) {
+    if (takes_bpre(a, k768)) {
         GemmArgs b = a; b.W = a.Wp;
         return launch_bf16_bpre<0>(b, epi, s);
     }
@@ -1188,6 +1241,13 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             return run<AT, SPLIT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
         case EPI_BIAS_RESID:
             if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N}, s); }
+            if constexpr (sizeof(AT) == 2) {
+                if (a.ln_part) {
+                    if (a.N != LN_PARTS * 64) { set_error("gemm: LayerNorm partials need N = %d", LN_PARTS * 64); return -1; }
+                    return run<AT, SPLIT>(a, EpiBiasResid<AT, AT, true>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N, a.ln_part}, s);
+                }
+            }
+            if (a.ln_part) { set_error("gemm: LayerNorm partials exist in the 16-bit modes only"); return -1; }
             return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
         case EPI_FC1:
             if constexpr (SPLIT) {   // the split forms take the A&S GELU (EpiFc1<FAST>): 42.7 vs 43.1 ms/step, logits vs the oracle unchanged (2.4e-5 / 6e-6)
@@ -1195,6 +1255,21 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
                 if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s);
                 return run<AT, SPLIT>(a, EpiFc1<AT, false, AT, true>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3, a.out3_f8}, s);
             }
+            if constexpr (sizeof(AT) == 2) {
+                if (a.ln_part) {   // LayerNorm folded in
+                    if (!a.ln_cs || !a.ln_st_out || !a.ln_scratch || a.K != LN_PARTS * 64) { set_error("gemm: folded LayerNorm form needs ln_cs, ln_st_out, ln_scratch and K = 768"); return -1; }
+                    const float2* st = nullptr;
+                    if (!takes_bpre(a)) {   // no statistics prologue in these tile shapes: merge the partials in a pre-pass
+                        hipLaunchKernelGGL(ln_finalize_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a.ln_part, a.a_map, a.a_map ? a.ln_scratch : a.ln_st_out,
+                                           a.a_map ? a.ln_st_out : nullptr, a.M);
+                        DYT_HIP_CHECK(hipGetLastError());
+                        st = a.a_map ? a.ln_scratch : a.ln_st_out;
+                    }
+                    if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, AT, false, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, nullptr, 0, a.ln_cs, st, a.ln_part, a.ln_st_out}, s);
+                    return run<AT, SPLIT>(a, EpiFc1<AT, false, AT, false, true>{a.bias, (AT*)a.out_at, nullptr, a.N, nullptr, 0, a.ln_cs, st, a.ln_part, a.ln_st_out}, s);
+                }
+            }
+            if (a.ln_part) { set_error("gemm: the folded LayerNorm form exists in the 16-bit modes only"); return -1; }
             if (a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s);
             return run<AT, SPLIT>(a, EpiFc1<AT, false>{a.bias, (AT*)a.out_at, nullptr, a.N, (bf16*)a.out3, a.out3_f8}, s);
         case EPI_FC2: {

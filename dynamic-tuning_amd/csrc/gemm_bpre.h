@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
     __shared__ __attribute__((aligned(16))) char ring1[SLOT];
     __shared__ __attribute__((aligned(16))) char ring2[SLOT];
     __shared__ __attribute__((aligned(16))) char ring3[SLOT];
+    constexpr bool RS = RowStats<Epi>::value;   // LayerNorm folded in: per-row (mean, rstd) merged from the producer's partials, parked in LDS
+    __shared__ float2 ln_s[RS ? BM : 1];
     constexpr int TM = 8, TN = 4, WN = 64;
     constexpr int A_INSTR = BM / 8 / NW;         // 4 LDS-DMA pieces (8 rows x 128 B) per wave and stage
 
@@ -56,6 +58,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
     unsigned long long t_start = 0, t_loop0 = 0, t_loop1 = 0;
     if (ABL == 9) t_start = __builtin_readcyclecounter();
 
+    if constexpr (RS) {   // (the barrier of the main-loop prologue publishes ln_s; the loads overlap the first DMA stages)
+        if (tid < BM) {
+            int grow = min(m0 + tid, Mv - 1);
+            if (a_map) grow = a_map[grow];
+            const float2 st = ln_merge_parts(epi.ln_part, grow);
+            ln_s[tid] = st;
+            if (tn == 0 && m0 + tid < Mv) epi.st_out[grow] = st;
+        }
+    }
     // ---- A staging (same image as the LDS-staged kernels: [row][8 x 16 B], chunk slot XOR (row & 7)) ----
     const int lrow = lane >> 3, slot8 = lane & 7, chunk = slot8 ^ lrow;
     unsigned a_src[A_INSTR];   // element offsets (M x K < 2^31): half the registers of four 64-bit pointers
@@ -189,7 +200,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
             typename Epi::Pre pr[PRE_ALL ? ITERS : BATCH];
             if (PRE_ALL) {
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) pr[it] = epi.pre(min(m0 + p * PROWS + rl0 + it * RSTEP, Mv - 1), col);
+                for (int it = 0; it < ITERS; ++it) {
+                    if constexpr (RS) pr[it] = ln_s[p * PROWS + rl0 + it * RSTEP];
+                    else pr[it] = epi.pre(min(m0 + p * PROWS + rl0 + it * RSTEP, Mv - 1), col);
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -208,7 +222,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
             for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
                 if (!PRE_ALL) {
 #pragma unroll
-                    for (int u = 0; u < BATCH; ++u) pr[u] = epi.pre(min(m0 + p * PROWS + rl0 + (it0 + u) * RSTEP, Mv - 1), col);
+                    for (int u = 0; u < BATCH; ++u) {
+                        if constexpr (RS) pr[u] = ln_s[p * PROWS + rl0 + (it0 + u) * RSTEP];
+                        else pr[u] = epi.pre(min(m0 + p * PROWS + rl0 + (it0 + u) * RSTEP, Mv - 1), col);
+                    }
                 }
                 f32x4 c4[BATCH];
 #pragma unroll

@@ -60,6 +60,12 @@ struct GemmArgs {
     bool f8 = false; const int* w_exp = nullptr;
     void* qkv_lo[3] = {nullptr, nullptr, nullptr};   // QKV in the split forms: q / k / v as 16-bit hi planes (out_at, out_at2, out_at3) + these lo planes
     bool out3_f8 = false;   // FC1: out3 (the fc2 GEMM's operand) in that form
+    // LayerNorm folded into the GEMM behind it (16-bit modes): BIAS_RESID (the producer of the row u) also writes per-row
+    // partial statistics -- (sum, centred sum of squares) of each 64-column group, [M][LN_PARTS] -- and FC1 (the consumer) contracts the
+    // 16-bit copy of the UN-normalised row with W' = AT(gamma W) and applies z = rstd (acc - mean colsum(W')) + (W beta + b) in its
+    // epilogue.  FC1 takes the partials (ln_part, indexed by source row: a_map), merges them itself -- in the kernel's prologue, or by a
+    // small pre-pass into ln_scratch [M] for the tile shapes without that prologue -- and leaves (mean, rstd) per source row in ln_st_out
+    float2* ln_part = nullptr; float2* ln_st_out = nullptr; float2* ln_scratch = nullptr; const float* ln_cs = nullptr;
     const float* bias = nullptr;
     float* out_f32 = nullptr;
     void* out_at = nullptr;
@@ -83,6 +89,10 @@ struct GemmArgs {
 };
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s);
+// fc1 of the folded form, from the fp32 weight W [N,768]: Wf = AT(gamma W) (+ its fragment-order twin when Wfp), cs[n] = sum_k Wf[n,k],
+// bf[n] = bias[n] + sum_k W[n,k] beta[k]
+int launch_ln_fold_w(int precision, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, void* Wfp, float* cs,
+                     float* bf, int N, hipStream_t s);
 // fp32 W [N,K] -> [N, 2K] 16-bit image [hi | lo] with hi = rn16(w), lo = rn16(w - hi)
 int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s);
 // ... in the hi16 / fp8 form [N, hi16 | e4m3(lo 2^(ew+11)) | e4m3(hi 2^ew)], ew = 7 - ceil(log2 max|w|) written to ew_dev[0]; scratch: one device word

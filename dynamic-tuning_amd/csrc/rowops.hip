@@ -150,6 +150,40 @@ int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* s
     return 0;
 }
 
+// the folded LayerNorm form's weight side (GemmArgs::ln_part), one wave per output feature n, from the fp32 weight (one rounding, like the
+// plain 16-bit copy): Wf[n,:] = AT(gamma * W[n,:]), cs[n] = sum of the ROUNDED Wf[n,:] (what the matrix cores contract), bf[n] = bias[n] + <W[n,:], beta>
+template <class AT>
+__global__ __launch_bounds__(256) void ln_fold_w_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ bias, AT* __restrict__ Wf, float* __restrict__ cs,
+                                                        float* __restrict__ bf, int N) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    Row12 wr, gr, br;
+    wr.load(W + (size_t)n * D, lane);
+    gr.load(gamma, lane);
+    br.load(beta, lane);
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        t = fmaf(wr.v[i], br.v[i], t);
+        wr.v[i] = to_f32(from_f32<AT>(wr.v[i] * gr.v[i]));
+        s += wr.v[i];
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+    wr.store(Wf + (size_t)n * D, lane);
+    if (lane == 0) { cs[n] = s; bf[n] = bias[n] + t; }
+}
+int launch_ln_fold_w(int precision, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, void* Wfp, float* cs,
+                     float* bf, int N, hipStream_t s) {
+    if (precision == 0) { set_error("ln_fold_w: 16-bit modes only"); return -1; }
+    hipLaunchKernelGGL(ln_fold_w_kernel<bf16>, dim3((N + 3) / 4), dim3(256), 0, s, W, gamma, beta, bias, (bf16*)Wf, cs, bf, N);
+    LAUNCH_CHECK();
+    if (Wfp) return launch_preshuffle_w(Wf, Wfp, N, D, s);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // token dispatcher: logits, (Gumbel-)sigmoid, hard threshold, per-image index compaction in LDS
 // ------------------------------------------------------------------------------------------

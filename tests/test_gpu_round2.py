@@ -36,11 +36,14 @@ def _bench_model(precision, mode, B, gate_bias, classes=100, r=64, kind="bench",
 
 
 # per-tensor-kind bounds on the relative L2 error of a bf16-mode gradient (measured x ~2.5; fp32 mode: 2e-3 for all)
-BF16_GRAD_TOL = {"mlp_token_select": 0.05, "adaptmlp.down_proj": 0.15, "adaptmlp.up_proj": 0.03, "head": 0.02}   # measured at B=16: 0.012 / 0.071 / 0.008 / 0.006
+# The gate and down_proj gradients of the 16-bit modes are dominated by DECISIONS that come out the other way (a token-keep decision or a
+# ReLU side within 16-bit round-off of its threshold), not by round-off itself: over five seeds at B=16 the fp16 gate gradients range
+# 1.3e-3 ... 2.7e-2 and bf16's 1.4e-2 ... 6.1e-2 (down_proj 2.3e-2 ... 9.8e-2) in BOTH LayerNorm forms (profiles/round4/r4_ln_fold_ab.txt)
+BF16_GRAD_TOL = {"mlp_token_select": 0.12, "adaptmlp.down_proj": 0.25, "adaptmlp.up_proj": 0.03, "head": 0.02}   # five seeds at B=16: <= 0.061 / 0.098 / 0.008 / 0.006 (VTAB cls-row block: 0.19)
 
 
 # the same for the fp16 mode (IEEE-half operands, libdyt_hip_f16.so); measured at B=16: 0.001 / 0.039 / 0.001 / 0.0008
-FP16_GRAD_TOL = {"mlp_token_select": 0.01, "adaptmlp.down_proj": 0.25, "adaptmlp.up_proj": 0.005, "head": 0.003}   # VTAB shapes (r=16): down_proj up to 0.115, gate 0.003
+FP16_GRAD_TOL = {"mlp_token_select": 0.05, "adaptmlp.down_proj": 0.25, "adaptmlp.up_proj": 0.005, "head": 0.003}   # VTAB shapes (r=16): down_proj up to 0.115, gate 0.003
 
 
 SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16x3q", "fp16f8")   # fp32 data flow, frozen-weight GEMMs / attention as IEEE-half (+ fp8) products

@@ -249,3 +249,54 @@ def test_fp8_correction_form_with_out_of_range_activations():
         plain = float(((a.half().double() @ w.half().double().t()) - ref).abs().max()) / scale
         print("activations up to %g sigma: fp8-corrected %.2e, plain half operands %.2e (of max|C|)" % (big, e8, plain))
         assert e8 < bar * plain, (big, e8, plain)
+
+
+def _step_outputs(prec, mode, B, C, r, x, y, g1, g2, keep, target):
+    m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
+    m.train()
+    eng = m.engine(B, torch.device("cuda", 0))
+    ls = torch.empty(B, C, device="cuda"); lt = torch.empty(B, C, device="cuda"); ts = torch.zeros(B, 12, 196, device="cuda")
+    losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), target, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                              g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+    out = (ls.cpu(), lt.cpu(), ts.cpu(), losses, eng.grad.detach().cpu().clone())
+    del m, eng
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.parametrize("B", [16, 2])
+@pytest.mark.parametrize("mode", ["compact", "masked"])
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_layernorm_folded_into_fc1_matches_the_kernel_form(prec, mode, B, monkeypatch):
+    """16-bit modes: LayerNorm-2 as per-row partial statistics from the proj epilogue + gamma-folded fc1 weights + normalisation in the
+    fc1 epilogue (the default; reference: models/vision_transformer_IN21K.py:123,159 norm2 -> mlp.fc1) against the ln_fwd / ln_gather
+    kernels (DYT_LN_FOLD=0) and against the CPU oracle.  B=16: the pre-shuffled-weight kernel with the statistics prologue
+    (M = 3152 rows); B=2: the LDS-staged tiles behind the merge pre-pass (M = 394).  The two forms differ by 16-bit round-off only:
+    same bounds vs the oracle as the mode itself, and the difference between them no larger than that."""
+    from oracle import dyt_oracle as O
+    C, r, target = 100, 64, 0.7
+    x, y = synth.make_batch(B, C, seed=31)
+    g1, g2 = synth.make_noise(B, seed=32)
+    keep = synth.make_dropout_masks(B, r, seed=33)
+    sd = synth.make_state_dict(C, r, seed=0, kind="test", gate_bias=0.85)
+    _, _, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
+    ref_ts = tok["token_select"].detach()[..., 0].float()
+    monkeypatch.setenv("DYT_LN_FOLD", "0")
+    ls0, lt0, ts0, losses0, g0 = _step_outputs(prec, mode, B, C, r, x, y, g1, g2, keep, target)
+    monkeypatch.delenv("DYT_LN_FOLD")
+    ls1, lt1, ts1, losses1, g1_ = _step_outputs(prec, mode, B, C, r, x, y, g1, g2, keep, target)
+    assert not torch.equal(ls0, ls1), "the folded form did not run"
+    ltol = {"fp16": 0.015, "bf16": 0.03}[prec]   # the modes' bounds vs the oracle (test_gpu_round2._step_vs_oracle)
+    e0, e1 = float((ls0 - ref_ls.detach()).abs().max()), float((ls1 - ref_ls.detach()).abs().max())
+    t0, t1 = float((lt0 - ref_lt.detach()).abs().max()), float((lt1 - ref_lt.detach()).abs().max())
+    f0, f1 = int((ts0 != ref_ts).sum()), int((ts1 != ref_ts).sum())
+    print("%s/%s B=%d: logits vs oracle kernel form %.2e / %.2e, folded %.2e / %.2e; decisions differing %d / %d of %d" % (
+        prec, mode, B, e0, t0, e1, t1, f0, f1, ts0.numel()))
+    assert e1 < ltol and t1 < ltol, (e1, t1)
+    assert f1 <= (max(6, B // 4) if prec == "fp16" else max(8, B * 3 // 2)), f1
+    assert float((ls1 - ls0).abs().max()) < ltol and float((lt1 - lt0).abs().max()) < ltol
+    for i in range(5):
+        assert abs(float(losses1[i]) - float(losses0[i])) < {"fp16": 3e-3, "bf16": 0.02}[prec] * max(1.0, abs(float(losses0[i]))), (i, losses0, losses1)
+    rel = float((g1_ - g0).norm() / g0.norm())   # the flat 1.2 M-element gradient as one vector
+    print("  gradient (flat) folded vs kernel form rel-L2 %.2e" % rel)
+    assert rel < {"fp16": 0.02, "bf16": 0.1}[prec], rel
