@@ -58,15 +58,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
     unsigned long long t_start = 0, t_loop0 = 0, t_loop1 = 0;
     if (ABL == 9) t_start = __builtin_readcyclecounter();
 
-    if constexpr (RS) {   // (the barrier of the main-loop prologue publishes ln_s; the loads overlap the first DMA stages)
-        if (tid < BM) {
-            int grow = min(m0 + tid, Mv - 1);
-            if (a_map) grow = a_map[grow];
-            const float2 st = ln_merge_parts(epi.ln_part, grow);
-            ln_s[tid] = st;
-            if (tn == 0 && m0 + tid < Mv) epi.st_out[grow] = st;
-        }
-    }
     // ---- A staging (same image as the LDS-staged kernels: [row][8 x 16 B], chunk slot XOR (row & 7)) ----
     const int lrow = lane >> 3, slot8 = lane & 7, chunk = slot8 ^ lrow;
     unsigned a_src[A_INSTR];   // element offsets (M x K < 2^31): half the registers of four 64-bit pointers
@@ -112,6 +103,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
     for (int t = 0; t < A_INSTR; ++t) stage_one(ring2, min(2, nk - 1), t);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fw0[j] = *reinterpret_cast<const bf16x8*>(wp[j] + wl);
+    if constexpr (RS) {   // behind the first DMA stages (its loads return after them anyway); the barrier below publishes ln_s
+        if (tid < BM) {
+            int grow = min(m0 + tid, Mv - 1);
+            if (a_map) grow = a_map[grow];
+            const float2 st = ln_merge_parts(epi.ln_part, grow);
+            ln_s[tid] = st;
+            if (tn == 0 && m0 + tid < Mv) epi.st_out[grow] = st;
+        }
+    }
     dma_wait_all();
     __syncthreads();
 #pragma unroll

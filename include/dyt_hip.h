@@ -42,7 +42,10 @@ extern "C" {
  *   "fp16x3f"  ... SPLIT16 = 2                                    the same forward, gradient products hi * hi (fp32-width backward)
  *   "fp16x3h"  ... SPLIT16 = 3                                    the same forward, backward pass on 16-bit operands (fp16 mode's kernels)
  *   "fp16x3q"  ... SPLIT16 = 5                                    as 3 with qkv / proj as hi * hi + two fp8 correction products
- *   "fp16f8"   ... SPLIT16 = 4                                    as 3 with every forward GEMM in that fp8-correction form */
+ *   "fp16f8"   ... SPLIT16 = 4                                    as 3 with every forward GEMM in that fp8-correction form
+ * In the two 16-bit modes LayerNorm-2 is folded into the fc1 GEMM (per-row statistics from the proj epilogue, gamma / beta folded into
+ * the frozen fc1 weight copy, normalisation in the fc1 epilogue: DESIGN.md section 5).  DYT_LN_FOLD=0 in the environment when
+ * dyt_create runs keeps it a separate kernel (LayerNorm in fp32, then rounded: the order of the reference's autocast). */
 #define DYT_PREC_FP32 0 /* exact: fp32 operands, fp32 accumulate -- the parity mode */
 #define DYT_PREC_BF16 1 /* fast: 16-bit MFMA operands (bfloat16 or IEEE half by build), fp32 accumulate, fp32 residual stream */
 
