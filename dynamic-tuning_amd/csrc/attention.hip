@@ -933,7 +933,9 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
         hi[4 + i] = s1.hi; lo[4 + i] = s1.lo;
     }
 }
-template <bool PLANES>   // PLANES: q / k / v arrive as 16-bit hi (q16 / k16 / v16) + lo planes written by the QKV epilogue: staged without conversion
+// PARTS = 1: the hi * hi product alone for S and P V (IEEE-half attention on the same planes, fp32 softmax): the complete_model pass of
+// "fp16x3q", whose output no token-keep decision depends on (its budget is the 1e-3 logit bar, not the gate's 1e-5)
+template <bool PLANES, int PARTS = 3>   // PLANES: q / k / v arrive as 16-bit hi (q16 / k16 / v16) + lo planes written by the QKV epilogue: staged without conversion
 __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, float* __restrict__ out,
                                                              float* __restrict__ lse, int nheads, bf16* __restrict__ out3,
@@ -961,10 +963,14 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
             bf16x8 ah, al, bhh, bl, vah, val, vbh, vbl;
             if constexpr (PLANES) {
                 const size_t o0 = ((size_t)bh * NT + min(r0, NT - 1)) * HD + c * 8, o1 = ((size_t)bh * NT + min(r0 + 1, NT - 1)) * HD + c * 8;
-                ah = *reinterpret_cast<const bf16x8*>(k16 + o0); al = *reinterpret_cast<const bf16x8*>(klo + o0);
-                bhh = *reinterpret_cast<const bf16x8*>(k16 + o1); bl = *reinterpret_cast<const bf16x8*>(klo + o1);
-                vah = *reinterpret_cast<const bf16x8*>(v16 + o0); val = *reinterpret_cast<const bf16x8*>(vlo + o0);
-                vbh = *reinterpret_cast<const bf16x8*>(v16 + o1); vbl = *reinterpret_cast<const bf16x8*>(vlo + o1);
+                ah = *reinterpret_cast<const bf16x8*>(k16 + o0); bhh = *reinterpret_cast<const bf16x8*>(k16 + o1);
+                vah = *reinterpret_cast<const bf16x8*>(v16 + o0); vbh = *reinterpret_cast<const bf16x8*>(v16 + o1);
+                if constexpr (PARTS == 3) {
+                    al = *reinterpret_cast<const bf16x8*>(klo + o0); bl = *reinterpret_cast<const bf16x8*>(klo + o1);
+                    val = *reinterpret_cast<const bf16x8*>(vlo + o0); vbl = *reinterpret_cast<const bf16x8*>(vlo + o1);
+                } else {
+                    al = zero8(); bl = zero8(); val = zero8(); vbl = zero8();
+                }
             } else {
             const float* k0 = kb + (size_t)min(r0, NT - 1) * HD + c * 8;
             const float* k1 = kb + (size_t)min(r0 + 1, NT - 1) * HD + c * 8;
@@ -980,9 +986,11 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
             if (r0 >= NT) { ah = zero8(); al = zero8(); }
             if (r0 + 1 >= NT) { bhh = zero8(); bl = zero8(); }
             *reinterpret_cast<bf16x8*>(Kh + r0 * RLD + c * 8) = ah;
-            *reinterpret_cast<bf16x8*>(Kl + r0 * RLD + c * 8) = al;
             *reinterpret_cast<bf16x8*>(Kh + (r0 + 1) * RLD + c * 8) = bhh;
-            *reinterpret_cast<bf16x8*>(Kl + (r0 + 1) * RLD + c * 8) = bl;
+            if constexpr (PARTS == 3) {
+                *reinterpret_cast<bf16x8*>(Kl + r0 * RLD + c * 8) = al;
+                *reinterpret_cast<bf16x8*>(Kl + (r0 + 1) * RLD + c * 8) = bl;
+            }
             if (!PLANES && k16) {
                 if (r0 < NT) *reinterpret_cast<bf16x8*>(k16 + ((size_t)bh * NT + r0) * HD + c * 8) = ah;
                 if (r0 + 1 < NT) *reinterpret_cast<bf16x8*>(k16 + ((size_t)bh * NT + r0 + 1) * HD + c * 8) = bhh;
@@ -998,7 +1006,7 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
             for (int i = 0; i < 8; ++i) {
                 bf16x2 ph = {ah[i], bhh[i]}, pl = {al[i], bl[i]};
                 *reinterpret_cast<bf16x2*>(Vth + (c * 8 + i) * TLD + r0) = ph;
-                *reinterpret_cast<bf16x2*>(Vtl + (c * 8 + i) * TLD + r0) = pl;
+                if constexpr (PARTS == 3) *reinterpret_cast<bf16x2*>(Vtl + (c * 8 + i) * TLD + r0) = pl;
             }
         }
         // ---- this wave's 32 query rows, split
@@ -1007,7 +1015,8 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
         for (int ks = 0; ks < 4; ++ks) {
             if constexpr (PLANES) {
                 const size_t o = ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8;
-                qh[ks] = *reinterpret_cast<const bf16x8*>(q16 + o); ql[ks] = *reinterpret_cast<const bf16x8*>(qlo + o);
+                qh[ks] = *reinterpret_cast<const bf16x8*>(q16 + o);
+                if constexpr (PARTS == 3) ql[ks] = *reinterpret_cast<const bf16x8*>(qlo + o);
             } else {
             const float* qp = q + ((size_t)bh * NT + qr) * HD + ks * 16 + hi * 8;
             split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[ks], ql[ks]);
@@ -1025,9 +1034,11 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
 #pragma unroll
             for (int kt = 0; kt < 7; ++kt) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Kh + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(Kl + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
-                st[kt] = MFMA32(al, qh[ks], st[kt]);   // small terms first
-                st[kt] = MFMA32(ah, ql[ks], st[kt]);
+                if constexpr (PARTS == 3) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Kl + (kt * 32 + l31) * RLD + ks * 16 + hi * 8);
+                    st[kt] = MFMA32(al, qh[ks], st[kt]);   // small terms first
+                    st[kt] = MFMA32(ah, ql[ks], st[kt]);
+                }
                 st[kt] = MFMA32(ah, qh[ks], st[kt]);
             }
         }
@@ -1055,11 +1066,12 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     vh[half][dt] = join44(Vth + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
-                    vl[half][dt] = join44(Vtl + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
+                    if constexpr (PARTS == 3) vl[half][dt] = join44(Vtl + (dt * 32 + l31) * TLD + kt * 32 + half * 16 + 4 * hi);
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp_c(st[kt][r] - m);
+                // (one-part form: a bare v_exp_f32 -- its |x| 2^-24 relative error is far below the half rounding of p)
+                const float p = PARTS == 3 ? exp_c(st[kt][r] - m) : __builtin_amdgcn_exp2f((st[kt][r] - m) * 1.44269502162933349609375f);
                 st[kt][r] = p;
                 sp[r & 3] += p;
             }
@@ -1073,8 +1085,10 @@ __global__ __launch_bounds__(448) void attn_fwd_split_kernel(const float* __rest
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    o[dt] = MFMA32(vl[half][dt], ph, o[dt]);
-                    o[dt] = MFMA32(vh[half][dt], pl, o[dt]);
+                    if constexpr (PARTS == 3) {
+                        o[dt] = MFMA32(vl[half][dt], ph, o[dt]);
+                        o[dt] = MFMA32(vh[half][dt], pl, o[dt]);
+                    }
                     o[dt] = MFMA32(vh[half][dt], ph, o[dt]);
                 }
             }
@@ -1389,7 +1403,7 @@ static int g_attn_f32_split = 0;   // process-wide: the split forward kernel for
 void set_attn_f32_split(int on) { g_attn_f32_split = on; }
 
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse, int batch,
-                    hipStream_t s, int split16, void* out3, const AttnSave16* save16, int out3_f8) {
+                    hipStream_t s, int split16, void* out3, const AttnSave16* save16, int out3_f8, int parts) {
     const int grid = batch * NH;
     if (dbg_skip(2)) return 0;
     if ((save16 || !out) && !(precision == 0 && (split16 || g_attn_f32_split))) { set_error("attention forward: 16-bit copies / no fp32 output need the split kernel"); return -1; }
@@ -1400,10 +1414,16 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (!done[dev & 63]) {
-            if (set_lds((const void*)attn_fwd_split_kernel<false>, lds) || set_lds((const void*)attn_fwd_split_kernel<true>, lds)) return -2;
+            if (set_lds((const void*)attn_fwd_split_kernel<false>, lds) || set_lds((const void*)attn_fwd_split_kernel<true>, lds) ||
+                set_lds((const void*)attn_fwd_split_kernel<true, 1>, lds)) return -2;
             done[dev & 63] = true;
         }
-        if (save16 && save16->q_lo)
+        if (parts != 3 && !(save16 && save16->q_lo && parts == 1)) { set_error("attention forward: the one-part form needs the planar q / k / v"); return -1; }
+        if (save16 && save16->q_lo && parts == 1)
+            hipLaunchKernelGGL((attn_fwd_split_kernel<true, 1>), dim3(min(grid, 256)), dim3(448), lds, s, nullptr, nullptr, nullptr, (float*)out, lse, grid,
+                               (bf16*)out3, (bf16*)save16->q, (bf16*)save16->k, (bf16*)save16->v, (bf16*)save16->o, out3_f8,
+                               (const bf16*)save16->q_lo, (const bf16*)save16->k_lo, (const bf16*)save16->v_lo);
+        else if (save16 && save16->q_lo)
             hipLaunchKernelGGL(attn_fwd_split_kernel<true>, dim3(min(grid, 256)), dim3(448), lds, s, nullptr, nullptr, nullptr, (float*)out, lse, grid,
                                (bf16*)out3, (bf16*)save16->q, (bf16*)save16->k, (bf16*)save16->v, (bf16*)save16->o, out3_f8,
                                (const bf16*)save16->q_lo, (const bf16*)save16->k_lo, (const bf16*)save16->v_lo);

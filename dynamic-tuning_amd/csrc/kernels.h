@@ -113,7 +113,8 @@ struct AttnSave16 { void* q = nullptr; void* k = nullptr; void* v = nullptr; voi
                     // planes: q / k / v above are INPUT hi planes (written by the QKV epilogue) and these the lo planes; the fp32 q / k / v arguments are unused
                     const void* q_lo = nullptr; const void* k_lo = nullptr; const void* v_lo = nullptr; };
 int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, void* out, float* lse,
-                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr, const AttnSave16* save16 = nullptr, int out3_f8 = 0);   // out may be null when out3 is given   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
+                    int batch, hipStream_t s, int split16 = 0, void* out3 = nullptr, const AttnSave16* save16 = nullptr, int out3_f8 = 0,
+                    int parts = 3);   // parts = 1 (split kernel on planar q / k / v): S and P V as the hi * hi product alone   // out may be null when out3 is given   // out3: + the output as a [M][3*768] split operand   // split16 (fp32 mode): products as three 16-bit MFMA products
 void set_attn_f32_split(int on);   // process-wide version of split16 (unit entries)
 // dqkv: [B*197][2304] AT (dq already multiplied by 1/8) ; delta: scratch [B*12][197] f32
 int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, const void* out,

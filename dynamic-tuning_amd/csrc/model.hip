@@ -180,7 +180,7 @@ struct dyt_ctx {
     char* aux_arena = nullptr;
     size_t aux_size = 0;
     bool aux_bwd16 = false;     // the aux arena holds the bwd16 buffers
-    int f8_mask_complete = 0;   // ... of a complete_model (teacher) pass: no token-keep decision depends on it (its gate output is discarded), only its logits -- "fp16x3q": 15
+    int f8_mask_complete = 0;   // ... of a complete_model (teacher) pass: no token-keep decision depends on it (its gate output is discarded), only its logits -- "fp16x3q": 15 + 32 (32 = its attention forward as the hi * hi product alone)
     int f8_mask = 0;            // classes of forward GEMMs in that form: 1 qkv, 2 proj, 4 fc1, 8 fc2, 16 patch embedding (DYT_F8_CLASSES; "fp16f8" = 31, "fp16x3q" = 3)
     bool f8 = false;            // "fp16f8": forward GEMMs as hi * hi on the f16 matrix cores + the two correction products on the fp8 ones (DYT_OPT_F32_SPLIT16 = 4; implies bwd16)
     int* pe_w_exp = nullptr; unsigned* f8_scratch = nullptr;
@@ -811,9 +811,9 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             c->f8_mask = value == 4 ? 31 : (value == 5 ? 3 : 0);
             // ... and the complete_model (teacher) pass of 5 takes the fp8-correction form for the MLP as well: its gate output is discarded, no
             // token-keep decision depends on it, only its logits (5e-5 from the reference instead of 7e-6) -- the dense pass is the heavier one
-            c->f8_mask_complete = value == 4 ? 31 : (value == 5 ? 15 : 0);
+            c->f8_mask_complete = value == 4 ? 31 : (value == 5 ? 15 + 32 : 0);   // (32: that pass's attention forward as the hi * hi product alone)
             if (const char* e = getenv("DYT_F8_CLASSES")) { if (c->f8) c->f8_mask = c->f8_mask_complete = atoi(e) & 31; }   // measurement knobs
-            if (const char* e = getenv("DYT_F8_CLASSES_COMPLETE")) { if (c->f8) c->f8_mask_complete = atoi(e) & 31; }
+            if (const char* e = getenv("DYT_F8_CLASSES_COMPLETE")) { if (c->f8) c->f8_mask_complete = atoi(e) & 63; }   // (32: that pass's attention forward as the hi * hi product alone)
             c->f8_mask_complete = (c->f8_mask_complete & ~16) | (c->f8_mask & 16);   // the patch embedding is shared between the passes
             c->gs = 1.0f;
 #ifdef DYT_FP16
@@ -1106,7 +1106,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             const bool tail_proj = c->cls_tail && l == depth - 1 && l > 0 && !tokens_out && !use_gate;
             AttnSave16 sv16{L.q16, L.k16, L.v16, nullptr};   // (the output's 16-bit copy is the hi plane of ao3)
             if (planes) { sv16.q_lo = T.qlo; sv16.k_lo = T.klo; sv16.v_lo = T.vlo; }   // bwd16: the 16-bit copies the backward reads (the fp32 output is then not needed once the proj operand is written)
-            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, (save16 || planes) ? &sv16 : nullptr, (fm >> 1) & 1));
+            RUN(1, 4.0 * B * NH * (double)NT * NT * HD, launch_attn_fwd(P, L.q, L.k, L.v, (save16 && ao3 && !tail_proj) ? nullptr : L.attn_o, L.lse, B, s, c->split16 && c->split_attn, ao3, (save16 || planes) ? &sv16 : nullptr, (fm >> 1) & 1, (planes && (fm & 32)) ? 1 : 3));
             if (tail_proj) {
                 // last block of a pass without a gate (teacher / complete model): only u[cls] is read downstream (LN2 / MLP / adapter of
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows

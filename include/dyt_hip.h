@@ -196,8 +196,9 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           bar, but token-keep decisions within ~1e-5 of the threshold can differ.
  *                           5 ("fp16x3q"): as 3 with only the attention branch's GEMMs (qkv, proj) in the form of 4, the MLP's
  *                           three-part: gate logits ~1e-5 (0 differing decisions over five seeds at B=16 and at B=128).  A complete_model
- *                           (teacher) pass takes the form of 4 for its MLP as well -- its gate output is discarded, so no token-keep
- *                           decision depends on it, only its logits (6e-5 instead of 7e-6 from the reference).
+ *                           (teacher) pass takes the form of 4 for its MLP as well and the hi * hi product alone in its attention
+ *                           forward -- its gate output is discarded, so no token-keep decision depends on it, only its logits
+ *                           (<= 1e-4 from the reference at B=16, 2.7e-4 from the fp32 mode at B=128, instead of 7e-6).
  *                           Values >= 1 allocate a second arena (the [hi | lo] weight images, split-operand scratch, the 16-bit
  *                           tensors of 3..5) the first time they are set; plain fp32 contexts do not carry it. */
 #define DYT_OPT_F32_SPLIT16 8
