@@ -166,7 +166,7 @@ int launch_ln_gather(int precision, const float* u, const float* w, const float*
 
 // the index half of launch_ln_gather alone (dense forward that is followed by a compacted backward): row_src, dst_of, total
 int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,
-                        int batch, hipStream_t s);
+                        int batch, hipStream_t s, int* drop_src = nullptr);   // drop_src: + the dropped tokens' rows, ascending (total[1] of them)
 
 // last block: LayerNorm of the cls rows only (out[b] = LN(u[b*197])), stats[b*197], u_cls[b] = AT(u[b*197])
 int launch_ln_cls(int precision, const float* u, const float* w, const float* b, void* out, float2* stats, void* u_cls,

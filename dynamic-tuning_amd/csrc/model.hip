@@ -132,6 +132,7 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
     void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
     float *g, *delta, *dmask, *tok_partial, *wg_partial, *wg_partial2;
     void *qlo = nullptr, *klo = nullptr, *vlo = nullptr;   // dyt_ctx::bwd16: lo planes of q / k / v (the hi planes are LayerS::q16 / k16 / v16), QKV epilogue -> split attention forward
+    int* drop_src = nullptr;        // dyt_ctx::ln_fold: token rows of the DROPPED tokens of the block in flight (gather_index -> their up-projection launch)
     float2* st_compact = nullptr;   // dyt_ctx::ln_fold: scratch for LN2's (mean, rstd) in logical-row order (GemmArgs::ln_scratch)
     void* dad16 = nullptr;   // dyt_ctx::bwd16: the adapter dgrad as a 16-bit [M,768] operand of tok_bwd (T.dad of the 16-bit modes)
 };
@@ -346,7 +347,7 @@ static void layout(dyt_ctx* c, bool dry) {
     for (int sl = 0; sl < cf.slots; ++sl) {
         Transients& T = c->slots[sl].T;
         T.xn = carve_at(c, M * D, dry);
-        if (c->prec != 0 && c->ln_fold) T.st_compact = carve<float2>(c, M, dry);
+        if (c->prec != 0 && c->ln_fold) { T.st_compact = carve<float2>(c, M, dry); T.drop_src = carve<int>(c, M, dry); }
         T.h1 = carve_at(c, M * DM, dry);
         T.g_at = carve_at(c, M * D, dry);
         T.dZ = carve_at(c, M * DM, dry);
@@ -1174,7 +1175,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         }
         const bool fold2 = fold && !tail;   // LN2 inside fc1: (mean, rstd) from the proj epilogue's partials, no normalised copy of u
         if (fold2) {   // (the fc1 GEMM merges the partials itself)
-            if (!dense || (masked_dense && save)) RUN(2, 0, launch_gather_index(L.keep_local, counts, L.total, L.maskf, L.row_src, L.dst_of, B, s));
+            if (!dense || (masked_dense && save)) RUN(2, 0, launch_gather_index(L.keep_local, counts, L.total, L.maskf, L.row_src, L.dst_of, B, s, T.drop_src));
         } else if (tail) {
             // nothing: T.xn already holds LN2 of the cls rows
         } else if (!dense) {
@@ -1202,8 +1203,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         }
         JOIN(sb);  // x_out now holds u + adapter(u) (two-launch form) / d_act is complete
         if (cat && !dense && !tail) {   // dropped tokens: x_out = u + adapter(u) (the kept ones are written by fc2 below)
-            up.row_mask = L.maskf;
-            RUN(0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
+            if (fold2) {   // over the dispatcher's list of dropped rows (gather + scatter) instead of every row with the kept ones skipped
+                up.a_map = T.drop_src; up.row_map = T.drop_src; up.m_dev = L.total + 1;
+            } else {
+                up.row_mask = L.maskf;
+            }
+            RUN_GEMM(EPI_AD_UP, up);
         }
         {
             GemmArgs a; a.A = T.h1; a.W = W.fc2_w; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.bias = W.fc2_b;

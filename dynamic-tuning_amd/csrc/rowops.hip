@@ -308,8 +308,10 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
 // token dispatcher index arrays without the gather (one thread per token): see ln_gather_kernel for the roles
 __global__ __launch_bounds__(256) void gather_index_kernel(const int* __restrict__ keep_local, const int* __restrict__ counts,
                                                            int* __restrict__ total, const float* __restrict__ maskf,
-                                                           int* __restrict__ row_src, int* __restrict__ dst_of, int batch) {
+                                                           int* __restrict__ row_src, int* __restrict__ dst_of, int batch,
+                                                           int* __restrict__ drop_src) {
     __shared__ int off_s;
+    __shared__ int wave_cnt[4];
     const int b = blockIdx.x, j = threadIdx.x;
     if (j < 64) {   // exclusive prefix of the per-image counts (block 0 also publishes the grand total)
         const int lim = b == 0 ? batch : b;
@@ -319,13 +321,23 @@ __global__ __launch_bounds__(256) void gather_index_kernel(const int* __restrict
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         if (j == 0) {
             off_s = b == 0 ? 0 : part;
-            if (b == 0) total[0] = part;
+            if (b == 0) { total[0] = part; total[1] = batch * NT - part; }
         }
     }
+    const int slot = b * NT + j;
+    const bool dropped = j < NT && maskf[slot] == 0.f;
+    const unsigned long long bal = __ballot(dropped);
+    if ((j & 63) == 0) wave_cnt[j >> 6] = __popcll(bal);
     __syncthreads();
     if (j >= NT) return;
-    const int slot = b * NT + j;
-    if (maskf[slot] == 0.f) dst_of[slot] = -1;
+    if (dropped) {
+        dst_of[slot] = -1;
+        if (drop_src) {   // the dropped tokens, ascending: the row list of their up-projection launch (total[1] of them)
+            int before = b * NT - off_s;   // dropped tokens of the images before this one
+            for (int w = 0; w < (j >> 6); ++w) before += wave_cnt[w];
+            drop_src[before + __popcll(bal & ((1ull << (j & 63)) - 1ull))] = slot;
+        }
+    }
     if (j < counts[b]) {
         const int src = b * NT + keep_local[(size_t)b * NT + j];
         row_src[off_s + j] = src;
@@ -333,8 +345,8 @@ __global__ __launch_bounds__(256) void gather_index_kernel(const int* __restrict
     }
 }
 int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,
-                        int batch, hipStream_t s) {
-    hipLaunchKernelGGL(gather_index_kernel, dim3(batch), dim3(256), 0, s, keep_local, counts, total, maskf, row_src, dst_of, batch);
+                        int batch, hipStream_t s, int* drop_src) {
+    hipLaunchKernelGGL(gather_index_kernel, dim3(batch), dim3(256), 0, s, keep_local, counts, total, maskf, row_src, dst_of, batch, drop_src);
     LAUNCH_CHECK();
     return 0;
 }
