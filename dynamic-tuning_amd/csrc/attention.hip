@@ -1438,6 +1438,8 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         if (!*once) { if (set_lds((const void*)attn_fwd_f32_kernel, lds)) return -2; *once = true; }
         hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid), dim3(448), lds, s, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, lse);
+    } else if (get_attn_v2() & 1) {
+        return launch_attn_fwd_v2(q, k, v, out, lse, batch, s);
     } else {
         const size_t lds = ROW_IMG + TR_IMG;
         hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(min(grid, 256)), dim3(448), lds, s, (const bf16*)q, (const bf16*)k,
@@ -1445,6 +1447,13 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
     }
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+static int g_attn_v2 = -1;   // -1: not set yet -> DYT_ATTN_V2 from the environment (default 3: both round-5 kernels)
+void set_attn_v2(int mask) { g_attn_v2 = mask; }
+int get_attn_v2() {
+    if (g_attn_v2 < 0) { const char* e = getenv("DYT_ATTN_V2"); g_attn_v2 = e ? atoi(e) : 1; }
+    return g_attn_v2;
 }
 
 static int g_attn_bwd_fused = 1;   // 16-bit modes: one kernel for dQ and dK/dV (0: the two separate kernels; 2: fused, row prefetch a head ahead)

@@ -124,6 +124,10 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
 // q_tiles: 32-row query tiles that can carry a non-zero dout (1: only the cls rows do); honoured by the fused 16-bit kernel, exact
 // 16-bit modes: 1 (default) = dQ and dK/dV of a head in one persistent kernel, 0 = the two separate kernels (process-wide)
 void set_attn_bwd_fused(int on);
+// round-5 kernels (attention_v2.hip; 16-bit modes): bit 0 = forward (online softmax, LDS-DMA images, two workgroups per CU), bit 1 = backward
+void set_attn_v2(int mask);
+int get_attn_v2();
+int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // row-wise / small kernels
