@@ -1510,6 +1510,7 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
             if (set_lds((const void*)attn_bwd_fused_bf16_kernel<true>, lds2)) return -2;
             *once = true;
         }
+        if (get_attn_v2() & 2) return launch_attn_bwd_v2(q, k, v, out, dout, lse, dqkv, batch, s, q_tiles, out_ld);
         if (g_attn_bwd_fused) {
             if (g_attn_bwd_fused == 2)
                 hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<true>, dim3(min(grid, 256)), dim3(448), lds2, s, (const bf16*)q, (const bf16*)k,

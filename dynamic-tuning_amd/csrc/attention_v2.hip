@@ -101,14 +101,81 @@ __device__ __forceinline__ void xhalf_pair(float v, float& a, float& b) {
 }
 __device__ __forceinline__ float xhalf_max(float v) { float a, b; xhalf_pair(v, a, b); return fmaxf(a, b); }   // over the two 32-lane halves, in every lane
 __device__ __forceinline__ float xhalf_sum(float v) { float a, b; xhalf_pair(v, a, b); return a + b; }
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+// Maximum of the first 8 / all 16 registers of an MFMA accumulator, v_max3 straight on the registers (fmaxf() puts a canonicalising v_max
+// in front of every MFMA output: 16 more VALU instructions per tile).  ONE asm statement that opens with the wait states the
+// matrix-core -> VALU read hazard needs (8-pass MFMA: 12): hipcc pads hazards for its own instructions only, and a bare `v_max3` on the
+// accumulators read them while the last MFMA of the chain was still writing whenever the SIMD's other wave kept the matrix pipe busy --
+// slightly different running maxima, i.e. output bits that changed from run to run (the wave that shares its SIMD with the loader never did).
+__device__ __forceinline__ float acc_max8(const f32x16& s) {
+    float t0, t1;
+    asm volatile("s_nop 11\n\tv_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %5, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\tv_max_f32 %0, %0, %1"
+                 : "=&v"(t0), "=&v"(t1)
+                 : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]));
+    return t0;
+}
+__device__ __forceinline__ float acc_max16(const f32x16& s) {
+    float t0, t1;
+    asm volatile("s_nop 11\n\tv_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %5, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\tv_max3_f32 %1, %1, %10, %11\n\t"
+                 "v_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %1, %1, %14, %15\n\tv_max3_f32 %0, %0, %16, %17\n\tv_max_f32 %0, %0, %1"
+                 : "=&v"(t0), "=&v"(t1)
+                 : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]),
+                   "v"(s[11]), "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]));
+    return t0;
 }
 #define MFMA32(a, b, c) DYT_MFMA_32x32x16((a), (b), (c))
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 8.0f * LOG2E;   // in log2 units: the running max is raised only when a tile exceeds it by more than e^8
+
+// Result tiles (X^T accumulators: lane = row of X, registers = channels) -> global rows, in two steps so that the stores can be issued
+// one at a time from inside the NEXT tile loop (a CU drains stores at ~7 B/clk; a burst of 24 stores stalls the wave for microseconds).
+// pack_rows: 16-bit conversion, then three lane exchanges that turn "32 bytes of 32 rows per store instruction" into "all 128 bytes of 8
+// rows" (the store path's cost is per cache line touched: 110 -> 102 us with 64-byte segments, -> with whole rows):
+//   v_permlane32_swap  the two half-waves' 4-channel groups        -> 8 channels = 16 B per lane
+//   v_permlane16_swap  the two 16-byte chunk pairs of a row        -> lanes r, 16 + r, 32 + r, 48 + r hold four adjacent chunks of row r (16 rows)
+//   v_mov_dpp row_ror:8 with a bank mask: the two channel tiles    -> lanes r, 8 + r, ... hold the eight chunks of row r (8 rows)
+// pk[p], p = half * 2 + sub: tile rows half*16 + sub*8 + (lane & 7); this lane holds the chunk 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + (lane >> 5).
+template <int BANKS> __device__ __forceinline__ unsigned dpp_ror8(unsigned old, unsigned src) {   // lanes of the banks in BANKS: src of lane ^ 8; others: old
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x128, 0xF, BANKS, false);
+}
+__device__ __forceinline__ void pack_rows(uint4 (&pk)[4], const f32x16 (&acc)[2], float scale) {
+    unsigned t[2][2][4];   // [dt][half][dword]
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        unsigned w[2][4];
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const int g = 2 * gp;
+            const bf16x4 a4 = {(bf16)(acc[dt][4 * g] * scale), (bf16)(acc[dt][4 * g + 1] * scale), (bf16)(acc[dt][4 * g + 2] * scale), (bf16)(acc[dt][4 * g + 3] * scale)};
+            const bf16x4 b4 = {(bf16)(acc[dt][4 * g + 4] * scale), (bf16)(acc[dt][4 * g + 5] * scale), (bf16)(acc[dt][4 * g + 6] * scale), (bf16)(acc[dt][4 * g + 7] * scale)};
+            const uint2 a = __builtin_bit_cast(uint2, a4), bb = __builtin_bit_cast(uint2, b4);
+            const auto rx = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+            const unsigned rx0 = rx[0], rx1 = rx[1], ry0 = ry[0], ry1 = ry[1];
+            w[gp][0] = rx0; w[gp][1] = ry0; w[gp][2] = rx1; w[gp][3] = ry1;   // channels 16 gp + 8 hi .. + 7 of row (lane & 31)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap(w[0][i], w[1][i], false, false);
+            const unsigned r0 = r[0], r1 = r[1];
+            t[dt][0][i] = r0; t[dt][1][i] = r1;   // rows half*16 + (lane & 15), chunk 2 * ((lane >> 4) & 1) + (lane >> 5) of channel tile dt
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        unsigned z0[4], z1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            z0[i] = dpp_ror8<0xC>(t[0][half][i], t[1][half][i]);   // lanes 0-7 of a row: tile 0 of rows 0-7; lanes 8-15: tile 1 of rows 0-7
+            z1[i] = dpp_ror8<0x3>(t[1][half][i], t[0][half][i]);   // lanes 0-7: tile 0 of rows 8-15; lanes 8-15: tile 1 of rows 8-15
+        }
+        pk[half * 2] = make_uint4(z0[0], z0[1], z0[2], z0[3]);
+        pk[half * 2 + 1] = make_uint4(z1[0], z1[1], z1[2], z1[3]);
+    }
+}
+// piece p of a packed tile; rp[p] = its global row, already advanced to this lane's chunk
+__device__ __forceinline__ void store_piece(bf16* const (&rp)[4], const bool (&ok)[4], const uint4& v, int p) {
+    if (ok[p]) *reinterpret_cast<uint4*>(rp[p]) = v;
+}
 
 // ------------------------------------------------------------------------------------------
 // forward
@@ -135,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const char* Qi = smem + 4 * IMG;
     if (wave_s == 7) {   // ---- loader ----
+        __builtin_amdgcn_s_setprio(3);   // the youngest wave of its SIMD would lose every arbitration to the compute wave it shares it with
         auto issue = [&](int bh, int buf) {
             dma_image<1>(q + (size_t)bh * NT * HD, HD, lds0 + 4 * IMG, 0, lane);
             dma_image<1>(k + (size_t)bh * NT * HD, HD, lds0 + buf * 2 * IMG, 0, lane);
@@ -197,9 +265,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
                 for (int r = 0; r < 16; ++r)
                     if (192 + (r & 3) + 8 * (r >> 2) + 4 * hi >= NT) s[r] = -INFINITY;
             }
-            // tile maximum: v_max3 straight on the accumulators (fmaxf() puts a canonicalising v_max in front of every MFMA output)
-            float mt = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[0]));
-            if (kt < 6) mt = max3(mt, max3(max3(s[8], s[9], s[10]), max3(s[11], s[12], s[13]), max3(s[14], s[15], s[8])), mt);
+            float mt = kt < 6 ? acc_max16(s) : acc_max8(s);
             mt = xhalf_max(mt) * LOG2E;
             if (__any(mt > m + RESCALE_THR)) {   // wave-uniform: raise the running max of every row of the tile, rescale l and O
                 const float mn = fmaxf(m, mt);
@@ -237,22 +303,308 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
         const float sum = xhalf_sum(l);
         if (ABL & 1) { if (sum == 123.456f) lse[0] = o[0][0] + o[1][5] + s[3]; continue; }
         if (hi == 0 && qrow < NT) lse[(size_t)bh * NT + qrow] = (m + __builtin_amdgcn_logf(sum)) * (1.0f / LOG2E);
-        // row q of O^T: this lane holds channels dt*32 + 8g + 4hi + 0..3 (g = 0..3); v_permlane32_swap pairs the groups (g, g+1) of the two
-        // half-waves so that every lane stores 16 contiguous bytes (T21 of the CDNA4 guide): 4 stores of 16 B instead of 8 of 8 B
+        // O^T tile -> whole 128-byte rows of `out` (pack_rows above)
         const float inv = 1.0f / sum;
-        bf16* op = out + ((size_t)b * NT + min(qrow, NT - 1)) * D + h * HD + hi * 8;
+        f32x16 on[2];
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int r = 0; r < 16; ++r) { on[0][r] = o[0][r]; on[1][r] = o[1][r]; }
+        uint4 pk[4];
+        pack_rows(pk, on, inv);
 #pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                const bf16x4 a4 = {(bf16)(o[dt][4 * g] * inv), (bf16)(o[dt][4 * g + 1] * inv), (bf16)(o[dt][4 * g + 2] * inv), (bf16)(o[dt][4 * g + 3] * inv)};
-                const bf16x4 b4 = {(bf16)(o[dt][4 * g + 4] * inv), (bf16)(o[dt][4 * g + 5] * inv), (bf16)(o[dt][4 * g + 6] * inv), (bf16)(o[dt][4 * g + 7] * inv)};
-                const uint2 a = __builtin_bit_cast(uint2, a4), bb = __builtin_bit_cast(uint2, b4);
-                const auto rx = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
-                const auto ry = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
-                const unsigned rx0 = rx[0], rx1 = rx[1], ry0 = ry[0], ry1 = ry[1];
-                if (qrow < NT) *reinterpret_cast<uint4*>(op + dt * 32 + 8 * g) = make_uint4(rx0, ry0, rx1, ry1);
+        for (int pc = 0; pc < 4; ++pc) {
+            const int tr_ = wave * 32 + pc * 8 + (lane & 7);
+            if (tr_ < NT)
+                *reinterpret_cast<uint4*>(out + ((size_t)b * NT + tr_) * D + h * HD + (4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + hi) * 8) = pk[pc];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dQ, dK, dV of one (image, head) in one persistent workgroup pass
+// ------------------------------------------------------------------------------------------
+// The arithmetic of attention.hip's fused kernel (phase B: wave w owns KEY tile w and walks the query tiles -> dK, dV; phase A: wave w
+// owns QUERY tile w and walks the key tiles -> dQ; S and dP are recomputed in both), on a different data path:
+//   * Q, dO, K, V are four swizzled LDS images filled by LDS-DMA; every transposed operand (dO^T, Q^T, K^T) is a ds_read_b64_tr_b16 of
+//     the same image -- no register staging, no transposed copies, no re-staging between the phases;
+//   * wave 7 is the loader.  K / V are double-buffered (head i+1's land while head i is computed); Q / dO are single-buffered and
+//     refilled as soon as phase B is over (barrier c), i.e. under phase A.  The loader also loads the rows of O and the log-sum-exp of
+//     the next head and leaves delta = rowsum(dO o) and lse log2(e) in LDS (pad rows: +inf / 0, which zeroes P and dS of the padding
+//     queries without a select) -- the compute waves issue no loads at all, so their dQ / dK / dV stores stay in flight across heads;
+//   * images are 208 rows (6 x 26 KB + 3.5 KB of row statistics = 159.5 KB of the 160 KB): tile 6 reads rows 192 .. 223, i.e. 16 rows
+//     of the NEXT image (finite data) or past the allocation (zeros); whatever they hold only reaches scores of padding rows / keys.
+constexpr int BROWS = 208;
+constexpr int BIMG = BROWS * 128;               // 26624
+constexpr int BSTAT = 2 * 2 * 224 * 4;          // lse2[2][224], delta[2][224]
+constexpr int BWD_LDS = BSTAT + 6 * BIMG;       // 163328
+
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16-byte stores of a transposed accumulator pair acc[dt][r] = X^T[channel dt*32 + 8g + 4hi + e][row = lane & 31] (r = 4g + e): see the forward kernel
+__device__ __forceinline__ void store_rows16(bf16* op /* row base + hi * 8 */, const f32x16 (&acc)[2], float scale, bool valid) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const bf16x4 a4 = {(bf16)(acc[dt][4 * g] * scale), (bf16)(acc[dt][4 * g + 1] * scale), (bf16)(acc[dt][4 * g + 2] * scale), (bf16)(acc[dt][4 * g + 3] * scale)};
+            const bf16x4 b4 = {(bf16)(acc[dt][4 * g + 4] * scale), (bf16)(acc[dt][4 * g + 5] * scale), (bf16)(acc[dt][4 * g + 6] * scale), (bf16)(acc[dt][4 * g + 7] * scale)};
+            const uint2 a = __builtin_bit_cast(uint2, a4), bb = __builtin_bit_cast(uint2, b4);
+            const auto rx = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+            const unsigned rx0 = rx[0], rx1 = rx[1], ry0 = ry[0], ry1 = ry[1];
+            if (valid) *reinterpret_cast<uint4*>(op + dt * 32 + 8 * g) = make_uint4(rx0, ry0, rx1, ry1);
+        }
+}
+
+__device__ unsigned long long g_bwd_dbg[8 + 16];   // ABL & 8 (probe builds): cycles of wave 0 in barrier (a) / phase B / barrier (c) / phase A / dq stores, heads
+template <int ABL = 0, int SETPRIO = 0, int EXPM = 0>
+__global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                             const bf16* __restrict__ v, const bf16* __restrict__ o,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16* __restrict__ dqkv, int nheads, int nq, int o_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [lse2[2][224] | delta[2][224] | Q | dO | K0 | V0 | K1 | V1]
+    float* lse_s = reinterpret_cast<float*>(smem);
+    float* del_s = lse_s + 2 * 224;
+    char* img0 = smem + BSTAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int l31 = lane & 31, hi = lane >> 5;
+    for (int i = tid; i < 6 * BIMG / 16; i += 512) reinterpret_cast<uint4*>(img0)[i] = make_uint4(0, 0, 0, 0);   // pad rows stay zero for good
+    for (int i = tid; i < 2 * 224; i += 512) { lse_s[i] = INFINITY; del_s[i] = 0.f; }
+    __syncthreads();
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(img0));
+    // Image slots.  A head uses four (Q, dO, K, V) and two are spare.  At barrier (a) of head i the spare pair takes Q / dO of head i+1 (the
+    // loader then has the whole of phase B for their row statistics); at barrier (c) the slots of Q_i / dO_i are free and take K / V of
+    // head i+1, which have phase A to land; K_i / V_i's slots are the next spare pair.  Loader and compute waves rotate the same indices.
+    int sQ = 0, sD = 1, sK = 2, sV = 3, sE = 4, sF = 5;
+    auto rotate = [&]() { const int q0 = sQ, d0 = sD, k0 = sK, v0 = sV; sQ = sE; sD = sF; sK = q0; sV = d0; sE = k0; sF = v0; };
+    if (wave_s == 7) {   // ---- loader ----
+        __builtin_amdgcn_s_setprio(3);   // the youngest wave of its SIMD loses every arbitration to the compute wave it shares it with; its few instructions gate every head
+        // rows of O and the log-sum-exp of a head into registers (25 x 16 B + 4 floats per lane), consumed by make_stats
+        bf16x8 orow[PIECES];
+        float lrow[4];
+        const int r8 = lane >> 3, c = lane & 7;
+        auto load_rows = [&](int bh) {
+            const int b = bh / NH, h = bh - b * NH;
+#pragma unroll
+            for (int it = 0; it < PIECES; ++it)
+                orow[it] = *reinterpret_cast<const bf16x8*>(o + ((size_t)b * NT + min(it * 8 + r8, NT - 1)) * o_ld + h * HD + c * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lrow[j] = lse[(size_t)bh * NT + min(lane + 64 * j, NT - 1)];
+        };
+        // Full drains only.  (A counted wait that leaves the younger DMA pieces in flight -- statistics under the flight of K / V -- was
+        // 10 % faster and gave run-to-run different results: loads of different kinds do not retire in issue order)
+#define DYT_ROWS_LANDED(N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+        auto issue_qdo = [&](int bh, int slq, int sld) {
+            const int b = bh / NH, h = bh - b * NH;
+            dma_image<1>(q + (size_t)bh * NT * HD, HD, lds0 + slq * BIMG, 0, lane);
+            dma_image<1>(dout + (size_t)b * NT * D + h * HD, D, lds0 + sld * BIMG, 0, lane);
+        };
+        auto issue_kv = [&](int bh, int slk, int slv) {
+            dma_image<1>(k + (size_t)bh * NT * HD, HD, lds0 + slk * BIMG, 0, lane);
+            dma_image<1>(v + (size_t)bh * NT * HD, HD, lds0 + slv * BIMG, 0, lane);
+        };
+        auto make_stats = [&](int ab, int sld) {   // delta = rowsum(dO o) of the head whose rows load_rows() fetched and whose dO image sits in slot sld
+            const char* dOi = img0 + sld * BIMG;
+#pragma unroll
+            for (int it = 0; it < PIECES; ++it) {
+                const int row = it * 8 + r8;
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dOi + row * 128 + ((c ^ swz(row)) << 4));
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc = fmaf((float)orow[it][i], (float)dv[i], acc);
+                acc += dpp_f32<0xB1>(acc);    // lane ^ 1
+                acc += dpp_f32<0x4E>(acc);    // lane ^ 2
+                acc += dpp_f32<0x141>(acc);   // row_half_mirror: the other quad of the 8-lane row group
+                if (c == 0 && row < NT) del_s[ab * 224 + row] = acc;
+                if (it % 5 == 4) __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting all 25 image reads (100 registers) to the top
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane + 64 * j < NT) lse_s[ab * 224 + lane + 64 * j] = lrow[j] * LOG2E;
+        };
+        int bh = blockIdx.x, ab = 0;
+        if (bh < nheads) {
+            load_rows(bh);
+            issue_qdo(bh, sQ, sD);
+            issue_kv(bh, sK, sV);
+            DYT_ROWS_LANDED(0);
+            make_stats(0, sD);
+        }
+        for (; bh < nheads; bh += gridDim.x, ab ^= 1) {
+            const int nb = bh + gridDim.x;
+            const bool more = nb < nheads && !(ABL & 4);
+            barrier_lds();   // (a) head bh may start; every wave has left head bh - gridDim.x: the spare slots take Q / dO of the next head
+            if (more) {
+                if (!(ABL & 32)) load_rows(nb);
+                issue_qdo(nb, sE, sF);
+                if (!(ABL & 64)) DYT_ROWS_LANDED(0);   // full drain (a counted wait that leaves younger pieces in flight gave run-to-run different statistics:
+                                      // loads of different kinds do not retire in issue order -- cf. DESIGN.md 7b)
+                if (!(ABL & 16)) make_stats(ab ^ 1, sF);
+            }
+            barrier_lds();   // (c) phase B of head bh is over: the slots of its Q / dO images are free and take K / V of the next head
+            if (more) {
+                issue_kv(nb, sQ, sD);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            rotate();
+        }
+#undef DYT_ROWS_LANDED
+        return;
+    }
+    // ---- compute waves ----
+    const FragAddr fa(lane);
+    const int trow = wave * 32 + l31;   // the wave's key (phase B) / query (phase A) of this lane
+    if (SETPRIO == 1 && wave_s >= 4) __builtin_amdgcn_s_setprio(1);   // the second wave of every SIMD wins arbitration: the pair falls into complementary MFMA / VALU phases
+    int buf = 0;
+    uint4 pq[4];              // packed dQ of the previous head, stored from inside this head's phase B loop
+    bf16* pq_row[4] = {nullptr, nullptr, nullptr, nullptr};   // its rows (null: nothing pending)
+    bool pq_ok[4] = {false, false, false, false};
+    for (int bh = blockIdx.x; bh < nheads; bh += gridDim.x, buf ^= 1, rotate()) {
+        const int b = bh / NH, h = bh - b * NH;
+        const char* Qi = img0 + sQ * BIMG;
+        const char* dOi = img0 + sD * BIMG;
+        const char* Ki = img0 + sK * BIMG;
+        const char* Vi = img0 + sV * BIMG;
+        const float* L2 = lse_s + buf * 224;
+        const float* Dl = del_s + buf * 224;
+        unsigned long long t0 = 0;
+        if (ABL & 8) t0 = __builtin_readcyclecounter();
+        barrier_lds();   // (a)
+        if (ABL & 8) { const unsigned long long t1 = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_bwd_dbg[0], t1 - t0); t0 = t1; }
+        bf16* orow[4];   // rows wave*32 + p*8 + (lane & 7) of dqkv, at this lane's 16-byte chunk of the head's 64 channels
+        bool ook[4];
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int tr_ = wave * 32 + pc * 8 + (lane & 7);
+            ook[pc] = tr_ < NT;
+            orow[pc] = dqkv + ((size_t)b * NT + min(tr_, NT - 1)) * (3 * D) + h * HD + (4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + hi) * 8;
+        }
+        uint4 pkK[4], pkV[4];   // packed dK / dV of this head, stored from inside the phase A loop
+        bf16* const okrow[4] = {orow[0] + D, orow[1] + D, orow[2] + D, orow[3] + D};
+        bf16* const ovrow[4] = {orow[0] + 2 * D, orow[1] + 2 * D, orow[2] + 2 * D, orow[3] + 2 * D};
+        // ---------------- phase B: dK, dV of key tile `wave` ----------------
+        if (!(ABL & 2)) {
+            bf16x8 kf[4], vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = row_frag(Ki, fa.row[ks] + wave * 4096); vf[ks] = row_frag(Vi, fa.row[ks] + wave * 4096); }
+            f32x16 aK[2], aV[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aK[0][r] = 0.f; aK[1][r] = 0.f; aV[0][r] = 0.f; aV[1][r] = 0.f; }
+#pragma unroll 1
+            for (int qt = 0; qt < nq; ++qt) {
+                if (SETPRIO == 2) { if ((qt ^ (wave_s >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+                if (SETPRIO == 3) __builtin_amdgcn_s_setprio(1);
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = MFMA32((EXPM & 4) ? kf[ks] : row_frag(Qi, fa.row[ks] + qt * 4096), kf[ks], s);      // S[q][key]: q in registers, key = lane
+                    dp = MFMA32((EXPM & 4) ? vf[ks] : row_frag(dOi, fa.row[ks] + qt * 4096), vf[ks], dp);   // dP[q][key]
+                }
+                if (SETPRIO == 3) __builtin_amdgcn_s_setprio(0);
+                // q = qt*32 + 8g + 4hi + e for register 4g + e; the padding queries have lse2 = +inf (P = 0) and delta = 0
+                f32x16 p;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 L4 = *reinterpret_cast<const float4*>(L2 + qt * 32 + 8 * g + 4 * hi);
+                    const float4 D4 = *reinterpret_cast<const float4*>(Dl + qt * 32 + 8 * g + 4 * hi);
+                    const float Ls[4] = {L4.x, L4.y, L4.z, L4.w}, Ds[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float pv = (EXPM & 1) ? fmaf(s[r], LOG2E, -Ls[e]) : __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -Ls[e]));
+                        p[r] = pv;
+                        s[r] = pv * (dp[r] - Ds[e]);   // dS
+                    }
+                }
+                if (pq_row[0] && qt < 4) {   // wave-uniform; constant register indices
+                    if (qt == 0) store_piece(pq_row, pq_ok, pq[0], 0);
+                    else if (qt == 1) store_piece(pq_row, pq_ok, pq[1], 1);
+                    else if (qt == 2) store_piece(pq_row, pq_ok, pq[2], 2);
+                    else store_piece(pq_row, pq_ok, pq[3], 3);
+                }
+                const int nh = qt < 6 ? 2 : 1;   // queries 208 .. 223 are all padding
+                for (int half = 0; half < nh; ++half) {
+                    const bf16x8 pf = half ? pack8(p, 8) : pack8(p, 0);
+                    const bf16x8 dsf = half ? pack8(s, 8) : pack8(s, 0);
+                    const int off = qt * 4096 + half * 2048;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        aV[dt] = MFMA32((EXPM & 2) ? vf[dt] : tr_frag(dOi, fa.tr[dt][0] + off, fa.tr[dt][1] + off), pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                        aK[dt] = MFMA32((EXPM & 2) ? kf[dt] : tr_frag(Qi, fa.tr[dt][0] + off, fa.tr[dt][1] + off), dsf, aK[dt]);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                    }
+                }
+            }
+            if (pq_row[0]) {   // a short phase B (nq < 4): the rest of the previous head's dQ
+                if (nq < 2) store_piece(pq_row, pq_ok, pq[1], 1);
+                if (nq < 3) store_piece(pq_row, pq_ok, pq[2], 2);
+                if (nq < 4) store_piece(pq_row, pq_ok, pq[3], 3);
+            }
+            pack_rows(pkK, aK, 1.0f);
+            pack_rows(pkV, aV, 1.0f);
+            if ((ABL & 1) && aK[0][0] == 123.456f) dqkv[0] = (bf16)(aK[1][3] + aV[0][2] + aV[1][7]);
+        }
+        // ---------------- phase A: dQ of query tile `wave` ----------------
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(Qi, fa.row[ks] + wave * 4096); dof[ks] = row_frag(dOi, fa.row[ks] + wave * 4096); }
+        const float L = L2[trow], dl = Dl[trow];
+        if (ABL & 8) { const unsigned long long t1 = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_bwd_dbg[1], t1 - t0); if (lane == 0) atomicAdd(&g_bwd_dbg[8 + wave], t1 - t0); t0 = t1; }
+        barrier_lds();   // (c): every wave holds its q / dO rows; the loader refills the Q / dO images
+        if (ABL & 8) { const unsigned long long t1 = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_bwd_dbg[2], t1 - t0); t0 = t1; }
+        f32x16 dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+        if (!(ABL & 2) && wave < nq) {
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt) {
+                if (SETPRIO == 2) { if ((kt ^ (wave_s >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = MFMA32(row_frag(Ki, fa.row[ks] + kt * 4096), qf[ks], s);      // S^T[key][q]
+                    dp = MFMA32(row_frag(Vi, fa.row[ks] + kt * 4096), dof[ks], dp);   // dP^T[key][q]
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -L));
+                    s[r] = pv * (dp[r] - dl);   // dS^T
+                    if (kt == 6 && 192 + (r & 3) + 8 * (r >> 2) + 4 * hi >= NT) s[r] = 0.f;
+                }
+                const int nh = kt < 6 ? 2 : 1;   // keys 208 .. 223 are all padding
+#pragma unroll
+                for (int half = 0; half < nh; ++half) {
+                    const bf16x8 dsf = pack8(s, half * 8);
+                    const int off = kt * 4096 + half * 2048;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        dq[dt] = MFMA32(tr_frag(Ki, fa.tr[dt][0] + off, fa.tr[dt][1] + off), dsf, dq[dt]);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+                }
+                if (!(ABL & 3)) {   // 8 pieces of dK / dV over the 7 key tiles
+                    if (kt < 4) store_piece(okrow, ook, pkK[kt & 3], kt);
+                    else store_piece(ovrow, ook, pkV[kt - 4], kt - 4);
+                    if (kt == 6) store_piece(ovrow, ook, pkV[3], 3);
+                }
+            }
+        } else if (!(ABL & 3)) {   // no phase A for this wave (cls-only tail): all eight pieces now
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { store_piece(okrow, ook, pkK[i], i); store_piece(ovrow, ook, pkV[i], i); }
+        }
+        if (ABL & 8) { const unsigned long long t1 = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_bwd_dbg[3], t1 - t0); if (lane == 0) atomicAdd(&g_bwd_dbg[16 + wave], t1 - t0); t0 = t1; }
+        pack_rows(pq, dq, 0.125f);
+        if (!(ABL & 1)) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) { pq_row[pc] = orow[pc]; pq_ok[pc] = ook[pc]; }
+        }
+        else if (dq[0][0] == 123.456f) dqkv[1] = (bf16)(dq[1][3]);
+        if (ABL & 8) { const unsigned long long t1 = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_bwd_dbg[4], t1 - t0); atomicAdd(&g_bwd_dbg[5], 1ull); } }
+    }
+    if (pq_row[0]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_piece(pq_row, pq_ok, pq[i], i);
     }
 }
 
@@ -276,6 +628,22 @@ int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, f
     }
     auto* kern = pipe ? av2::attn_fwd_v2_kernel<true> : av2::attn_fwd_v2_kernel<false>;
     hipLaunchKernelGGL(kern, dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, grid);
+    DYT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_bwd_v2(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, void* dqkv,
+                       int batch, hipStream_t s, int q_tiles, int out_ld) {
+    const int grid = batch * NH;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (!done[dev & 63]) {
+        if (set_lds_v2((const void*)av2::attn_bwd_v2_kernel<0>, av2::BWD_LDS)) return -2;
+        done[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(av2::attn_bwd_v2_kernel<0>, dim3(min(grid, 256)), dim3(512), av2::BWD_LDS, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, grid, q_tiles, out_ld);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }

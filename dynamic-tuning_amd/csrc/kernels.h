@@ -128,6 +128,8 @@ void set_attn_bwd_fused(int on);
 void set_attn_v2(int mask);
 int get_attn_v2();
 int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s);
+int launch_attn_bwd_v2(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, void* dqkv,
+                       int batch, hipStream_t s, int q_tiles, int out_ld);
 
 // ------------------------------------------------------------------------------------------
 // row-wise / small kernels
