@@ -1452,7 +1452,7 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
 static int g_attn_v2 = -1;   // -1: not set yet -> DYT_ATTN_V2 from the environment (default 3: both round-5 kernels)
 void set_attn_v2(int mask) { g_attn_v2 = mask; }
 int get_attn_v2() {
-    if (g_attn_v2 < 0) { const char* e = getenv("DYT_ATTN_V2"); g_attn_v2 = e ? atoi(e) : 1; }
+    if (g_attn_v2 < 0) { const char* e = getenv("DYT_ATTN_V2"); g_attn_v2 = e ? (atoi(e) & 3) : 3; }
     return g_attn_v2;
 }
 

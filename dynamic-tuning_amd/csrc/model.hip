@@ -842,6 +842,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             return DYT_OK;
         }
         case DYT_OPT_ATTN_BWD_FUSED: set_attn_bwd_fused(value); return DYT_OK;   // process-wide
+        case DYT_OPT_ATTN_V2: set_attn_v2(value & 3); return DYT_OK;             // process-wide
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
             c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
@@ -852,6 +853,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
 
 extern "C" int dyt_set_global_option(int option, int value) {
     if (option == DYT_OPT_ATTN_BWD_FUSED) { set_attn_bwd_fused(value); return DYT_OK; }
+    if (option == DYT_OPT_ATTN_V2) { set_attn_v2(value & 3); return DYT_OK; }
     if (option == DYT_OPT_F32_SPLIT16) { set_attn_f32_split(value); return DYT_OK; }   // unit entry dyt_attention(precision 0): split forward kernel
     set_error("option %d is not process-wide", option);
     return DYT_ERR_ARG;

@@ -202,8 +202,16 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           Values >= 1 allocate a second arena (the [hi | lo] weight images, split-operand scratch, the 16-bit
  *                           tensors of 3..5) the first time they are set; plain fp32 contexts do not carry it. */
 #define DYT_OPT_F32_SPLIT16 8
+/*   DYT_OPT_ATTN_V2             bit mask, default 3 (environment DYT_ATTN_V2 overrides the default).  16-bit modes: bit 0 = the round-5
+ *                           attention FORWARD kernel (csrc/attention_v2.hip: K / V / Q as swizzled LDS images filled by LDS-DMA from a loader
+ *                           wave, V^T fragments by ds_read_b64_tr_b16 from the row-major image, online softmax per 32-key tile), bit 1 = the
+ *                           round-5 BACKWARD kernel (four DMA images, every transposed operand a transposed read of the same image, row
+ *                           statistics by the loader wave, results stored as whole rows from inside the next tile loop).  0: the round 1-4
+ *                           kernels of csrc/attention.hip (DYT_OPT_ATTN_BWD_FUSED then selects among those).  Same arithmetic contract;
+ *                           different summation order, so results agree to rounding, not bit for bit.  PROCESS-wide. */
+#define DYT_OPT_ATTN_V2 9
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
-/* the process-wide options (DYT_OPT_ATTN_BWD_FUSED) without a context: unit entries such as dyt_attention() see them too */
+/* the process-wide options (DYT_OPT_ATTN_BWD_FUSED, DYT_OPT_ATTN_V2) without a context: unit entries such as dyt_attention() see them too */
 int dyt_set_global_option(int option, int value);
 
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library

@@ -121,6 +121,7 @@ def test_fused_attention_backward_is_bitwise_the_two_kernel_form(B):
     for fp16 in (False, True):
         L = _lib.lib(fp16=fp16)
         res = []
+        check(L.dyt_set_global_option(_lib.OPT_ATTN_V2, 0))   # the round 1-4 kernels (round 5's are compared with them in test_gpu_round5.py)
         for mode in (0, 1, 2, 1):
             check(L.dyt_set_global_option(_lib.OPT_ATTN_BWD_FUSED, mode))
             out = torch.full((B * 197, 768), float("nan"), device="cuda")
@@ -129,6 +130,7 @@ def test_fused_attention_backward_is_bitwise_the_two_kernel_form(B):
             torch.cuda.synchronize()
             res.append(dqkv.clone())
         check(L.dyt_set_global_option(_lib.OPT_ATTN_BWD_FUSED, 1))
+        check(L.dyt_set_global_option(_lib.OPT_ATTN_V2, 3))
         assert torch.isfinite(res[0]).all()
         for r in res[1:]:
             assert torch.equal(r, res[0]), (B, fp16, int((r != res[0]).sum()))
