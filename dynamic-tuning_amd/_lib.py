@@ -117,6 +117,7 @@ SYMBOLS = {
     "dyt_allreduce_grads": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dyt_clip_grad_norm": (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp]),
     "dyt_debug_dispatch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dyt_debug_dact": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "dyt_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dyt_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_linear_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -1848,6 +1848,24 @@ extern "C" int dyt_debug_dispatch(dyt_ctx* c, int slot, int layer, int32_t* row_
     return DYT_OK;
 }
 
+// Saved adapter bottleneck relu(down(u)) (times the dropout scale) of one block of a saved pass, as fp32 [rows, 64]; *rows_out = B*197,
+// or B for the last block in the cls-only tail form.  Test accessor (tests/parity_rules.py checks which side of the ReLU a unit is on).
+extern "C" int dyt_debug_dact(dyt_ctx* c, int slot, int layer, float* out, int* rows_out, void* stream) {
+    if (!c || !out || slot < 0 || slot >= c->cfg.slots || layer < 0 || layer >= c->cfg.depth) { set_error("bad slot / layer"); return DYT_ERR_ARG; }
+    const Slot& S = c->slots[slot];
+    if (S.batch < 1) { set_error("slot %d holds no pass", slot); return DYT_ERR_STATE; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool tail = c->cls_tail && layer == c->cfg.depth - 1;
+    const size_t rows = tail ? (size_t)S.batch : (size_t)S.batch * NT, n = rows * RP;
+    const LayerS& L = S.L[layer];
+    if (rows_out) *rows_out = (int)rows;
+    if (S.saved16 && L.dact16) hipLaunchKernelGGL(to_f32_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)L.dact16, out, n);
+    else if (c->prec == DYT_PREC_FP32) DYT_HIP_CHECK(hipMemcpyAsync(out, L.d_act, n * 4, hipMemcpyDeviceToDevice, s));
+    else hipLaunchKernelGGL(to_f32_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)L.d_act, out, n);
+    DYT_HIP_CHECK(hipGetLastError());
+    return DYT_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // single-kernel entry points (unit tests).  These allocate scratch and synchronise: test-only.
 // ------------------------------------------------------------------------------------------

@@ -305,6 +305,14 @@ class DyTEngine:
                                             stream_ptr()))
         return row_src, dst_of, counts, total
 
+    def debug_dact(self, slot, layer):
+        """Saved adapter bottleneck of one block of a saved pass as fp32 [rows, 64] on the CPU (rows = B*197, or B for the cls-only last block)."""
+        out = torch.empty(int(self.cfg.max_batch) * 197 * 64, device=self.device, dtype=torch.float32)
+        rows = ctypes.c_int(0)
+        self._ck(self.L.dyt_debug_dact(self.h, int(slot), int(layer), ptr(out), ctypes.byref(rows), stream_ptr()))
+        torch.cuda.synchronize()
+        return out[:rows.value * 64].reshape(rows.value, 64).cpu()
+
     def set_grad_scale_log2(self, k):
         """DYT_OPT_GRAD_SCALE_LOG2: the fixed loss scale of the 16-bit gradient operands (never visible in a returned gradient)."""
         from _lib import OPT_GRAD_SCALE_LOG2

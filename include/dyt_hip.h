@@ -324,6 +324,9 @@ int dyt_clip_grad_norm(dyt_ctx* ctx, float* grad, int64_t numel, float max_norm,
  *   any pointer may be NULL. */
 int dyt_debug_dispatch(dyt_ctx* ctx, int slot, int layer, int32_t* row_src, int32_t* dst_of, int32_t* counts, int32_t* total,
                        void* stream);
+/* Test accessor: the adapter bottleneck relu(down(u)) (x dropout scale) a saved pass holds for `layer`, as fp32 [rows, 64] (64 = the
+ * padded rank); *rows_out = B*197, or B when the last block ran in the cls-only tail form.  out: device memory for B*197*64 floats. */
+int dyt_debug_dact(dyt_ctx* ctx, int slot, int layer, float* out, int* rows_out, void* stream);
 
 /* ---- sub-module entry points: they allocate scratch and synchronise; not for the hot loop ---- */
 /* Adapter.forward (models/dynamic_adapter.py:120-140, layernorm option "none"): out[M,768] = [residual +] scale *

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 import gpu_diag as D  # noqa: E402
 import synth  # noqa: E402
 from oracle import dyt_oracle as O  # noqa: E402
+import parity_rules as PR  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -52,26 +53,15 @@ SPLIT_MODES = ("fp16x3", "fp16x3f", "fp16x3h", "fp16x3q", "fp16f8")   # fp32 dat
 def _grad_tol(name, precision):
     if precision in ("fp32", "fp16x3", "fp16x3f"):
         return 2e-3
-    if precision in ("fp16x3h", "fp16x3q", "fp16f8"):   # 16-bit backward pass on the exact forward's masks: measured <= 2.0e-3 at B=16 over five seeds
-        return 4e-3
+    if precision in ("fp16x3h", "fp16x3q", "fp16f8"):
+        # 16-bit backward pass on the exact forward's masks.  Worst tensor per draw, B=16, five seeds (test_parity_modes_vs_oracle_over_seeds prints
+        # the table): fp16x3h 7.6e-4 ... 1.4e-3, fp16x3q <= 1.4e-3, fp16f8 6.8e-4 ... 2.0e-3; the masked-mode and VTAB-shape steps of this file reach
+        # 2.0e-3.  Bound = 1.5 x the worst measured (round 4 had 4e-3 here).
+        return 3e-3
     for k, v in (FP16_GRAD_TOL if precision == "fp16" else BF16_GRAD_TOL).items():
         if k in name:
             return v
     return 0.1
-
-
-def _without_relu_side_units(got, gr, e, what, max_units=2):
-    """Relative L2 error of a down_proj gradient ([r,768] weight or [r] bias) without its `max_units` worst bottleneck units.
-    A unit whose pre-activation sits within the forward's round-off of zero takes the other side of the ReLU: the whole difference
-    then lives in that unit's row of the gradient (the derivative is discontinuous there, in the reference as well).  The last
-    block runs its adapter on the B cls rows only, so one unit of one row is 1 / (B r) of the mask there."""
-    rows = (got - gr).reshape(gr.shape[0], -1).norm(dim=1)
-    bad = rows.argsort(descending=True)[:max_units]
-    keep_rows = torch.ones(gr.shape[0], dtype=torch.bool)
-    keep_rows[bad] = False
-    e2 = float((got - gr)[keep_rows].norm() / (gr[keep_rows].norm() + 1e-20))
-    print("%s: rel-L2 %.2e, %.2e without bottleneck units %s (ReLU side differs)" % (what, e, e2, bad.tolist()))
-    return e2
 
 
 def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16", precs=("fp32", "fp16x3h", "fp16x3q", "fp16f8", "fp16", "bf16")):
@@ -84,6 +74,7 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16", precs=("fp32",
     d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
     ref_ls, ref_lt, ref_ts = ref_ls.detach(), ref_lt.detach(), tok["token_select"].detach()
     z = ((tok["token_logits"].detach()[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0).abs()   # decision margins [12,B,196]
+    band = PR.tie_band(sd, x, g1[0], g2[0], keep[0], mode, tok["token_logits"].detach()[..., 0], key=("step", B, C, r, mode, seed))   # [12], z units
     for prec in precs:
         m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
         m.train()
@@ -98,12 +89,13 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16", precs=("fp32",
         assert float((ls.cpu() - ref_ls).abs().max()) < ltol, (prec, float((ls.cpu() - ref_ls).abs().max()))
         assert float((lt.cpu() - ref_lt).abs().max()) < ltol
         flip = ts.cpu() != ref_ts[..., 0].float()
-        if prec == "fp32" or prec in SPLIT_MODES:   # bit-exact wherever the decision is not within round-off of the threshold
-            assert int((flip & (z.permute(1, 0, 2) > (1e-4 if prec == "fp16f8" else 2e-5))).sum()) == 0, int(flip.sum())
-            assert int(flip.sum()) <= 2
-            print("%s %s/%s: logits %.2e / %.2e, %d of %d decisions differ" % (label, prec, mode, float((ls.cpu() - ref_ls).abs().max()),
-                                                                              float((lt.cpu() - ref_lt).abs().max()), int(flip.sum()), flip.numel()))
-            if int(flip.sum()):   # a near-tie went the other way: the later blocks see another token set
+        if prec == "fp32" or prec in SPLIT_MODES:   # bit-exact outside the reference's own fp32 tie band (tests/parity_rules.py) -- one rule for every mode
+            nflip, outside, zmax, blk = PR.judge_decisions(flip, z.permute(1, 0, 2), band)
+            print("%s %s/%s: logits %.2e / %.2e, %d of %d decisions differ (first in block %d: largest margin %.1e, tie band %.1e, %d outside it)" % (
+                label, prec, mode, float((ls.cpu() - ref_ls).abs().max()), float((lt.cpu() - ref_lt).abs().max()), nflip, flip.numel(), blk, zmax,
+                float(band[blk]) if blk >= 0 else 0.0, outside))
+            assert outside == 0, (prec, nflip, outside, zmax, blk)
+            if nflip:   # a tie went the other way: the later blocks see another token set
                 del m, eng
                 torch.cuda.empty_cache()
                 continue
@@ -116,6 +108,7 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16", precs=("fp32",
             ref = float(d_ref[k])
             assert abs(float(losses[i]) - ref) < {"fp16": 3e-3, "bf16": 0.02, "fp16f8": 2e-4}.get(prec, 1e-4) * max(1.0, abs(ref)), (prec, k, float(losses[i]), ref)
         worst, scalars = {}, {}
+        relu = PR.ReluSideBudget(eng, sd, x, g1, g2, keep, mode)
         for n, gr in g_ref.items():
             got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
             kind = n.split(".", 2)[-1]
@@ -124,7 +117,7 @@ def _step_vs_oracle(B, C, r, mode, target, seed=31, label="B=16", precs=("fp32",
                 continue
             e = float((got - gr).norm() / (gr.norm() + 1e-20))
             if e >= _grad_tol(n, prec) and prec in SPLIT_MODES and "down_proj" in n:
-                e = _without_relu_side_units(got, gr, e, "%s %s/%s %s" % (label, prec, mode, n))
+                e = relu.without_side_units(n, got, gr, e, "%s %s/%s %s" % (label, prec, mode, n), fwd_roundoff=1e-4)
             assert e < _grad_tol(n, prec), (prec, mode, n, e)
             worst[kind] = max(worst.get(kind, 0.0), e)
         for kind, pairs in scalars.items():
@@ -425,9 +418,7 @@ def test_video_training_step_at_train_video_sh_size(precision):
         e = float((got - gr).norm() / max(float(gr.norm()), {"fp32": 1e-4, "fp16x3q": 3e-4, "fp16": 3e-4, "bf16": 1e-3}[precision]))
         kind = n.split(".", 2)[-1] if n.startswith("blocks.") else n
         tol = _grad_tol(n, precision) if n.startswith("blocks.") or n.startswith("head") else {"fp32": 2e-3, "fp16x3q": 4e-3, "fp16": 0.01, "bf16": 0.05}[precision]
-        if e >= tol and precision in SPLIT_MODES and "down_proj" in n:
-            e = _without_relu_side_units(got, gr, e, "video 16x8 %s %s" % (precision, n))
-        assert e < tol, (precision, n, e)
+        assert e < tol, (precision, n, e)   # (round 4 set "ReLU-side" rows aside here without checking them; removed)
         worst[kind] = max(worst.get(kind, 0.0), e)
     a, b = torch.tensor(scal, dtype=torch.float64).unbind(1)
     e = float((a - b).norm() / (b.norm() + 1e-20))

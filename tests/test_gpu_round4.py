@@ -7,7 +7,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import synth  # noqa: E402
-from test_gpu_round2 import _bench_model, _without_relu_side_units  # noqa: E402
+from test_gpu_round2 import _bench_model, _grad_tol  # noqa: E402
+import parity_rules as PR  # noqa: E402
 
 
 @pytest.mark.parametrize("M,N,K", [(3152, 2304, 768), (25216, 2304, 768), (25216, 768, 3072), (17690, 3072, 768), (128, 768, 768)])
@@ -39,16 +40,20 @@ def test_linear_split_forms_vs_fp64(M, N, K):
     assert errs[8] < 1e-4 and errs[8] < plain / 4, (errs, plain)
 
 
-def _check_flips(prec, flip, z):
-    """flip, z: [B,12,196] decisions that differ from the reference / the reference's decision margins |(logit + g) / tau|.
-    fp16x3h / fp16x3q: bit-exact wherever the margin exceeds fp32 round-off of the threshold.  fp16f8 (gate logits ~5e-5 off): only
-    near-ties may differ in the FIRST block that differs at all (margin < 1e-4); a flipped token changes what every later block sees,
-    so the decisions of the blocks after it are consequences (a cascade of a few more), bounded in number."""
-    n = int(flip.sum())
-    if prec != "fp16f8":
-        assert int((flip & (z > 2e-5)).sum()) == 0 and n <= 2, n
-        return
+def _check_flips(prec, flip, z, band):
+    """flip, z: [B,12,196] decisions that differ from the reference / the reference's decision margins |(logit + g) / tau|; band: [12], the
+    reference's own fp32 tie band (tests/parity_rules.py).  ONE rule for every mode: a decision may differ only inside the band.
+    fp16x3h / fp16x3q (gate logits 0.5 - 1e-5 from the reference): asserted.  fp16f8 (gate logits ~5e-5, i.e. ~25x the band): the same rule is
+    evaluated and REPORTED; a flip outside the band is tolerated up to a margin of 1e-4 in the first block that differs (its later decisions
+    are consequences), which is why fp16f8 is not the parity mode -- it keeps its masks by the draw, not by construction."""
+    n, outside, zmax, blk = PR.judge_decisions(flip, z, band)
     if n:
+        print("    %s: %d decision(s) differ; first in block %d, largest margin there %.1e (tie band %.1e): %s" % (
+            prec, n, blk, zmax, float(band[blk]), "inside the band" if not outside else "%d OUTSIDE the band" % outside))
+    if prec != "fp16f8":
+        assert outside == 0, (prec, n, outside, zmax, blk)
+        return
+    if outside:
         first = int(flip.any(dim=2).any(dim=0).nonzero()[0])
         assert int((flip[:, first] & (z[:, first] > 1e-4)).sum()) == 0, (first, float(z[:, first][flip[:, first]].max()))
         assert n <= 12, n
@@ -69,6 +74,7 @@ def test_parity_modes_vs_oracle_over_seeds(prec, seed):
     d_ref, g_ref, (ref_ls, ref_lt, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=target)
     ref_ts = tok["token_select"].detach()
     z = ((tok["token_logits"].detach()[..., 0].permute(1, 0, 2) + g1[0] - g2[0]) / 5.0).abs()
+    band = PR.tie_band(sd, x, g1[0], g2[0], keep[0], mode, tok["token_logits"].detach()[..., 0], key=("step", B, C, r, mode, seed))
     m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
     m.train()
     eng = m.engine(B, torch.device("cuda", 0))
@@ -80,7 +86,7 @@ def test_parity_modes_vs_oracle_over_seeds(prec, seed):
     # fp16x3h: the fp16x3 forward (gate logits 5e-6 from the reference).  fp16f8: gate logits ~5e-5 -- a decision whose margin
     # |(logit + g) / tau| is below ~1e-5 can come out the other way (seed 61: one of 37 632, margin 3.6e-7); such a token then changes
     # what the later blocks see, so the draw is checked for the logit bar and the decisions only
-    _check_flips(prec, flip, z.permute(1, 0, 2))
+    _check_flips(prec, flip, z.permute(1, 0, 2), band)
     if int(flip.sum()):   # measured: fp16f8 seeds 61 (margin 3.6e-7) and 71; none in fp16x3h / fp16x3q
         assert prec == "fp16f8" and et < 1e-3, (prec, et)
         print("%s seed %d: logits %.2e / %.2e, %d decision(s) at margin %.1e flipped: student logits / losses / gradients not compared" % (
@@ -90,20 +96,21 @@ def test_parity_modes_vs_oracle_over_seeds(prec, seed):
     for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")):
         assert abs(float(losses[i]) - float(d_ref[k])) < 1e-4 * max(1.0, abs(float(d_ref[k]))), (k, float(losses[i]), float(d_ref[k]))
     worst, wname = 0.0, ""
+    relu = PR.ReluSideBudget(eng, sd, x, g1, g2, keep, mode)
     for n, gr in g_ref.items():
         if gr.numel() == 1:
             continue
         got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
         e = float((got - gr).norm() / (gr.norm() + 1e-20))
-        if e >= 2e-3 and "down_proj" in n:
-            e = _without_relu_side_units(got, gr, e, "%s seed %d %s" % (prec, seed, n))
+        if e >= _grad_tol(n, prec) and "down_proj" in n:
+            e = relu.without_side_units(n, got, gr, e, "%s seed %d %s" % (prec, seed, n), fwd_roundoff=1e-4)
         if e > worst:
             worst, wname = e, n
     print("%s seed %d: logits %.2e / %.2e, gate flips %d of %d (min margin of a flip %.1e), worst gradient rel-L2 %.2e (%s)" % (
         prec, seed, es, et, int(flip.sum()), flip.numel(), float(z.permute(1, 0, 2)[flip].min()) if int(flip.sum()) else 0.0, worst, wname))
     # measured over the five draws: fp16x3h 7.6e-4 ... 1.4e-3; fp16f8 6.8e-4 ... 2.0e-3 -- the lowest blocks' adapter / gate gradients carry
     # the round-off of the whole 16-bit backward chain above them (the fp16 mode itself: 1e-3 ... 4e-2, test_gpu_round2.py)
-    assert worst < (3e-3 if prec == "fp16f8" else 2e-3), (wname, worst)
+    assert worst < _grad_tol(wname, prec), (wname, worst)   # 3e-3 = 1.5 x the worst of the table above
 
 
 @pytest.mark.parametrize("prec", ["fp16x3h", "fp16x3q", "fp16f8"])
@@ -135,7 +142,16 @@ def test_parity_modes_match_the_fp32_mode_at_bench_size(prec):
     print("B=128 %s vs fp32 mode: logits %.2e / %.2e, %d of %d decisions differ (largest margin of one %.1e)" % (
         prec, es, et, int(flip.sum()), flip.numel(), float(z[flip].max()) if int(flip.sum()) else 0.0))
     assert et < 1e-3, et
-    _check_flips(prec, flip, z)
+    # no fp64 reference at this size (the oracle needs minutes): the band of the B=16 draw with the same weights (seed 31), per block
+    from oracle import dyt_oracle as O
+    xb, yb = synth.make_batch(16, C, seed=31)
+    gb1, gb2 = synth.make_noise(16, seed=32)
+    kb = synth.make_dropout_masks(16, r, seed=33)
+    sdb = synth.make_state_dict(C, r, seed=0, kind="test", gate_bias=0.85)
+    with torch.no_grad():
+        _, ob = O.forward(sdb, xb, gb1[0], gb2[0], kb[0], scale=0.1, training=True, mode="compact")
+    band = PR.tie_band(sdb, xb, gb1[0], gb2[0], kb[0], "compact", ob["token_logits"][..., 0], key=("step", 16, C, r, "compact", 31))
+    _check_flips(prec, flip, z, band)
     if not int(flip.sum()):
         assert es < 1e-3, es
         assert float((a[3] - b[3]).abs().max()) < 1e-3
