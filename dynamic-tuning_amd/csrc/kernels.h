@@ -345,7 +345,7 @@ inline size_t at_size(int precision) { return precision == 0 ? 4 : 2; }
 //   128 N = 768 GEMMs (K >= 256)  256 wide GEMMs (N >= 2304)
 //   1024: the mask applies to launches enqueued by the backward pass only (the forward pass, hence the kept-token counts, stays intact)
 extern int g_dbg_in_backward;
-#ifdef DYT_DEBUG_HOOKS   // measurement builds only (make CXXFLAGS+=-DDYT_DEBUG_HOOKS): a product build cannot be talked into dropping launches by an environment variable
+#ifdef DYT_DEBUG_HOOKS   // measurement builds only (make CXXFLAGS_EXTRA=-DDYT_DEBUG_HOOKS; a command-line CXXFLAGS= would replace the Makefile's own flags): a product build cannot be talked into dropping launches by an environment variable
 inline bool dbg_skip(int bit) {
     static int mask = -1;
     if (mask < 0) { const char* e = getenv("DYT_DBG_SKIP"); mask = e ? atoi(e) : 0; }

@@ -433,7 +433,8 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
         for (size_t l = 0; l < depth; ++l) {
             LayerS& L = S.L[l];
             L.q16 = carve<uint16_t>(c, M * D, dry); L.k16 = carve<uint16_t>(c, M * D, dry); L.v16 = carve<uint16_t>(c, M * D, dry);
-            L.o16 = nullptr; L.ao3 = carve<uint16_t>(c, M * SA * D, dry); L.u16 = carve<uint16_t>(c, M * D, dry); L.h16 = carve<uint16_t>(c, M * D, dry);
+            L.o16 = nullptr; L.ao3 = carve<uint16_t>(c, Mp * SA * D, dry);   // padded to whole 256-row tiles like the other fp8-form operand images (the 256x256 kernel reads its last tile unclamped)
+             L.u16 = carve<uint16_t>(c, M * D, dry); L.h16 = carve<uint16_t>(c, M * D, dry);
             L.z16 = carve<uint16_t>(c, M * DM, dry); L.dact16 = carve<uint16_t>(c, M * RP, dry);
         }
         if (!dry) S.u0_16_own = S.L[0].u16;
@@ -443,18 +444,26 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
 static int alloc_aux(dyt_ctx* c, bool with_bwd16) {
     if (c->aux_arena && (c->aux_bwd16 || !with_bwd16)) return 0;
     DYT_HIP_CHECK(hipDeviceSynchronize());
-    if (c->aux_arena) { DYT_HIP_CHECK(hipFree(c->aux_arena)); c->aux_arena = nullptr; }
     char* main_base = c->arena; const size_t main_used = c->arena_used;
-    layout_aux(c, true, with_bwd16);
-    c->aux_size = c->arena_used;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->aux_arena), c->aux_size);
-    if (e == hipSuccess) e = hipMemset(c->aux_arena, 0, c->aux_size);
+    char* old_arena = c->aux_arena; const size_t old_size = c->aux_size; const bool old_bwd16 = c->aux_bwd16;
+    layout_aux(c, true, with_bwd16);   // dry run: the new size (this nulls every aux pointer; they are re-carved below on either path)
+    const size_t new_size = c->arena_used;
+    char* fresh = nullptr;
+    // the NEW arena first: if it cannot be had, the context keeps the old one (freeing first left every W.*_w3 / T.*3 /
+    // L.*16 pointer null while split16 stayed set from the earlier option value)
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), new_size);
+    if (e == hipSuccess) e = hipMemset(fresh, 0, new_size);
     if (e != hipSuccess) {
-        set_error("aux arena: hipMalloc / hipMemset(%zu bytes) failed: %s", c->aux_size, hipGetErrorString(e));
-        if (c->aux_arena) { (void)hipFree(c->aux_arena); c->aux_arena = nullptr; }
+        set_error("aux arena: hipMalloc / hipMemset(%zu bytes) failed: %s", new_size, hipGetErrorString(e));
+        if (fresh) (void)hipFree(fresh);
+        if (old_arena) { c->arena = old_arena; layout_aux(c, false, old_bwd16); }   // the old arena's layout, contents untouched
         c->arena = main_base; c->arena_used = main_used;
+        c->aux_size = old_size;
         return DYT_ERR_HIP;
     }
+    if (old_arena) (void)hipFree(old_arena);
+    c->aux_arena = fresh;
+    c->aux_size = new_size;
     c->arena = c->aux_arena;
     layout_aux(c, false, with_bwd16);
     c->arena = main_base; c->arena_used = main_used;

@@ -61,6 +61,15 @@ class FusedAdamW:
         self.guard = True
         self.opt_state = None
         self._skips_seen = 0
+        # GradScaler.update (misc.py:256-272; torch defaults): halve the scale when an update was skipped, double it after
+        # `growth_interval` consecutive clean updates.  The scale here is the power of two the library carries on its 16-bit gradient
+        # operands (DYT_OPT_GRAD_SCALE_LOG2, initially 2^12); it never shows in a returned gradient, so growth only trades underflow of the
+        # smallest gradient operands against overflow of the largest: capped at 2^GROW_MAX_LOG2.
+        self.growth_interval = 2000
+        self.GROW_MAX_LOG2 = 16
+        self._clean_run = 0            # applied updates since the last skip / the last growth
+        self._applied_seen = 0
+        self._scale_log2 = None        # last scale this optimizer set or loaded (persisted: a resumed run / a re-created engine starts from it)
 
     def zero_grad(self, set_to_none=True):
         pass  # dyt_step_fwd_bwd zeroes the flat gradient buffer itself
@@ -75,6 +84,9 @@ class FusedAdamW:
             self.exp_avg, self.exp_avg_sq = self.exp_avg.to(eng.device), self.exp_avg_sq.to(eng.device)
         if self.opt_state is None or self.opt_state.device != eng.device:
             self.opt_state = torch.tensor([self.step_count, 0, 0, 0], device=eng.device, dtype=torch.int32)
+            self._skips_seen, self._applied_seen = 0, self.step_count   # the device counters start over with the new state word
+            if self._scale_log2 is not None and getattr(eng, "grad_scale_log2", None) is not None and eng.grad_scale_log2 != int(self._scale_log2):
+                eng.set_grad_scale_log2(int(self._scale_log2))       # a re-created engine (eval, resume) continues at the scale reached
         if self._pending is not None:
             for name, st in self._pending.items():
                 off, num = eng.trainable_slice(name)
@@ -117,15 +129,47 @@ class FusedAdamW:
         return int(a), int(k)
 
     def overflow_backoff(self, eng):
-        """GradScaler.update's back-off (misc.py:272), at the loop's own sync points: if updates were skipped since the last call the
-        library's fixed gradient scale (2^12 on the 16-bit gradient operands) is halved; returns the number of new skips."""
+        """GradScaler.update (misc.py:256-272) at the loop's own sync points, from the device-side counters of dyt_adamw_guarded: updates
+        skipped since the last call halve the library's gradient scale (once per call, like one GradScaler.update per skipped step would
+        at most do between two of our sync points); `growth_interval` consecutive applied updates double it (up to 2^GROW_MAX_LOG2).
+        Returns the number of new skips.  Works with hipGraph replay too: set_grad_scale_log2 drops the captured graphs, the next step
+        re-captures."""
         applied, skipped = self.applied_and_skipped()
         self.step_count = applied
         new = skipped - self._skips_seen
-        self._skips_seen = skipped
-        if new > 0 and getattr(eng, "grad_scale_log2", None) is not None and eng.grad_scale_log2 > 0:
-            eng.set_grad_scale_log2(eng.grad_scale_log2 - 1)
+        new_applied = applied - self._applied_seen
+        self._skips_seen, self._applied_seen = skipped, applied
+        k = getattr(eng, "grad_scale_log2", None)
+        if k is None:
+            return new
+        if new > 0:
+            self._clean_run = 0
+            if k > 0:
+                eng.set_grad_scale_log2(k - 1)
+        else:
+            self._clean_run += max(0, new_applied)
+            if self._clean_run >= self.growth_interval and k < self.GROW_MAX_LOG2:
+                eng.set_grad_scale_log2(k + 1)
+                self._clean_run = 0
+        self._scale_log2 = eng.grad_scale_log2
         return new
+
+    def scaler_state(self):
+        """What GradScaler.state_dict() holds, in our terms (goes into the checkpoint's 'scaler' entry and the optimizer's own dict)."""
+        eng = self.model._engine
+        k = getattr(eng, "grad_scale_log2", None) if eng is not None else None
+        return dict(scale_log2=self._scale_log2 if k is None else k, growth_tracker=int(self._clean_run), skipped=int(self._skips_seen),
+                    growth_interval=int(self.growth_interval))
+
+    def load_scaler_state(self, st):
+        if not st:
+            return
+        self._clean_run = int(st.get("growth_tracker", 0))
+        self.growth_interval = int(st.get("growth_interval", self.growth_interval))
+        self._scale_log2 = st.get("scale_log2", None)
+        eng = self.model._engine
+        if eng is not None and self._scale_log2 is not None and getattr(eng, "grad_scale_log2", None) is not None:
+            eng.set_grad_scale_log2(int(self._scale_log2))
 
     def state_dict(self):
         names = _trainable_names(self.model)
@@ -143,7 +187,7 @@ class FusedAdamW:
                 else:
                     ea, es = self._pending[name]["exp_avg"], self._pending[name]["exp_avg_sq"]
                 state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=ea, exp_avg_sq=es)
-        return dict(state=state, param_groups=[dict(self.param_groups[0])])
+        return dict(state=state, param_groups=[dict(self.param_groups[0])], dyt_scaler=self.scaler_state())   # torch.optim ignores the extra key
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW.state_dict() of the reference (or our own): tensors may live on any device
@@ -167,7 +211,8 @@ class FusedAdamW:
             pending[name] = dict(exp_avg=st["exp_avg"].detach(), exp_avg_sq=st["exp_avg_sq"].detach())
             step = max(step, int(float(st["step"])))
         self.step_count = step
-        self.opt_state = None   # re-created with the loaded step count
+        self.opt_state = None   # re-created with the loaded step count (which also resets the skip / applied bookkeeping)
+        self.load_scaler_state(sd.get("dyt_scaler"))
         self._pending = pending if pending else None
         if self._pending is not None and self.model._engine is not None:
             self._state(self.model._engine)
@@ -188,14 +233,40 @@ def allreduce_grads(engine, group=None, overlap=True):
         # process).  If that communicator cannot be made (no librccl, several ranks on one GPU) the torch.distributed path below runs.
         global _native_rccl_failed
         if not _native_rccl_failed:
-            try:
-                engine.allreduce_native(overlap=overlap)
+            if getattr(engine, "_rccl_comm", None) is None:
+                # Creating the communicator can fail on SOME ranks only (no librccl on one host, two ranks on one GPU); a rank that fell back
+                # to torch.distributed on its own would then wait in a collective the others never issue.  The ranks agree twice, by a MIN
+                # over the torch group: that librccl loads everywhere (before the unique-id broadcast of rccl_comm_create, which a rank
+                # without the library would never join), and that ncclCommInitRank succeeded everywhere.
+                import _lib
+
+                def everywhere(ok):
+                    flag = torch.tensor([1 if ok else 0], device=engine.grad.device, dtype=torch.int32)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    return int(flag.item()) == 1
+                why = ""
+                try:
+                    _lib.rccl()
+                    loaded = True
+                except Exception as e:   # OSError from ctypes, DyTError
+                    loaded, why = False, str(e)
+                if not everywhere(loaded):
+                    _native_rccl_failed = True
+                else:
+                    try:
+                        engine._rccl_comm = _lib.rccl_comm_shared(engine.device)
+                        made = True
+                    except DyTError as e:
+                        made, why = False, str(e)
+                    if not everywhere(made):
+                        _native_rccl_failed = True
+                        engine._rccl_comm = None
+                        _lib.rccl_comm_destroy_all()
+                if _native_rccl_failed:
+                    print("[dyt] native RCCL all-reduce off on every rank%s: using torch.distributed.all_reduce" % ((" (rank %d: %s)" % (dist.get_rank(), why)) if why else ""))
+            if not _native_rccl_failed:
+                engine.allreduce_native(overlap=overlap)   # the communicator exists on every rank: a failing collective is an error
                 return 1.0 / dist.get_world_size()
-            except DyTError as e:
-                if getattr(engine, "_rccl_comm", None) is not None:
-                    raise                                  # the communicator exists: a failing collective is an error, not a missing feature
-                _native_rccl_failed = True
-                print("[dyt] native RCCL all-reduce unavailable (%s): using torch.distributed.all_reduce" % e)
     if overlap and engine.grad.is_cuda:
         off, num = engine.grad_part(0)
         comm, cur = engine.comm_stream(), torch.cuda.current_stream(engine.device)
@@ -300,10 +371,11 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         pending += 1
         if (it + 1) % print_freq == 0 or it + 1 == nsteps:
             host = acc.tolist()  # the only host<->device sync of the loop
-            new_skips = optimizer.overflow_backoff(m._engine) if optimizer.guard and not use_graph else 0
-            if new_skips and logger is not None:
-                logger.info("%d update(s) skipped: non-finite gradient (16-bit overflow); gradient scale now 2^%s" % (
-                    new_skips, getattr(m._engine, "grad_scale_log2", "?")))
+            before = getattr(m._engine, "grad_scale_log2", None)
+            new_skips = optimizer.overflow_backoff(m._engine) if optimizer.guard else 0   # graph replay too: the scale change drops the captured graphs
+            if logger is not None and (new_skips or getattr(m._engine, "grad_scale_log2", None) != before):
+                logger.info("%d update(s) skipped (non-finite gradient: 16-bit overflow); gradient scale 2^%s -> 2^%s" % (
+                    new_skips, before, getattr(m._engine, "grad_scale_log2", "?")))
             acc.zero_()
             for i, k in enumerate(LOSS_KEYS):
                 sums[k] += host[i]

@@ -38,7 +38,8 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler=Non
             'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
             'optimizer': _to_cpu(optimizer.state_dict()) if optimizer is not None else None,
             'epoch': epoch,
-            'scaler': loss_scaler.state_dict() if loss_scaler is not None else {},
+            # the reference's GradScaler state; here the gradient scale lives in the optimizer (FusedAdamW.scaler_state: scale, growth tracker, skips)
+            'scaler': loss_scaler.state_dict() if loss_scaler is not None else (optimizer.scaler_state() if hasattr(optimizer, 'scaler_state') else {}),
             'args': args,
         }
         save_on_master(to_save, output_dir / ('checkpoint-%s.pth' % epoch))
@@ -65,3 +66,6 @@ def load_model(args, model_without_ddp, optimizer, loss_scaler=None):
         args.start_epoch = checkpoint['epoch'] + 1
         if loss_scaler is not None and 'scaler' in checkpoint:
             loss_scaler.load_state_dict(checkpoint['scaler'])
+        elif optimizer is not None and hasattr(optimizer, 'load_scaler_state') and isinstance(checkpoint.get('scaler'), dict) \
+                and 'scale_log2' in checkpoint['scaler']:
+            optimizer.load_scaler_state(checkpoint['scaler'])

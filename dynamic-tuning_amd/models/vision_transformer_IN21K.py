@@ -121,6 +121,9 @@ class Block(nn.Module):
         if not x.is_cuda:
             raise DyTError("Block runs on the HIP device only")
         B = x.shape[0]
+        if self.count_flops and self.token_select_num is None:
+            # the reference asserts here too (forward_count_flops, :175): refuse instead of silently running the gated path
+            raise AssertionError("Block.count_flops is set without token_select_num (block_flops_dict.get_block_flops sets both)")
         eng = self._block_engine(B, x.device)
         eng.set_option(OPT_COUNT_FLOPS_TOKENS, int(self.token_select_num) if (self.count_flops and self.token_select_num) else 0)
         g1 = g2 = None

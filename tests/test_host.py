@@ -231,3 +231,45 @@ def test_step_seed_is_unique_across_epochs():
     from engine_finetune import step_seed
     seen = {step_seed(e, it, base=1234) for e in range(40) for it in range(9000)}
     assert len(seen) == 40 * 9000
+
+
+def test_gradient_scale_backoff_and_growth_follow_gradscaler_update():
+    """FusedAdamW.overflow_backoff = GradScaler.update (reference misc.py:256-272) on the device-side counters: a skipped update halves the
+    scale and resets the growth tracker, `growth_interval` consecutive applied updates double it (capped), the state survives
+    state_dict() / load_state_dict() and is applied to a re-created engine.  Host logic only (fake engine, no GPU)."""
+    import types
+    import engine_finetune as E
+
+    class Eng:
+        grad_scale_log2 = 12
+        def set_grad_scale_log2(self, k):
+            self.grad_scale_log2 = int(k)
+
+    opt = E.FusedAdamW.__new__(E.FusedAdamW)
+    opt.model = types.SimpleNamespace(_engine=Eng())
+    opt.growth_interval, opt.GROW_MAX_LOG2 = 5, 14
+    opt._clean_run = opt._applied_seen = opt._skips_seen = 0
+    opt._scale_log2, opt.step_count = None, 0
+    counters = [0, 0]
+    opt.applied_and_skipped = lambda: tuple(counters)
+    eng = opt.model._engine
+    counters[:] = [3, 0]
+    assert opt.overflow_backoff(eng) == 0 and eng.grad_scale_log2 == 12          # 3 clean updates: below the interval
+    counters[:] = [6, 0]
+    assert opt.overflow_backoff(eng) == 0 and eng.grad_scale_log2 == 13          # 6 clean: grown once, tracker reset
+    counters[:] = [7, 2]
+    assert opt.overflow_backoff(eng) == 2 and eng.grad_scale_log2 == 12          # skips since the last call: halved (once), tracker reset
+    counters[:] = [11, 2]
+    assert opt.overflow_backoff(eng) == 0 and eng.grad_scale_log2 == 12          # 4 clean after the skip
+    counters[:] = [12, 2]
+    assert opt.overflow_backoff(eng) == 0 and eng.grad_scale_log2 == 13
+    st = opt.scaler_state()
+    assert st["scale_log2"] == 13 and st["skipped"] == 2 and st["growth_tracker"] == 0
+    eng2 = Eng()
+    opt.model._engine = eng2
+    opt.load_scaler_state(st)
+    assert eng2.grad_scale_log2 == 13
+    for _ in range(4):                                                            # the cap
+        counters[0] += 5
+        opt.overflow_backoff(eng2)
+    assert eng2.grad_scale_log2 == 14
