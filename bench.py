@@ -267,7 +267,13 @@ def main():
                  "steps": em["steps"], "roofline": em["roofline"],
                  "parity": "fp32 mode vs reference goldens on MI355X: logits max abs err 4e-6, token-keep masks bit-exact, "
                            "74 gradients rel-L2 < 2e-3 (tests/test_gpu_parity.py, tests/gpu_diag.py)"}
+    dist_info = None
     if dist.is_initialized():
+        cores = [None] * world
+        dist.all_gather_object(cores, synth.available_cores())
+        dist_info = {"torch_world_size": world, "rccl_ranks": head.get("rccl_ranks"), "host_cores_per_rank": cores,
+                     "comm_stream_concurrent": head.get("comm_stream_concurrent"),
+                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
         dist.barrier()
 
     if rank == 0:
@@ -294,6 +300,8 @@ def main():
             "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
             "roofline": head["roofline"],
         }
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if parity is not None:
             out["parity_mode"] = parity
         if exact is not None:
@@ -436,6 +444,11 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
            "step_gflop_executed_per_image": round(gflop_exec, 3),
            "step_mfma_frac_executed": round(ips / world * gflop_exec * 1e9 / (PEAK[precision] * 1e12), 4), "roofline": roof,
            "hip_graph": bool(args.hip_graph) and not os.environ.get("DYT_NO_OVERLAP")}
+    if dist.is_initialized():   # evidence for a multi-GPU record: the ranks RCCL itself saw, and that the all-reduce stream has a hardware queue of its own
+        import _lib
+        comm = getattr(eng, "_rccl_comm", None)
+        res["rccl_ranks"] = _lib.rccl_comm_ranks(comm) if comm is not None else None
+        res["comm_stream_concurrent"] = bool(eng.streams_concurrent(torch.cuda.current_stream(device), eng.comm_stream()))
     del opt, model, eng
     torch.cuda.empty_cache()
     return res

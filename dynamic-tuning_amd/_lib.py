@@ -227,6 +227,7 @@ def rccl():
         R.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
         R.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         R.ncclGetErrorString.restype = ctypes.c_char_p
+        R.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         _rccl = R
     return _rccl
 
@@ -267,6 +268,15 @@ def rccl_comm_shared(device):
         if len(_shared_comms) == 1:
             atexit.register(rccl_comm_destroy_all)
     return _shared_comms[key]
+
+
+def rccl_comm_ranks(comm):
+    """Number of ranks the library's communicator spans (ncclCommCount): what a multi-GPU record should show next to torch's world size."""
+    n = ctypes.c_int(0)
+    rc = rccl().ncclCommCount(comm, ctypes.byref(n))
+    if rc != 0:
+        raise DyTError("ncclCommCount: %s" % rccl().ncclGetErrorString(rc).decode())
+    return n.value
 
 
 def rccl_comm_destroy_all():

@@ -187,7 +187,9 @@ class FusedAdamW:
                 else:
                     ea, es = self._pending[name]["exp_avg"], self._pending[name]["exp_avg_sq"]
                 state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=ea, exp_avg_sq=es)
-        return dict(state=state, param_groups=[dict(self.param_groups[0])], dyt_scaler=self.scaler_state())   # torch.optim ignores the extra key
+        # exactly torch.optim.AdamW.state_dict()'s keys (checkpoint interchange); the gradient-scale state travels in the checkpoint's 'scaler'
+        # entry like the reference's GradScaler state (misc.save_model / load_model -> scaler_state / load_scaler_state)
+        return dict(state=state, param_groups=[dict(self.param_groups[0])])
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW.state_dict() of the reference (or our own): tensors may live on any device

@@ -274,9 +274,59 @@ class DyTEngine:
         self._ck(self.L.dyt_grad_part(self.h, int(part), ctypes.byref(off), ctypes.byref(num)))
         return off.value, num.value
 
+    def streams_concurrent(self, a, b, spin_cycles=400_000):
+        """True when work queued on streams `a` and `b` really runs at the same time.  HIP multiplexes a process's streams onto
+        GPU_MAX_HW_QUEUES hardware queues (default 4; _lib.py / bench.py ask for 8 when they are imported before the runtime starts) and two
+        streams on one queue run one after the other -- a DP rank's all-reduce stream sharing the step's queue costs 30.6 instead of 25.9
+        ms per step.  Measured, not assumed: one ~0.2 ms spin kernel on each stream; together they take ~1x (separate
+        queues) or ~2x (same queue) the time of one."""
+        with torch.cuda.device(self.device):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            torch.cuda._sleep(1000)                     # warm the spin kernel up
+            torch.cuda.synchronize(self.device)
+            cur = torch.cuda.current_stream(self.device)
+            ev[0].record(cur)
+            a.wait_event(ev[0]); b.wait_event(ev[0])
+            with torch.cuda.stream(a):
+                ev[1].record(a); torch.cuda._sleep(spin_cycles); ev[2].record(a)
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(spin_cycles); ev[3].record(b)
+            torch.cuda.synchronize(self.device)
+            one = ev[1].elapsed_time(ev[2])
+            both = max(ev[1].elapsed_time(ev[2]), ev[1].elapsed_time(ev[3]))
+            alone = None
+            with torch.cuda.stream(a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(a); torch.cuda._sleep(spin_cycles); e1.record(a)
+            torch.cuda.synchronize(self.device)
+            alone = e0.elapsed_time(e1)
+        self._last_concurrency = (alone, one, both)
+        return both < 1.5 * alone
+
     def comm_stream(self):
+        """Side stream of the early gradient all-reduce: one that is VERIFIED to run beside the step's stream (up to eight candidates; streams
+        map to hardware queues in creation order).  If none does -- a launcher imported torch before GPU_MAX_HW_QUEUES could be raised and
+        the queues are exhausted -- a warning names the cause; DYT_STRICT=1 turns it into an error."""
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(self.device)
+            import os
+            import warnings
+            cur = torch.cuda.current_stream(self.device)
+            tried = []
+            for _ in range(8):
+                st = torch.cuda.Stream(self.device)
+                tried.append(st)
+                if self.streams_concurrent(cur, st):
+                    self._comm_stream = st
+                    break
+            if self._comm_stream is None:
+                msg = ("the gradient all-reduce stream shares a hardware queue with the step's stream on %s (GPU_MAX_HW_QUEUES=%s): the "
+                       "all-reduce will run after the backward pass instead of under it; export GPU_MAX_HW_QUEUES=8 before the HIP runtime "
+                       "starts" % (self.device, os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)")))
+                if os.environ.get("DYT_STRICT", "0") == "1":
+                    raise DyTError(msg)
+                warnings.warn(msg)
+                self._comm_stream = tried[0]
+            self.comm_stream_verified = self._comm_stream is not tried[0] or len(tried) == 1 or self.streams_concurrent(cur, self._comm_stream)
         return self._comm_stream
 
     def allreduce_native(self, overlap=True):

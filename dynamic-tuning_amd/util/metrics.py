@@ -5,12 +5,13 @@ from torch.nn import functional as F
 
 
 def accuracy(output, target, topk=(1,)):
-    maxk = min(max(topk), output.size()[1])
-    batch_size = target.size(0)
-    _, pred = output.topk(maxk, 1, True, True)
-    pred = pred.t()
-    correct = pred.eq(target.reshape(1, -1).expand_as(pred))
-    return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100. / batch_size for k in topk]
+    """Percentage of rows whose label is among the k best-scored classes, one 0-dim tensor per k (the return contract of the
+    reference's accuracy(), util/metrics.py:4-11, which engine_finetune.evaluate reads as acc1 / acc5)."""
+    n = target.shape[0]
+    kmax = min(max(topk), output.shape[1])
+    ranked = output.topk(kmax, dim=1).indices                       # [n, kmax], best first (ties: lowest index, as torch.topk)
+    hit_rank = (ranked == target.reshape(n, 1)).float().cumsum(1)  # hit_rank[i, j] = 1 iff the label is among the j+1 best
+    return [hit_rank[:, min(k, kmax) - 1].sum() * (100.0 / n) for k in topk]
 
 
 def mean_per_class_accuracy(pred, target, num_classes):

@@ -211,9 +211,9 @@ def test_upper_gradient_allreduce_really_overlaps_the_backward():
         x, y = synth.make_batch(B, 100, seed=95)
         x, y = x.cuda(), y.cuda()
         eng = m.engine(B, torch.device("cuda", 0))
-        # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues in creation order, and two streams on one queue run
-        # one after the other: late in a long pytest process the comm stream can land on the step's queue.  Up to
-        # eight fresh comm streams are tried; one whose all-reduce completes well before the backward does is what is asserted.
+        # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues in creation order, and two streams on one queue run one
+        # after the other.  Engine.comm_stream() now picks a stream it has MEASURED to run beside the step's stream
+        # (round 4 retried here, in the test; production never retried).
         def run(iters):
             gaps = []
             for it in range(iters):
@@ -226,16 +226,14 @@ def test_upper_gradient_allreduce_really_overlaps_the_backward():
                 torch.cuda.synchronize()
                 gaps.append((t0.elapsed_time(comm_end), t0.elapsed_time(bwd_end)))
             return gaps
+        cs = eng.comm_stream()
+        assert eng.streams_concurrent(torch.cuda.current_stream(), cs), eng._last_concurrency
+        assert not eng.streams_concurrent(cs, cs)                  # the detector does see serialisation (one stream against itself)
         run(1)                                                     # creates the communicator
-        seen = []
-        for attempt in range(8):
-            gaps = run(3)
-            seen.append(["%.2f / %.2f" % g for g in gaps])
-            if all(c < b - 0.5 and c > 0.3 * b for c, b in gaps[1:]):
-                break
-            eng._comm_stream = torch.cuda.Stream(eng.device)       # next hardware queue
-        print("part-0 all-reduce done / backward done, ms after the step's start (attempt %d):" % attempt, seen[-1])
-        assert all(c < b - 0.5 and c > 0.3 * b for c, b in gaps[1:]), seen
+        gaps = run(3)
+        print("part-0 all-reduce done / backward done, ms after the step's start:", ["%.2f / %.2f" % g for g in gaps],
+              "stream probe (alone, one of two, both) ms:", ["%.3f" % t for t in eng._last_concurrency])
+        assert all(c < b - 0.5 and c > 0.3 * b for c, b in gaps[1:]), gaps
     finally:
         dist.destroy_process_group()
 
