@@ -503,9 +503,12 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     const int Mv = m_dev ? min(*m_dev, M) : M;
     // XCD-aware block remap (bijective): consecutive logical tiles share an A row panel and
     // should land on the same XCD's L2; hardware places block b on XCD b % 8.
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     const int tiles_n = N / BN;
+    // ... over the tiles that exist (device-side row count: see gemm_bpre.h), so that a compacted launch spreads over all eight XCDs
+    const int nwg_v = min(nwg, ((max(Mv - m_begin, 0) + BM - 1) / BM) * tiles_n);
+    if (bid >= nwg_v) return;
+    const int q8 = nwg_v >> 3, r8 = nwg_v & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
     const int m0 = m_begin + tm * BM, n0 = tn * BN;
     if (m0 >= Mv) return;

@@ -47,10 +47,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_bpre_kernel(const bf16* __re
     constexpr int A_INSTR = BM / 8 / NW;         // 4 LDS-DMA pieces (8 rows x 128 B) per wave and stage
 
     const int Mv = m_dev ? min(*m_dev, M) : M;
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int tiles_n = N / BN;
+    // XCD-aware remap over the tiles that EXIST: with a device-side row count (compacted student pass: 17 690 of 25 216 rows) the grid is
+    // sized for M, and a remap over gridDim hands the XCDs contiguous tile ranges of which the last ones are entirely past Mv -- two of the
+    // eight XCDs then idle while the others run as many rounds as the dense launch (round 4: student fc1 154 us vs dense 168).  Blocks
+    // are dispatched round-robin over the XCDs, so the first `nwg` block ids cover all eight evenly.
+    const int nwg = min((int)gridDim.x, ((max(Mv - m_begin, 0) + BM - 1) / BM) * tiles_n), bid = blockIdx.x;
+    if (bid >= nwg) return;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int tiles_n = N / BN;
     const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
     const int m0 = m_begin + tm * BM, n0 = tn * BN;
     if (m0 >= Mv) return;
