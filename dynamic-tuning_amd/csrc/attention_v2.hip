@@ -356,7 +356,7 @@ __device__ __forceinline__ void store_rows16(bf16* op /* row base + hi * 8 */, c
 }
 
 __device__ unsigned long long g_bwd_dbg[8 + 16];   // ABL & 8 (probe builds): cycles of wave 0 in barrier (a) / phase B / barrier (c) / phase A / dq stores, heads
-template <int ABL = 0, int SETPRIO = 0, int EXPM = 0>
+template <int ABL = 0, int SETPRIO = 0, int EXPM = 0, int LT = 1>
 __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                              const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -383,17 +383,33 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restr
         bf16x8 orow[PIECES];
         float lrow[4];
         const int r8 = lane >> 3, c = lane & 7;
+        // LT = 1 (default): asm loads + a COUNTED wait, so that the statistics run under the flight of the K / V pieces issued after them (hipcc
+        // would count only its own 29 loads among the ~130 operations in flight and wait for nearly all of them before the first use): 101.5 vs
+        // 107.4 us, bit-identical to LT = 0 (full drain, statistics before barrier (c)) over repeated launches at B = 128
+        // (tools/probes/r5/av2_test.hip).  The workgroup owns its CU (159.5 KB of LDS), so no other stream's waves share it -- the condition
+        // under which DESIGN.md 7b saw a partial wait consumed early.
         auto load_rows = [&](int bh) {
             const int b = bh / NH, h = bh - b * NH;
 #pragma unroll
-            for (int it = 0; it < PIECES; ++it)
-                orow[it] = *reinterpret_cast<const bf16x8*>(o + ((size_t)b * NT + min(it * 8 + r8, NT - 1)) * o_ld + h * HD + c * 8);
+            for (int it = 0; it < PIECES; ++it) {
+                const bf16* gp = o + ((size_t)b * NT + min(it * 8 + r8, NT - 1)) * o_ld + h * HD + c * 8;
+                if (LT) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(orow[it]) : "v"(gp) : "memory");
+                else orow[it] = *reinterpret_cast<const bf16x8*>(gp);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lrow[j] = lse[(size_t)bh * NT + min(lane + 64 * j, NT - 1)];
+            for (int j = 0; j < 4; ++j) {
+                const float* gp = lse + (size_t)bh * NT + min(lane + 64 * j, NT - 1);
+                if (LT) asm volatile("global_load_dword %0, %1, off" : "=v"(lrow[j]) : "v"(gp) : "memory");
+                else lrow[j] = *gp;
+            }
         };
-        // Full drains only.  (A counted wait that leaves the younger DMA pieces in flight -- statistics under the flight of K / V -- was
-        // 10 % faster and gave run-to-run different results: loads of different kinds do not retire in issue order)
-#define DYT_ROWS_LANDED(N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DYT_ROWS_LANDED(N)                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                                  \
+                 : "+v"(orow[0]), "+v"(orow[1]), "+v"(orow[2]), "+v"(orow[3]), "+v"(orow[4]), "+v"(orow[5]), "+v"(orow[6]), "+v"(orow[7]),   \
+                   "+v"(orow[8]), "+v"(orow[9]), "+v"(orow[10]), "+v"(orow[11]), "+v"(orow[12]), "+v"(orow[13]), "+v"(orow[14]),           \
+                   "+v"(orow[15]), "+v"(orow[16]), "+v"(orow[17]), "+v"(orow[18]), "+v"(orow[19]), "+v"(orow[20]), "+v"(orow[21]),         \
+                   "+v"(orow[22]), "+v"(orow[23]), "+v"(orow[24]), "+v"(lrow[0]), "+v"(lrow[1]), "+v"(lrow[2]), "+v"(lrow[3])             \
+                 :: "memory")
         auto issue_qdo = [&](int bh, int slq, int sld) {
             const int b = bh / NH, h = bh - b * NH;
             dma_image<1>(q + (size_t)bh * NT * HD, HD, lds0 + slq * BIMG, 0, lane);
@@ -437,13 +453,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restr
             if (more) {
                 if (!(ABL & 32)) load_rows(nb);
                 issue_qdo(nb, sE, sF);
-                if (!(ABL & 64)) DYT_ROWS_LANDED(0);   // full drain (a counted wait that leaves younger pieces in flight gave run-to-run different statistics:
-                                      // loads of different kinds do not retire in issue order -- cf. DESIGN.md 7b)
-                if (!(ABL & 16)) make_stats(ab ^ 1, sF);
+                if (!LT) {
+                    if (!(ABL & 64)) DYT_ROWS_LANDED(0);
+                    if (!(ABL & 16)) make_stats(ab ^ 1, sF);
+                }
             }
             barrier_lds();   // (c) phase B of head bh is over: the slots of its Q / dO images are free and take K / V of the next head
             if (more) {
-                issue_kv(nb, sQ, sD);
+                issue_kv(nb, sQ, sD);   // 50 pieces
+                if (LT) {
+                    DYT_ROWS_LANDED(50);      // everything older than those 50: o rows, lse, dO and Q images (issued a phase ago)
+                    make_stats(ab ^ 1, sF);   // ... under the flight of K / V
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             rotate();

@@ -162,6 +162,21 @@ int main(int argc, char** argv) {
             stamps("  no LDS reads", av2::attn_bwd_v2_kernel<13, 0, 6>);
             stamps("  no LDS, no exp", av2::attn_bwd_v2_kernel<13, 0, 7>);
             runb("full", av2::attn_bwd_v2_kernel<0>);
+            runb("full LT", av2::attn_bwd_v2_kernel<0, 0, 0, 1>);
+            {   // determinism of the LT form + equality with the default form
+                std::vector<unsigned short> g0(n * 3), g1(n * 3);
+                auto kd = av2::attn_bwd_v2_kernel<0>; auto kl = av2::attn_bwd_v2_kernel<0, 0, 0, 1>;
+                hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)av2::BWD_LDS);
+                hipLaunchKernelGGL(kd, dim3(std::min(nhb, 256)), dim3(512), av2::BWD_LDS, 0, bq, bk, bv, bo, bdo, bl, bg, nhb, 7, D);
+                hipDeviceSynchronize(); hipMemcpy(g0.data(), bg, n * 6, hipMemcpyDeviceToHost);
+                for (int rep = 0; rep < 6; ++rep) {
+                    hipMemset(bg, 0xff, n * 6);
+                    hipLaunchKernelGGL(kl, dim3(std::min(nhb, 256)), dim3(512), av2::BWD_LDS, 0, bq, bk, bv, bo, bdo, bl, bg, nhb, 7, D);
+                    hipDeviceSynchronize(); hipMemcpy(g1.data(), bg, n * 6, hipMemcpyDeviceToHost);
+                    size_t nd = 0; for (size_t i = 0; i < g0.size(); ++i) nd += g0[i] != g1[i];
+                    printf("bwd LT rep %d vs default form: %zu elements differ\n", rep, nd);
+                }
+            }
             runb("full prio alt", av2::attn_bwd_v2_kernel<0, 2>);
             runb("full prio mfma", av2::attn_bwd_v2_kernel<0, 3>);
             runb("no DMA, no stores, prio alt", av2::attn_bwd_v2_kernel<5, 2>);
