@@ -48,7 +48,7 @@ PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3,   # TFLOP/s dense MFMA, M
         "fp16x3h": 2500.0 / 2,
         "fp16x3q": 2500.0 / 1.75,  # qkv / proj (both passes) and the teacher pass's MLP in the fp8-correction form (two f16-equivalents), the student's MLP three-part
         "fp16f8": 2500.0 / 1.5}  # forward: one f16 product + two fp8 products at twice the rate = two f16-equivalents; backward one  # the same product counts; the backward runs on 16-bit operands with the fp16 mode's kernels
-TRAFFIC_JSON = os.path.join("round4", "gemm_traffic.json")
+TRAFFIC_JSON = os.path.join("round5", "gemm_traffic.json")
 
 
 class Cfg(dict):
@@ -248,10 +248,13 @@ def main():
         parity["fp8_corrections"] = {
             "dtype": "fp16f8", "value": qm["value"], "unit": "images/s", "ms_per_step": qm["ms_per_step"], "steps": qm["steps"],
             "roofline": qm["roofline"],
-            "parity": "vs the CPU oracle at B=16 over five seeds: logits max abs err <= 6.2e-5 (bar 1e-3; one draw with a flipped decision 5.9e-4), "
-                      "token-keep decisions equal outside a margin of 1e-5 in (logit + g) / tau: 2 of 5 x 37 632 differ, at margins 3.6e-7 and "
-                      "1.8e-6 (gate logits are ~5e-5 from the reference here, ~5e-6 in fp16x3h: near-ties flip ten times as often, and a "
-                      "flipped token moves the student logits by up to 1.7e-3); 74 gradients rel-L2 <= 1.9e-3 on the draws without a flip; per GEMM 1.5-2.5e-5 of max|C| vs fp64 (three-part: 1-2e-6, plain half: 4e-4)"}
+            "parity": "vs the CPU oracle at B=16 over five seeds: logits max abs err <= 6.2e-5 (bar 1e-3; one draw with a flipped decision 5.9e-4).  "
+                      "Token-keep decisions under the ONE tie rule of tests/parity_rules.py (a decision may differ only inside the reference's own "
+                      "fp32 tie band, 4 x its measured gate-logit round-off vs float64: 0.5 - 1.9e-6 in (logit + g) / tau): the first differing decision "
+                      "of two of the five draws lies inside the band (margins 3.6e-7 / <1.4e-6), and ONE of 301 056 decisions at B=128 lies just outside "
+                      "(margin 9.8e-7, band 9.5e-7).  With gate logits ~5e-5 from the reference (25x the band; fp16x3q: ~1e-5) fp16f8 keeps its masks by "
+                      "the draw, not by construction, and a flipped token moves the student logits by up to 1.7e-3: not the parity mode.  74 gradients "
+                      "rel-L2 <= 2.0e-3 on the draws without a flip; per GEMM 1.5-2.5e-5 of max|C| vs fp64 (three-part: 1-2e-6, plain half: 4e-4)"}
         torch.cuda.empty_cache()
         fm = measure(args, "fp16x3", args.mode, max(2, min(args.steps, 4)), 1, device, world, rank)
         parity["all_products_three_part"] = {
