@@ -11,7 +11,7 @@ def accuracy(output, target, topk=(1,)):
     kmax = min(max(topk), output.shape[1])
     ranked = output.topk(kmax, dim=1).indices                       # [n, kmax], best first (ties: lowest index, as torch.topk)
     hit_rank = (ranked == target.reshape(n, 1)).float().cumsum(1)  # hit_rank[i, j] = 1 iff the label is among the j+1 best
-    return [hit_rank[:, min(k, kmax) - 1].sum() * (100.0 / n) for k in topk]
+    return [hit_rank[:, min(k, kmax) - 1].sum() * 100.0 / n for k in topk]   # (x 100, then / n: the golden accuracy is compared to the last fp32 bit)
 
 
 def mean_per_class_accuracy(pred, target, num_classes):
