@@ -339,24 +339,11 @@ constexpr int BWD_LDS = BSTAT + 6 * BIMG;       // 163328
 
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// 16-byte stores of a transposed accumulator pair acc[dt][r] = X^T[channel dt*32 + 8g + 4hi + e][row = lane & 31] (r = 4g + e): see the forward kernel
-__device__ __forceinline__ void store_rows16(bf16* op /* row base + hi * 8 */, const f32x16 (&acc)[2], float scale, bool valid) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-            const bf16x4 a4 = {(bf16)(acc[dt][4 * g] * scale), (bf16)(acc[dt][4 * g + 1] * scale), (bf16)(acc[dt][4 * g + 2] * scale), (bf16)(acc[dt][4 * g + 3] * scale)};
-            const bf16x4 b4 = {(bf16)(acc[dt][4 * g + 4] * scale), (bf16)(acc[dt][4 * g + 5] * scale), (bf16)(acc[dt][4 * g + 6] * scale), (bf16)(acc[dt][4 * g + 7] * scale)};
-            const uint2 a = __builtin_bit_cast(uint2, a4), bb = __builtin_bit_cast(uint2, b4);
-            const auto rx = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
-            const auto ry = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
-            const unsigned rx0 = rx[0], rx1 = rx[1], ry0 = ry[0], ry1 = ry[1];
-            if (valid) *reinterpret_cast<uint4*>(op + dt * 32 + 8 * g) = make_uint4(rx0, ry0, rx1, ry1);
-        }
-}
-
 __device__ unsigned long long g_bwd_dbg[8 + 16];   // ABL & 8 (probe builds): cycles of wave 0 in barrier (a) / phase B / barrier (c) / phase A / dq stores, heads
-template <int ABL = 0, int SETPRIO = 0, int EXPM = 0, int LT = 1>
+// ABL / SETPRIO: measurement variants instantiated by tools/probes/r5/av2_test.hip only (ABL: 1 no stores, 2 no compute, 4 no DMA after the first
+// head, 8 per-wave cycle stamps, 16 / 32 / 64 loader ablations; SETPRIO 1 static priority for waves 4-6, 2 alternating per tile, 3 around the
+// S / dP MFMA block: all measured equal or worse than none).  The product launches <0, 0, 1>.
+template <int ABL = 0, int SETPRIO = 0, int LT = 1>
 __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                              const bf16* __restrict__ v, const bf16* __restrict__ o,
                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -520,8 +507,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restr
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    s = MFMA32((EXPM & 4) ? kf[ks] : row_frag(Qi, fa.row[ks] + qt * 4096), kf[ks], s);      // S[q][key]: q in registers, key = lane
-                    dp = MFMA32((EXPM & 4) ? vf[ks] : row_frag(dOi, fa.row[ks] + qt * 4096), vf[ks], dp);   // dP[q][key]
+                    s = MFMA32(row_frag(Qi, fa.row[ks] + qt * 4096), kf[ks], s);      // S[q][key]: q in registers, key = lane
+                    dp = MFMA32(row_frag(dOi, fa.row[ks] + qt * 4096), vf[ks], dp);   // dP[q][key]
                 }
                 if (SETPRIO == 3) __builtin_amdgcn_s_setprio(0);
                 // q = qt*32 + 8g + 4hi + e for register 4g + e; the padding queries have lse2 = +inf (P = 0) and delta = 0
@@ -534,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        const float pv = (EXPM & 1) ? fmaf(s[r], LOG2E, -Ls[e]) : __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -Ls[e]));
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -Ls[e]));
                         p[r] = pv;
                         s[r] = pv * (dp[r] - Ds[e]);   // dS
                     }
@@ -552,8 +539,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_v2_kernel(const bf16* __restr
                     const int off = qt * 4096 + half * 2048;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        aV[dt] = MFMA32((EXPM & 2) ? vf[dt] : tr_frag(dOi, fa.tr[dt][0] + off, fa.tr[dt][1] + off), pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
-                        aK[dt] = MFMA32((EXPM & 2) ? kf[dt] : tr_frag(Qi, fa.tr[dt][0] + off, fa.tr[dt][1] + off), dsf, aK[dt]);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                        aV[dt] = MFMA32(tr_frag(dOi, fa.tr[dt][0] + off, fa.tr[dt][1] + off), pf, aV[dt]);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                        aK[dt] = MFMA32(tr_frag(Qi, fa.tr[dt][0] + off, fa.tr[dt][1] + off), dsf, aK[dt]);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
                     }
                 }
             }

@@ -156,16 +156,11 @@ int main(int argc, char** argv) {
             stamps("no stats no rows", av2::attn_bwd_v2_kernel<8 + 16 + 32>);
             stamps("no stats no rows no drain", av2::attn_bwd_v2_kernel<8 + 16 + 32 + 64>);
             stamps("compute only", av2::attn_bwd_v2_kernel<13>);
-            stamps("  no exp", av2::attn_bwd_v2_kernel<13, 0, 1>);
-            stamps("  no tr reads", av2::attn_bwd_v2_kernel<13, 0, 2>);
-            stamps("  no row reads", av2::attn_bwd_v2_kernel<13, 0, 4>);
-            stamps("  no LDS reads", av2::attn_bwd_v2_kernel<13, 0, 6>);
-            stamps("  no LDS, no exp", av2::attn_bwd_v2_kernel<13, 0, 7>);
             runb("full", av2::attn_bwd_v2_kernel<0>);
-            runb("full LT", av2::attn_bwd_v2_kernel<0, 0, 0, 1>);
+            runb("full, full-drain loader", av2::attn_bwd_v2_kernel<0, 0, 0>);
             {   // determinism of the LT form + equality with the default form
                 std::vector<unsigned short> g0(n * 3), g1(n * 3);
-                auto kd = av2::attn_bwd_v2_kernel<0>; auto kl = av2::attn_bwd_v2_kernel<0, 0, 0, 1>;
+                auto kd = av2::attn_bwd_v2_kernel<0, 0, 0>; auto kl = av2::attn_bwd_v2_kernel<0, 0, 1>;
                 hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)av2::BWD_LDS);
                 hipLaunchKernelGGL(kd, dim3(std::min(nhb, 256)), dim3(512), av2::BWD_LDS, 0, bq, bk, bv, bo, bdo, bl, bg, nhb, 7, D);
                 hipDeviceSynchronize(); hipMemcpy(g0.data(), bg, n * 6, hipMemcpyDeviceToHost);
