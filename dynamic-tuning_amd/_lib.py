@@ -25,7 +25,7 @@ PREC_FP16F8 = 6   # host-side name only: PREC_FP16X3H with the forward GEMMs' co
 PREC_FP16X3Q = 7  # host-side name only: PREC_FP16X3H with the attention branch's GEMMs (qkv, proj) in the fp8-correction form, the MLP three-part (DYT_OPT_F32_SPLIT16 = 5)
 PREC_FP16X3 = 3   # host-side name only: libdyt_hip_f16.so in its fp32 mode with DYT_OPT_F32_SPLIT16 (frozen-weight GEMMs as three IEEE-half products)
 F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED, F_TOKENS_IN, F_TOKENS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
-OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2, OPT_FC2_CAT, OPT_ATTN_BWD_FUSED, OPT_F32_SPLIT16, OPT_ATTN_V2 = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2, OPT_FC2_CAT, OPT_ATTN_BWD_FUSED, OPT_F32_SPLIT16, OPT_ATTN_V2, OPT_GEMM_SPLITK = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 # enum dyt_param (include/dyt_hip.h)
 (P_CLS, P_POS, P_PE_W, P_PE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_PROJ_W, P_PROJ_B, P_LN2_W, P_LN2_B,

@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_rows_kernel(
 }  // namespace dyt
 #include "gemm_bpre.h"
 #include "gemm_f32_mfma.h"
+#include "gemm_skinny.h"
 namespace dyt {
 
 // ------------------------------------------------------------------------------------------
@@ -1100,6 +1101,12 @@ int launch_preshuffle_w(const void* W, void* Wp, int N, int K, hipStream_t s) {
     return 0;
 }
 
+static int g_splitk = -1;   // DYT_OPT_GEMM_SPLITK (process-wide; environment DYT_SPLITK sets the default)
+void set_gemm_splitk(int v) { g_splitk = v != 0; }
+int get_gemm_splitk() {
+    if (g_splitk < 0) { const char* e = getenv("DYT_SPLITK"); g_splitk = e ? (atoi(e) != 0) : 1; }
+    return g_splitk;
+}
 static int g_big_tile_min_n = 2304;
 static int g_use_bpre = 1;        // wide-N GEMMs with a pre-shuffled frozen weight: 128x256 tiles, 2 workgroups / CU (gemm_bpre.h)
 static int g_split_rows = 1;      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
@@ -1130,6 +1137,23 @@ static bool takes_bpre(const GemmArgs& a, bool k768 = false) {
 template <class Epi, bool CAT = false>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
+    if constexpr (SplitKEpi<Epi>::value) {
+        // the K = 3072 GEMMs of the cls-only last block: split-K over 256-wide slices + a reduce launch that runs the functor (gemm_skinny.h).
+        // B = 128, serial: fc2 forward 56 -> see DESIGN.md 7d; DYT_OPT_GEMM_SPLITK 0 keeps the 6-tile launches
+        const int splitk = get_gemm_splitk();
+        const int slices = a.K / SK_SLICE + (CAT ? 1 : 0);
+        if (splitk && a.splitk_ws && a.M <= SK_MAX_M && a.K >= 1024 && a.K % SK_SLICE == 0 && a.N % 64 == 0 && !a.m_dev && !a.a_fold && !a.a_ld && !a.f8 &&
+            (size_t)slices * a.M * a.N * sizeof(float) <= a.splitk_ws_bytes && (!CAT || (a.A2 && a.W2))) {
+            hipLaunchKernelGGL((gemm_splitk_kernel<CAT>), dim3(a.N / 32, (a.M + 127) / 128, slices), dim3(256), 0, s, static_cast<const bf16*>(a.A),
+                               static_cast<const bf16*>(a.W), a.M, a.N, a.K, a.a_map, static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2),
+                               a.a2_map, a.splitk_ws);
+            ++g_bf16_kernel_launches;
+            hipLaunchKernelGGL((splitk_reduce_kernel<Epi>), dim3((unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256)), dim3(256), 0, s, a.splitk_ws, slices, a.M,
+                               a.N, a.out_scale, epi);
+            DYT_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     if constexpr (CAT) {
         if (!a.A2 || !a.W2 || a.N % 128 != 0) { set_error("gemm_bf16: K-concatenated form needs A2, W2 and N %% 128 == 0 (N=%d)", a.N); return -1; }
     } else {

@@ -85,6 +85,8 @@ struct GemmArgs {
     uint64_t seed = 0, subseq = 0;
     const uint64_t* seed_dev = nullptr;   // when set, the Philox seed is read from this device word (graph replay)
     int accumulate = 0;
+    // skinny K >= 1024 GEMMs (the cls-only last block): workspace for the split-K form (gemm_skinny.h), [slices][M][N] fp32; null = tile kernels
+    float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;
     double flops() const { return 2.0 * M * (double)N * K; }
 };
 
@@ -125,6 +127,8 @@ int launch_attn_bwd(int precision, const void* q, const void* k, const void* v, 
 // 16-bit modes: 1 (default) = dQ and dK/dV of a head in one persistent kernel, 0 = the two separate kernels (process-wide)
 void set_attn_bwd_fused(int on);
 // round-5 kernels (attention_v2.hip; 16-bit modes): bit 0 = forward (online softmax, LDS-DMA images, two workgroups per CU), bit 1 = backward
+void set_gemm_splitk(int on);   // DYT_OPT_GEMM_SPLITK
+int get_gemm_splitk();
 void set_attn_v2(int mask);
 int get_attn_v2();
 int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s);

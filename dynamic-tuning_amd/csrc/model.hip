@@ -852,6 +852,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         }
         case DYT_OPT_ATTN_BWD_FUSED: set_attn_bwd_fused(value); return DYT_OK;   // process-wide
         case DYT_OPT_ATTN_V2: set_attn_v2(value & 3); return DYT_OK;             // process-wide
+        case DYT_OPT_GEMM_SPLITK: set_gemm_splitk(value); return DYT_OK;         // process-wide
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
             c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
@@ -863,6 +864,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
 extern "C" int dyt_set_global_option(int option, int value) {
     if (option == DYT_OPT_ATTN_BWD_FUSED) { set_attn_bwd_fused(value); return DYT_OK; }
     if (option == DYT_OPT_ATTN_V2) { set_attn_v2(value & 3); return DYT_OK; }
+    if (option == DYT_OPT_GEMM_SPLITK) { set_gemm_splitk(value); return DYT_OK; }
     if (option == DYT_OPT_F32_SPLIT16) { set_attn_f32_split(value); return DYT_OK; }   // unit entry dyt_attention(precision 0): split forward kernel
     set_error("option %d is not process-wide", option);
     return DYT_ERR_ARG;
@@ -1234,6 +1236,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
                 a.bias2 = base + c->off_ub; a.scale = c->cfg.adapter_scale; a.resid = L.u;
             }
+            if (tail) { a.splitk_ws = (float*)T.dZ; a.splitk_ws_bytes = (size_t)M * DM * c->at; }   // (a backward-pass buffer: idle here)
             RUN_GEMM(EPI_FC2, a);
         }
     }
@@ -1523,6 +1526,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             }
             {
                 GemmArgs a; a.A = T.dZ; a.W = fc1_wT; a.Wp = fc1_wTp; a.M = Mr; a.N = D; a.K = DM; a.m_dev = kdev; a.out_at = T.dA2; if (split16) { SPLIT_G(a, W.fc1_wT3); SPLIT_READY(a, T.h3); }
+                if (tail) { a.splitk_ws = (float*)T.dqkv; a.splitk_ws_bytes = (size_t)M * 3 * D * atb; }   // (written by this block's attention backward, later)
                 if (dense) POISON(2, T.dA2, (size_t)Mr * D * atb);
                 ISO(8, RUN_GEMM(EPI_STORE_AT, a););
                 CK("fc1_dgrad dA2", T.dA2, (size_t)Mr * D * atb);

@@ -210,8 +210,14 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           kernels of csrc/attention.hip (DYT_OPT_ATTN_BWD_FUSED then selects among those).  Same arithmetic contract;
  *                           different summation order, so results agree to rounding, not bit for bit.  PROCESS-wide. */
 #define DYT_OPT_ATTN_V2 9
+/*   DYT_OPT_GEMM_SPLITK         default 1 (environment DYT_SPLITK overrides the default).  16-bit kernels: the K = 3072 GEMMs of the cls-only
+ *                           last block (DYT_OPT_CLS_TAIL; M = batch rows: fc2 forward with the adapter pair, fc1 dgrad) run split over
+ *                           256-wide k slices on ~300 workgroups + one reduce launch that applies the epilogue, instead of 6 tiles of
+ *                           128x128 (csrc/gemm_skinny.h).  Slices are summed in a fixed order: deterministic; agrees with the tile kernels to
+ *                           fp32 rounding of the k sums, not bit for bit.  PROCESS-wide. */
+#define DYT_OPT_GEMM_SPLITK 10
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
-/* the process-wide options (DYT_OPT_ATTN_BWD_FUSED, DYT_OPT_ATTN_V2) without a context: unit entries such as dyt_attention() see them too */
+/* the process-wide options (DYT_OPT_ATTN_BWD_FUSED, DYT_OPT_ATTN_V2, DYT_OPT_GEMM_SPLITK) without a context: unit entries such as dyt_attention() see them too */
 int dyt_set_global_option(int option, int value);
 
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library

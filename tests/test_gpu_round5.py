@@ -125,3 +125,45 @@ def test_fast_modes_vs_oracle_over_seeds(prec, seed):
         prec, seed, got["ls"], got["lt"], got["flips"], ts.numel(), got["gate"], got["down"], got["up"], got["head"]))
     for k, bound in FAST_MODE_BOUND[prec].items():
         assert got[k] <= bound, (prec, seed, k, got[k], bound)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("B", [5, 23])
+def test_splitk_cls_tail_gemms_agree_with_the_tile_kernels_and_are_reproducible(precision, B):
+    """DYT_OPT_GEMM_SPLITK (csrc/gemm_skinny.h): the two K = 3072 GEMMs of the cls-only last block -- fc2 forward with the adapter's operand
+    pair, fc1 dgrad -- as 256-wide k slices + a reduce launch that runs the epilogue functor.  Against the same step on the 128x128 tile
+    kernels: identical masks, logits / losses / the flat gradient to the rounding of a different fp32 summation order; the split form itself
+    twice: identical bits.  B = 5 and 23 leave partial 32-row groups (rows past the batch are neither read nor stored)."""
+    import _lib
+    import synth
+    from test_gpu_parity import _bench_model
+    x, y = synth.make_batch(B, 100, seed=41)
+    g1, g2 = synth.make_noise(B, seed=42)
+    keep = synth.make_dropout_masks(B, 64, seed=43)
+    L = _lib.lib(fp16=(precision == "fp16"))
+    res = []
+    try:
+        for splitk in (0, 1, 1):
+            _lib.check(L.dyt_set_global_option(_lib.OPT_GEMM_SPLITK, splitk))
+            m = _bench_model(precision, "compact", B, 0.7)
+            m.train()
+            eng = m.engine(B, torch.device("cuda", 0))
+            ls = torch.empty(B, 100, device="cuda")
+            ts = torch.zeros(B, 12, 196, device="cuda")
+            losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(),
+                                      keep_mask=keep.cuda().contiguous(), logits_s=ls, token_select=ts).clone()
+            torch.cuda.synchronize()
+            res.append((losses.cpu(), ls.cpu(), ts.cpu(), eng.grad.clone().cpu()))
+            del m, eng
+    finally:
+        _lib.check(L.dyt_set_global_option(_lib.OPT_GEMM_SPLITK, 1))
+    tile, sk, sk2 = res
+    for a, b in zip(sk, sk2):
+        assert torch.equal(a, b)
+    assert torch.equal(sk[2], tile[2])
+    tol = 1e-3 if precision == "fp16" else 4e-3
+    dl = float((sk[1] - tile[1]).abs().max())
+    dg = float((sk[3] - tile[3]).norm() / tile[3].norm())
+    print("%s B=%d split-K vs tiles: logits %.2e, losses %.2e, gradient (relative norm) %.2e" % (precision, B, dl, float((sk[0][:5] - tile[0][:5]).abs().max()), dg))
+    assert dl < tol and dg < tol * 5 and float((sk[0][:5] - tile[0][:5]).abs().max()) < tol * 5
+    assert torch.isfinite(sk[3]).all()
