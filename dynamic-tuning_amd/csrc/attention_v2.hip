@@ -188,10 +188,21 @@ __device__ __forceinline__ void store_piece(bf16* const (&rp)[4], const bool (&o
 // Two barriers per head: (a) head i's images have landed / every wave has left head i-1's K, V; (b) every wave holds its q fragments,
 // the Q image may be overwritten.  PIPE: the score tile of key tile kt+1 is issued before the exponentials of tile kt.
 // ABL (tools/probes/r5/av2_test.hip only): 1 = no output stores, 2 = no compute, 4 = no DMA after the first head
-template <bool PIPE, int ABL = 0>
+// OUT3 (the exact-forward modes' complete_model pass, whose attention is the hi * hi product of the q / k / v planes): `out` is the proj
+// GEMM's split operand image, rows of SPLIT_A * 768 16-bit elements -- [hi | lo] (store4_split3) or, f8, [hi | e4m3(hi) | e4m3(lo 2^12)]
+// (store4_split_f8) -- written from the fp32 result: hi = its 16-bit rounding (also what the 16-bit backward reads as o), lo the remainder.
+// The lo plane goes through the same lane exchanges as a second packed tile.
+__device__ __forceinline__ uint2 e4m3x8(const uint4& h8) {   // 8 packed 16-bit values -> 8 e4m3 bytes
+    const bf16x8 x = __builtin_bit_cast(bf16x8, h8);
+    uint2 r;
+    r.x = (unsigned)pack4_e4m3((float)x[0], (float)x[1], (float)x[2], (float)x[3]);
+    r.y = (unsigned)pack4_e4m3((float)x[4], (float)x[5], (float)x[6], (float)x[7]);
+    return r;
+}
+template <bool PIPE, int ABL = 0, bool OUT3 = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                              const bf16* __restrict__ v, bf16* __restrict__ out,
-                                                             float* __restrict__ lse, int nheads) {
+                                                             float* __restrict__ lse, int nheads, int f8 = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | V0 | K1 | V1 | Q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -309,12 +320,45 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) { on[0][r] = o[0][r]; on[1][r] = o[1][r]; }
         uint4 pk[4];
+        const int chunk = 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + hi;
+        if constexpr (OUT3) {
+            f32x16 lo[2];
+            const float ls = f8 ? F8_LO_SCALE : 1.0f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = on[dt][r] * inv;
+                    asm("" : "+v"(x));   // (split2: one rounding of ONE value)
+                    on[dt][r] = x;
+                    lo[dt][r] = (x - (float)(bf16)x) * ls;
+                }
+            uint4 pl[4];
+            pack_rows(pk, on, 1.0f);
+            pack_rows(pl, lo, 1.0f);
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int tr_ = wave * 32 + pc * 8 + (lane & 7);
+                if (tr_ >= NT) continue;
+                bf16* rowp = out + ((size_t)b * NT + tr_) * (SPLIT_A * D);
+                const int col = h * HD + chunk * 8;
+                *reinterpret_cast<uint4*>(rowp + col) = pk[pc];
+                if (!f8) {
+                    *reinterpret_cast<uint4*>(rowp + D + col) = pl[pc];
+                } else {
+                    unsigned char* r8 = reinterpret_cast<unsigned char*>(rowp) + 2 * (size_t)D + col;
+                    *reinterpret_cast<uint2*>(r8) = e4m3x8(pk[pc]);
+                    *reinterpret_cast<uint2*>(r8 + D) = e4m3x8(pl[pc]);
+                }
+            }
+            continue;
+        }
         pack_rows(pk, on, inv);
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) {
             const int tr_ = wave * 32 + pc * 8 + (lane & 7);
             if (tr_ < NT)
-                *reinterpret_cast<uint4*>(out + ((size_t)b * NT + tr_) * D + h * HD + (4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + hi) * 8) = pk[pc];
+                *reinterpret_cast<uint4*>(out + ((size_t)b * NT + tr_) * D + h * HD + chunk * 8) = pk[pc];
         }
     }
 }
@@ -623,7 +667,7 @@ static int set_lds_v2(const void* fn, size_t bytes) {
     return 0;
 }
 
-int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s) {
+int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s, int out3, int out3_f8) {
     const int grid = batch * NH;
     const size_t lds = 5 * av2::IMG;
     static bool done[64] = {};
@@ -631,11 +675,18 @@ int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, f
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (!done[dev & 63]) {
-        if (set_lds_v2((const void*)av2::attn_fwd_v2_kernel<true>, lds) || set_lds_v2((const void*)av2::attn_fwd_v2_kernel<false>, lds)) return -2;
+        if (set_lds_v2((const void*)av2::attn_fwd_v2_kernel<true>, lds) || set_lds_v2((const void*)av2::attn_fwd_v2_kernel<false>, lds) ||
+            set_lds_v2((const void*)av2::attn_fwd_v2_kernel<true, 0, true>, lds)) return -2;
         done[dev & 63] = true;
     }
+    if (out3) {   // `out` = the split operand image of the proj GEMM
+        hipLaunchKernelGGL((av2::attn_fwd_v2_kernel<true, 0, true>), dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                           (bf16*)out, lse, grid, out3_f8);
+        DYT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     auto* kern = pipe ? av2::attn_fwd_v2_kernel<true> : av2::attn_fwd_v2_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, grid);
+    hipLaunchKernelGGL(kern, dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, grid, 0);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1146,8 +1146,7 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
             (size_t)slices * a.M * a.N * sizeof(float) <= a.splitk_ws_bytes && (!CAT || (a.A2 && a.W2))) {
             hipLaunchKernelGGL((gemm_splitk_kernel<CAT>), dim3(a.N / 32, (a.M + 127) / 128, slices), dim3(256), 0, s, static_cast<const bf16*>(a.A),
                                static_cast<const bf16*>(a.W), a.M, a.N, a.K, a.a_map, static_cast<const bf16*>(a.A2), static_cast<const bf16*>(a.W2),
-                               a.a2_map, a.splitk_ws);
-            ++g_bf16_kernel_launches;
+                               a.a2_map, a.splitk_ws);   // (not counted in g_bf16_kernel_launches: tools/pmc_traffic.py selects the gemm_bf16_* kernels)
             hipLaunchKernelGGL((splitk_reduce_kernel<Epi>), dim3((unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256)), dim3(256), 0, s, a.splitk_ws, slices, a.M,
                                a.N, a.out_scale, epi);
             DYT_HIP_CHECK(hipGetLastError());
@@ -1180,6 +1179,14 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         if (shortk_small && a.a_ld && a.K <= D && (a.N >= g_big_tile_min_n || shortk_small == 2) && a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
     }
     if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
+    if constexpr (!CAT) {
+        // K <= 768, N = 768 with a residual epilogue (proj forward, patch embedding): 12 k-steps against an epilogue that moves 194 MB -- the
+        // launch is bound by its epilogue traffic, and 1182 tiles of 128x128 on 512 slots interleave main loops and epilogues where 255 big
+        // tiles run them as two chip-wide phases: 74.6 vs 59 + 20.5 us (256x256 body + 128x128 row tail), step 24.98 vs 25.03 ms same-box,
+        // one launch instead of two; same k order, same bits.  DYT_SHORTK_N768_SMALL=0: the split-row scheme for these too
+        static const int shortk_n768 = getenv("DYT_SHORTK_N768_SMALL") ? atoi(getenv("DYT_SHORTK_N768_SMALL")) : 1;
+        if (shortk_n768 && a.K <= D && a.N % 128 == 0 && a.M >= 2048 && !a.a_ld) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
+    }
     if (a.N % 256 == 0 && a.K >= 256 && g_split_rows) {
         // Narrow-N GEMMs (N = 768): per row, 256x256 tiles are ~1.6x cheaper than 128x128 tiles (half the L2->LDS bytes
         // per FLOP), but 99 x 3 = 297 tiles leave 41 for a second round.  The rows that fill whole rounds of 256

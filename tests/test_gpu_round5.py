@@ -167,3 +167,47 @@ def test_splitk_cls_tail_gemms_agree_with_the_tile_kernels_and_are_reproducible(
     print("%s B=%d split-K vs tiles: logits %.2e, losses %.2e, gradient (relative norm) %.2e" % (precision, B, dl, float((sk[0][:5] - tile[0][:5]).abs().max()), dg))
     assert dl < tol and dg < tol * 5 and float((sk[0][:5] - tile[0][:5]).abs().max()) < tol * 5
     assert torch.isfinite(sk[3]).all()
+
+
+@pytest.mark.parametrize("precision", ["fp16x3q"])   # (the only mode whose complete_model pass takes the one-part attention)
+def test_complete_model_attention_of_the_exact_forward_modes_on_the_round5_kernel(precision):
+    """The complete_model (teacher) pass of the exact-forward modes takes the hi * hi product alone in its attention forward.  With
+    DYT_OPT_ATTN_V2 bit 0 that product runs on the round-5 16-bit kernel (planes as they are, the fp32 result split into the proj GEMM's
+    [hi | e4m3 | e4m3] operand image on the way out) instead of attn_fwd_split_kernel<PLANES, 1>: the teacher logits of a step stay within
+    1e-4 of the round-4 kernel's, the student logits / masks (three-part attention: untouched) are bit-identical, the gradient agrees to
+    1e-3 of its norm; and the step is reproducible bit for bit."""
+    import _lib
+    import synth
+    from test_gpu_parity import _bench_model
+    B = 6
+    x, y = synth.make_batch(B, 100, seed=51)
+    g1, g2 = synth.make_noise(B, seed=52)
+    keep = synth.make_dropout_masks(B, 64, seed=53)
+    L = _lib.lib(fp16=True)
+    res = []
+    try:
+        for v2 in (2, 3, 3):   # 2: the round-5 backward with the round-4 forward kernels -> only the teacher's forward attention differs
+            _lib.check(L.dyt_set_global_option(_lib.OPT_ATTN_V2, v2))
+            m = _bench_model(precision, "compact", B, 0.7)
+            m.train()
+            eng = m.engine(B, torch.device("cuda", 0))
+            ls = torch.empty(B, 100, device="cuda")
+            lt = torch.empty(B, 100, device="cuda")
+            ts = torch.zeros(B, 12, 196, device="cuda")
+            eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(),
+                             keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts)
+            torch.cuda.synchronize()
+            res.append((ls.cpu(), lt.cpu(), ts.cpu(), eng.grad.clone().cpu()))
+            del m, eng
+    finally:
+        _lib.check(L.dyt_set_global_option(_lib.OPT_ATTN_V2, 3))
+    old, new, new2 = res
+    for a, b in zip(new, new2):
+        assert torch.equal(a, b)
+    assert torch.equal(new[2], old[2])
+    dt = float((new[1] - old[1]).abs().max())
+    ds = float((new[0] - old[0]).abs().max())
+    dg = float((new[3] - old[3]).norm() / old[3].norm())
+    print("%s B=%d teacher logits %.2e, student logits %.2e, gradient (relative norm) %.2e vs the round-4 one-part kernel" % (precision, B, dt, ds, dg))
+    assert dt < 1e-4 and dg < 1e-3 and ds == 0.0
+    assert torch.isfinite(new[3]).all()
