@@ -1421,8 +1421,8 @@ int launch_attn_fwd(int precision, const void* q, const void* k, const void* v, 
         if (parts != 3 && !(save16 && save16->q_lo && parts == 1)) { set_error("attention forward: the one-part form needs the planar q / k / v"); return -1; }
         // one-part form with nothing but the operand image to write (every block of a complete_model pass but the cls-only last one): the
         // round-5 16-bit kernel on the hi planes, its result split on the way out (DYT_OPT_ATTN_V2 bit 0)
-        if (save16 && save16->q_lo && parts == 1 && !out && out3 && !save16->o && (get_attn_v2() & 1))
-            return launch_attn_fwd_v2(save16->q, save16->k, save16->v, out3, lse, batch, s, 1, out3_f8);
+        if (save16 && save16->q_lo && parts == 1 && !out && out3 && out3_f8 && !save16->o && (get_attn_v2() & 1))
+            return launch_attn_fwd_v2(save16->q, save16->k, save16->v, out3, lse, batch, s, 1);
         if (save16 && save16->q_lo && parts == 1)
             hipLaunchKernelGGL((attn_fwd_split_kernel<true, 1>), dim3(min(grid, 256)), dim3(448), lds, s, nullptr, nullptr, nullptr, (float*)out, lse, grid,
                                (bf16*)out3, (bf16*)save16->q, (bf16*)save16->k, (bf16*)save16->v, (bf16*)save16->o, out3_f8,

@@ -188,10 +188,10 @@ __device__ __forceinline__ void store_piece(bf16* const (&rp)[4], const bool (&o
 // Two barriers per head: (a) head i's images have landed / every wave has left head i-1's K, V; (b) every wave holds its q fragments,
 // the Q image may be overwritten.  PIPE: the score tile of key tile kt+1 is issued before the exponentials of tile kt.
 // ABL (tools/probes/r5/av2_test.hip only): 1 = no output stores, 2 = no compute, 4 = no DMA after the first head
-// OUT3 (the exact-forward modes' complete_model pass, whose attention is the hi * hi product of the q / k / v planes): `out` is the proj
-// GEMM's split operand image, rows of SPLIT_A * 768 16-bit elements -- [hi | lo] (store4_split3) or, f8, [hi | e4m3(hi) | e4m3(lo 2^12)]
-// (store4_split_f8) -- written from the fp32 result: hi = its 16-bit rounding (also what the 16-bit backward reads as o), lo the remainder.
-// The lo plane goes through the same lane exchanges as a second packed tile.
+// OUT3 (the complete_model pass of "fp16x3q", whose attention is the hi * hi product of the q / k / v planes): `out` is the proj GEMM's
+// operand image in the hi16 / fp8 form, rows of SPLIT_A * 768 16-bit elements [hi | e4m3(hi) | e4m3(lo 2^12)] (store4_split_f8), written
+// from the fp32 result: hi = its 16-bit rounding (also what the 16-bit backward reads as o), lo the remainder.  The lo plane goes through
+// the same lane exchanges as a second packed tile.
 __device__ __forceinline__ uint2 e4m3x8(const uint4& h8) {   // 8 packed 16-bit values -> 8 e4m3 bytes
     const bf16x8 x = __builtin_bit_cast(bf16x8, h8);
     uint2 r;
@@ -202,7 +202,7 @@ __device__ __forceinline__ uint2 e4m3x8(const uint4& h8) {   // 8 packed 16-bit 
 template <bool PIPE, int ABL = 0, bool OUT3 = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                              const bf16* __restrict__ v, bf16* __restrict__ out,
-                                                             float* __restrict__ lse, int nheads, int f8 = 0) {
+                                                             float* __restrict__ lse, int nheads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | V0 | K1 | V1 | Q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -323,7 +323,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
         const int chunk = 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + hi;
         if constexpr (OUT3) {
             f32x16 lo[2];
-            const float ls = f8 ? F8_LO_SCALE : 1.0f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
                     float x = on[dt][r] * inv;
                     asm("" : "+v"(x));   // (split2: one rounding of ONE value)
                     on[dt][r] = x;
-                    lo[dt][r] = (x - (float)(bf16)x) * ls;
+                    lo[dt][r] = (x - (float)(bf16)x) * F8_LO_SCALE;
                 }
             uint4 pl[4];
             pack_rows(pk, on, 1.0f);
@@ -343,13 +342,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(const bf16* __restr
                 bf16* rowp = out + ((size_t)b * NT + tr_) * (SPLIT_A * D);
                 const int col = h * HD + chunk * 8;
                 *reinterpret_cast<uint4*>(rowp + col) = pk[pc];
-                if (!f8) {
-                    *reinterpret_cast<uint4*>(rowp + D + col) = pl[pc];
-                } else {
-                    unsigned char* r8 = reinterpret_cast<unsigned char*>(rowp) + 2 * (size_t)D + col;
-                    *reinterpret_cast<uint2*>(r8) = e4m3x8(pk[pc]);
-                    *reinterpret_cast<uint2*>(r8 + D) = e4m3x8(pl[pc]);
-                }
+                unsigned char* r8 = reinterpret_cast<unsigned char*>(rowp) + 2 * (size_t)D + col;
+                *reinterpret_cast<uint2*>(r8) = e4m3x8(pk[pc]);
+                *reinterpret_cast<uint2*>(r8 + D) = e4m3x8(pl[pc]);
             }
             continue;
         }
@@ -667,7 +662,7 @@ static int set_lds_v2(const void* fn, size_t bytes) {
     return 0;
 }
 
-int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s, int out3, int out3_f8) {
+int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s, int out3_f8) {
     const int grid = batch * NH;
     const size_t lds = 5 * av2::IMG;
     static bool done[64] = {};
@@ -679,14 +674,14 @@ int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, f
             set_lds_v2((const void*)av2::attn_fwd_v2_kernel<true, 0, true>, lds)) return -2;
         done[dev & 63] = true;
     }
-    if (out3) {   // `out` = the split operand image of the proj GEMM
+    if (out3_f8) {   // `out` = the proj GEMM's operand image in the hi16 / fp8 form
         hipLaunchKernelGGL((av2::attn_fwd_v2_kernel<true, 0, true>), dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                           (bf16*)out, lse, grid, out3_f8);
+                           (bf16*)out, lse, grid);
         DYT_HIP_CHECK(hipGetLastError());
         return 0;
     }
     auto* kern = pipe ? av2::attn_fwd_v2_kernel<true> : av2::attn_fwd_v2_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, grid, 0);
+    hipLaunchKernelGGL(kern, dim3(min(grid, 256)), dim3(512), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, grid);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -131,7 +131,7 @@ void set_gemm_splitk(int on);   // DYT_OPT_GEMM_SPLITK
 int get_gemm_splitk();
 void set_attn_v2(int mask);
 int get_attn_v2();
-int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s, int out3 = 0, int out3_f8 = 0);   // out3: `out` is the proj GEMM's split operand image (rows of SPLIT_A * 768), [hi | lo] or the hi16 / fp8 form
+int launch_attn_fwd_v2(const void* q, const void* k, const void* v, void* out, float* lse, int batch, hipStream_t s, int out3_f8 = 0);   // out3_f8: `out` is the proj GEMM's operand image in the hi16 / fp8 form (rows of SPLIT_A * 768)
 int launch_attn_bwd_v2(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, void* dqkv,
                        int batch, hipStream_t s, int q_tiles, int out_ld);
 
