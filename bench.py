@@ -49,6 +49,7 @@ PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3,   # TFLOP/s dense MFMA, M
         "fp16x3q": 2500.0 / 1.75,  # qkv / proj (both passes) and the teacher pass's MLP in the fp8-correction form (two f16-equivalents), the student's MLP three-part
         "fp16f8": 2500.0 / 1.5}  # forward: one f16 product + two fp8 products at twice the rate = two f16-equivalents; backward one  # the same product counts; the backward runs on 16-bit operands with the fp16 mode's kernels
 TRAFFIC_JSON = os.path.join("round5", "gemm_traffic.json")
+SUSTAINED_MFMA_TFLOPS = 1670.0   # measured, see roofline.sustained_mfma_measured
 
 
 class Cfg(dict):
@@ -421,6 +422,12 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
                 "avg_launch_ms": round(ms / max(n, 1), 4), "gemm_ms_per_step": round(ms, 3),
                 "attention_ms_per_step": round(ms_a, 3), "attention_tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2) if ms_a else None,
                 "other_kernels_ms_per_step": round(ms_o, 3), "other_launches": n_o}
+        if precision != "fp32":
+            # `peak` is the guide's dense figure (2.4 GHz).  What the matrix cores SUSTAIN on this board with non-zero operands is set by its power cap:
+            # a register-only v_mfma_f32_{16x16x32,32x32x16}_f16 loop (no LDS, no memory) runs 2 475 TFLOP/s on zeros (2.40 GHz, 0.9 kW) and
+            # 1 670 TFLOP/s on random data (1.75 GHz at the 1.3 kW cap) -- tools/probes/r5/mfma_f16_peak.hip, profiles/round5/r5_mfma_f16_peak.txt
+            roof["sustained_mfma_measured"] = {"value": SUSTAINED_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach * 2500.0 / PEAK[precision] / SUSTAINED_MFMA_TFLOPS, 4),
+                                               "source": "profiles/round5/r5_mfma_f16_peak.txt: register-only f16 MFMA loop, random operands, 5 s, power-capped at 1.3 kW / 1.75 GHz (zeros: 2475 at 2.4 GHz); informational -- `frac` above is against `peak`"}
     ips = args.batch * world * steps / dt
     # algorithmic FLOPs per image.  compact: MLP forward AND backward on the kept tokens of the student pass;
     # masked: the student forward is dense (mask-multiply, as the reference), its backward is compacted all the same
