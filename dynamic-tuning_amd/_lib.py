@@ -101,6 +101,8 @@ SYMBOLS = {
     "dyt_ctx_bytes": (_i, [_vp, ctypes.POINTER(_i64)]),
     "dyt_ctx_set_option": (_i, [_vp, _i, _i]),
     "dyt_set_global_option": (_i, [_i, _i]),
+    "dyt_set_drop_path": (_i, [_vp, _f]),
+    "dyt_set_drop_path_scales": (_i, [_vp, _i, _vp]),
     "dyt_set_frozen": (_i, [_vp, _i, _i, _vp, _vp]),
     "dyt_trainable_numel": (_i, [_vp, ctypes.POINTER(_i64)]),
     "dyt_trainable_offset": (_i, [_vp, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
@@ -118,6 +120,7 @@ SYMBOLS = {
     "dyt_clip_grad_norm": (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp]),
     "dyt_debug_dispatch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dyt_debug_dact": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "dyt_debug_drop_path": (_i, [_vp, _i, _vp, _vp]),
     "dyt_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dyt_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dyt_linear_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -131,6 +131,7 @@ template <class AT, class OT = AT, bool STATS = false>
 struct EpiBiasResid {
     const float* bias; const float* resid; float* out; OT* out_at; int ld;
     float2* part = nullptr;
+    const float* rs = nullptr;   // stochastic depth (GemmArgs::row_scale): the branch (acc + bias) of image row / 197 is multiplied by rs[image]
     typedef Bias4 Col; typedef Raw4<float> Pre;
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
     __device__ __forceinline__ Pre pre(int row, int col) const { return load_raw4(resid + (size_t)row * ld + col); }
@@ -138,8 +139,13 @@ struct EpiBiasResid {
         const size_t o = (size_t)row * ld + col;
         float r[4];
         p.get(r);
-        const float v0 = a[0] + c.b[0] + r[0], v1 = a[1] + c.b[1] + r[1];
-        const float v2 = a[2] + c.b[2] + r[2], v3 = a[3] + c.b[3] + r[3];
+        float v0 = a[0] + c.b[0] + r[0], v1 = a[1] + c.b[1] + r[1];
+        float v2 = a[2] + c.b[2] + r[2], v3 = a[3] + c.b[3] + r[3];
+        if (rs) {   // (uniform branch; off the default path)
+            const float sc = rs[row / NT];
+            v0 = fmaf(sc, a[0] + c.b[0], r[0]); v1 = fmaf(sc, a[1] + c.b[1], r[1]);
+            v2 = fmaf(sc, a[2] + c.b[2], r[2]); v3 = fmaf(sc, a[3] + c.b[3], r[3]);
+        }
         store4(out + o, v0, v1, v2, v3);
         if (out_at) store4(out_at + o, v0, v1, v2, v3);
         if constexpr (STATS) {
@@ -241,6 +247,7 @@ template <class AT, bool PLAIN, class HT = AT>   // HT: type the MLP output is s
 struct EpiFc2 {
     const float* bias; float* x; const int* row_map; const float* row_mask; HT* h_out;
     const float* resid; const float* bias2; float scale2;
+    const float* rs = nullptr;   // stochastic depth (GemmArgs::row_scale): the MLP branch of token row t is multiplied by rs[t / 197] (h_out keeps the unscaled value)
     // b: what is added to the accumulator for x (fc2 bias + s * up-projection bias); hb: the same for the saved MLP output h_out
     // (fc2 bias only: with the up-projection riding on the contraction h_out = mlp(x) + s up_nobias(d_act), and tok_bwd takes
     // <g, s up_nobias(d_act)> back out of the gate gradient -- without the bias term it needs no 768-wide dot for that)
@@ -281,11 +288,13 @@ struct EpiFc2 {
         if constexpr (PLAIN) {
             if (h_out) store4_nt(h_out + (size_t)row * D + col, h0, h1, h2, h3);   // read again only by the backward pass
             p.get(r);
-            store4(x + (size_t)row * D + col, r[0] + h0, r[1] + h1, r[2] + h2, r[3] + h3);
+            const float sc = rs ? rs[row / NT] : 1.0f;
+            store4(x + (size_t)row * D + col, fmaf(sc, h0, r[0]), fmaf(sc, h1, r[1]), fmaf(sc, h2, r[2]), fmaf(sc, h3, r[3]));
         } else {
             if (h_out) store4_nt(h_out + (size_t)row * D + col, a[0] + c.hb[0], a[1] + c.hb[1], a[2] + c.hb[2], a[3] + c.hb[3]);
             p.r.get(r);
-            store4(x + (size_t)p.dst * D + col, r[0] + p.m * h0, r[1] + p.m * h1, r[2] + p.m * h2, r[3] + p.m * h3);
+            const float m = rs ? p.m * rs[p.dst / NT] : p.m;
+            store4(x + (size_t)p.dst * D + col, r[0] + m * h0, r[1] + m * h1, r[2] + m * h2, r[3] + m * h3);
         }
     }
 };
@@ -395,6 +404,7 @@ template <bool MAPPED>   // MAPPED: rows go through row_map (cls-only tail of th
 struct EpiAdUp {
     const float* bias; const float* u; float* out; float scale; const int* row_map;
     const float* skip_mask;   // rows with skip_mask[row] != 0 are left alone (kept tokens: their fc2 launch adds the adapter itself)
+    const float* rs = nullptr;   // MAPPED (cls-row proj of a complete_model pass's last block): stochastic-depth scale of image dst / 197
     typedef Bias4 Col;
     struct PreG { int dst; Raw4<float> r; };
     typedef typename std::conditional<MAPPED, PreG, Raw4<float>>::type Pre;
@@ -414,8 +424,10 @@ struct EpiAdUp {
         float r[4];
         size_t dst = row;
         if constexpr (MAPPED) { p.r.get(r); dst = p.dst; } else { if (skip_mask && skip_mask[row] != 0.f) return; p.get(r); }
-        store4(out + dst * D + col, r[0] + scale * (a[0] + c.b[0]), r[1] + scale * (a[1] + c.b[1]),
-               r[2] + scale * (a[2] + c.b[2]), r[3] + scale * (a[3] + c.b[3]));
+        float sc = scale;
+        if constexpr (MAPPED) { if (rs) sc *= rs[dst / NT]; }
+        store4(out + dst * D + col, r[0] + sc * (a[0] + c.b[0]), r[1] + sc * (a[1] + c.b[1]),
+               r[2] + sc * (a[2] + c.b[2]), r[3] + sc * (a[3] + c.b[3]));
     }
 };
 
@@ -1274,15 +1286,15 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             }
             return run<AT, SPLIT>(a, EpiQKV<AT>{a.bias, (AT*)a.out_at, (AT*)a.out_at2, (AT*)a.out_at3}, s);
         case EPI_BIAS_RESID:
-            if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N}, s); }
+            if constexpr (SPLIT) { if (a.save16) return run<AT, SPLIT>(a, EpiBiasResid<AT, bf16>{a.bias, a.resid, a.out_f32, (bf16*)a.out_at, a.N, nullptr, a.row_scale}, s); }
             if constexpr (sizeof(AT) == 2) {
                 if (a.ln_part) {
                     if (a.N != LN_PARTS * 64) { set_error("gemm: LayerNorm partials need N = %d", LN_PARTS * 64); return -1; }
-                    return run<AT, SPLIT>(a, EpiBiasResid<AT, AT, true>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N, a.ln_part}, s);
+                    return run<AT, SPLIT>(a, EpiBiasResid<AT, AT, true>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N, a.ln_part, a.row_scale}, s);
                 }
             }
             if (a.ln_part) { set_error("gemm: LayerNorm partials exist in the 16-bit modes only"); return -1; }
-            return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N}, s);
+            return run<AT, SPLIT>(a, EpiBiasResid<AT>{a.bias, a.resid, a.out_f32, (AT*)a.out_at, a.N, nullptr, a.row_scale}, s);
         case EPI_FC1:
             if constexpr (SPLIT) {   // the split forms take the A&S GELU (EpiFc1<FAST>): 42.7 vs 43.1 ms/step, logits vs the oracle unchanged (2.4e-5 / 6e-6)
                 if (a.save16 && a.out_at2) return run<AT, SPLIT>(a, EpiFc1<AT, true, bf16, true>{a.bias, (AT*)a.out_at, (bf16*)a.out_at2, a.N, (bf16*)a.out3, a.out3_f8}, s);
@@ -1311,8 +1323,8 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             if (a.A2) {   // adapter up-projection as the leading k-tile of the contraction (16-bit kernels only)
                 if constexpr (sizeof(AT) == 2) {
                     if (!a.row_map && !a.row_mask)
-                        return run_bf16<EpiFc2<AT, true>, true>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, a.bias2, a.scale}, s);
-                    return run_bf16<EpiFc2<AT, false>, true>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, a.bias2, a.scale}, s);
+                        return run_bf16<EpiFc2<AT, true>, true>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
+                    return run_bf16<EpiFc2<AT, false>, true>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
                 } else {
                     set_error("gemm: the K-concatenated fc2 form exists in the 16-bit modes only");
                     return -1;
@@ -1320,12 +1332,12 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             }
             if constexpr (SPLIT) {
                 if (a.save16 && a.h_out) {
-                    if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true, bf16>{a.bias, a.out_f32, nullptr, nullptr, (bf16*)a.h_out, resid, nullptr, 0.f}, s);
-                    return run<AT, SPLIT>(a, EpiFc2<AT, false, bf16>{a.bias, a.out_f32, a.row_map, a.row_mask, (bf16*)a.h_out, resid, nullptr, 0.f}, s);
+                    if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true, bf16>{a.bias, a.out_f32, nullptr, nullptr, (bf16*)a.h_out, resid, nullptr, 0.f, a.row_scale}, s);
+                    return run<AT, SPLIT>(a, EpiFc2<AT, false, bf16>{a.bias, a.out_f32, a.row_map, a.row_mask, (bf16*)a.h_out, resid, nullptr, 0.f, a.row_scale}, s);
                 }
             }
-            if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, nullptr, 0.f}, s);
-            return run<AT, SPLIT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f}, s);
+            if (!a.row_map && !a.row_mask) return run<AT, SPLIT>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, nullptr, 0.f, a.row_scale}, s);
+            return run<AT, SPLIT>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, nullptr, 0.f, a.row_scale}, s);
         }
         case EPI_GELU_BWD:
             if (a.row_map) return run<AT, SPLIT>(a, EpiGeluBwd<AT, true>{(const AT*)a.aux_at, (AT*)a.out_at, a.N, a.row_map, (bf16*)a.out3, a.out3_scale, a.out3_hi_only}, s);
@@ -1338,7 +1350,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             }
             return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (AT*)a.out_at2, a.scale}, s);
         case EPI_AD_UP:
-            if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr}, s);
+            if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr, a.row_scale}, s);
             return run<AT, SPLIT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT, SPLIT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);

@@ -85,6 +85,9 @@ struct GemmArgs {
     uint64_t seed = 0, subseq = 0;
     const uint64_t* seed_dev = nullptr;   // when set, the Philox seed is read from this device word (graph replay)
     int accumulate = 0;
+    // stochastic depth (timm DropPath, reference models/vision_transformer_IN21K.py:121,131,148,159): per-IMAGE factors (0 or 1 / keep) on the
+    // branch a residual epilogue adds -- BIAS_RESID / mapped AD_UP: x + rs[b] (acc + bias); FC2: u + rs[b] mask (acc + bias) -- b = token row / 197
+    const float* row_scale = nullptr;
     // skinny K >= 1024 GEMMs (the cls-only last block): workspace for the split-K form (gemm_skinny.h), [slices][M][N] fp32; null = tile kernels
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;
     double flops() const { return 2.0 * M * (double)N * K; }
@@ -280,8 +283,16 @@ struct TokBwdArgs {
     float cat_scale = 0.f, cat_ddz_scale = 0.f;   // s ; 1 / (inv_keep * gs)
     void* du3 = nullptr;           // fp32 split form: + du * du3_scale as the [M][3*768] 16-bit hi / hi / lo operand of the proj dgrad
     float du3_scale = 1.0f; bool du3_hi_only = false;   // hi_only: without the lo half (one-part proj dgrad)
+    // stochastic depth: the MLP branch of image b was multiplied by branch_scale[b] in the forward pass (GemmArgs::row_scale of FC2), so
+    // its LN2-input gradient and the gate gradient <g, h> are too
+    const float* branch_scale = nullptr;
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
+// stochastic depth (timm DropPath): scales[branch][l][b] for branch 0 (attention) / 1 (MLP), blocks l < depth, images b < batch: 1 with
+// probability keep_l = 1 - rate * l / (depth - 1), else 0, divided by keep_l; block 0 (rate 0) always 1.  Philox stream (seed | *seed_dev, subseq_base + 2 l + branch, b)
+int launch_drop_path_draw(float* scales, int depth, int batch, float rate, uint64_t seed, const uint64_t* seed_dev, uint64_t subseq_base, hipStream_t s);
+// x[row, :] *= scale[row / 197] for an AT matrix [M, ld] (the attention branch's gradient after the proj dgrad)
+int launch_scale_rows(int precision, void* x, const float* scale, int M, int ld, hipStream_t s);
 // out[i] += alpha * sum_p partial[p*stride + i], i < n
 int launch_reduce_partials(const float* partial, int nparts, int stride, float* out, int n, float alpha,
                            hipStream_t s);

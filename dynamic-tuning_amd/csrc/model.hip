@@ -166,6 +166,9 @@ struct Slot {
     bool valid = false;
     bool saved16 = false;    // the saved pass holds the 16-bit tensors of a 16-bit backward (dyt_ctx::bwd16)
     const float* trainable = nullptr;  // flat trainable buffer the saved pass was computed with
+    // stochastic depth (dyt_set_drop_path): the per-image branch factors [2][depth][batch] of this slot's passes -- drawn by the library
+    // into dp_own at every training forward, or the caller's (dp_inject, dyt_set_drop_path_scales); dp = what the SAVED pass used (null: none)
+    float* dp_own = nullptr; const float* dp_inject = nullptr; const float* dp = nullptr;
 };
 struct ProfRec { int cat; double flops; hipEvent_t a, b; const int* m_dev; int M; };
 
@@ -235,6 +238,7 @@ struct dyt_ctx {
     bool ov_pass = true, ov_branch = false;  // student / teacher passes on two streams; adapter branch on its own stream
     bool ov_bwd_serial = false;          // the teacher's backward starts after the student's (bit-reproducible schedule)
     bool share_block0 = true;  // step: the teacher pass reuses the student's embedding + block-0 attention branch
+    float drop_path_rate = 0.f;  // timm DropPath rate of the LAST block (block l: rate * l / (depth - 1)); training forward passes only
     int count_flops_tokens = 0;  // > 0: Block.forward_count_flops -- MLP on the first n tokens of every image
     // profiling
     bool prof = false;
@@ -366,6 +370,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
         T.wg_partial2 = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
         Slot& S = c->slots[sl];
+        S.dp_own = carve<float>(c, 2 * depth * B, dry);
         S.wg_part.resize(depth); S.wg_part2.resize(depth); S.tok_part.resize(depth);
         for (size_t l = 0; l < depth; ++l) {
             S.wg_part[l] = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
@@ -861,6 +866,19 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
     return DYT_ERR_ARG;
 }
 
+extern "C" int dyt_set_drop_path(dyt_ctx* c, float rate) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    if (!(rate >= 0.f) || rate >= 1.f) { set_error("drop_path rate %g out of [0, 1)", rate); return DYT_ERR_ARG; }
+    c->drop_path_rate = rate;
+    return DYT_OK;
+}
+extern "C" int dyt_set_drop_path_scales(dyt_ctx* c, int slot, const float* scales) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
+    c->slots[slot].dp_inject = scales;
+    return DYT_OK;
+}
+
 extern "C" int dyt_set_global_option(int option, int value) {
     if (option == DYT_OPT_ATTN_BWD_FUSED) { set_attn_bwd_fused(value); return DYT_OK; }
     if (option == DYT_OPT_ATTN_V2) { set_attn_v2(value & 3); return DYT_OK; }
@@ -1082,6 +1100,18 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
+    // stochastic depth (reference vision_transformer_IN21K.py:121,131,148,159; dpr = linspace(0, rate, depth), :285): training passes only;
+    // every pass draws its own factors, like every call of the reference's forward does.  dp[(branch * depth + l) * B + b]
+    const float* dp = nullptr;
+    if (training && (S.dp_inject || c->drop_path_rate > 0.f)) {
+        if (c->count_flops_tokens) { set_error("drop_path with the count_flops forward"); return DYT_ERR_STATE; }
+        dp = S.dp_inject;
+        if (!dp) {
+            RUN(2, 0, launch_drop_path_draw(S.dp_own, depth, B, c->drop_path_rate, seed, seed_dev, ((uint64_t)slot << 32) | 0x10000ull, s));
+            dp = S.dp_own;
+        }
+    }
+    S.dp = dp;
     const bool tokens_in = flags & DYT_F_TOKENS_IN, tokens_out = flags & DYT_F_TOKENS_OUT;
     if (tokens_in) {
         // stand-alone Block.forward (reference vision_transformer_IN21K.py:144-165 called on a token tensor, as
@@ -1107,6 +1137,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
+        const float* dp1 = (dp && l > 0) ? dp + (size_t)l * B : nullptr;             // attention branch (block 0: rate 0, never dropped)
+        const float* dp2 = (dp && l > 0) ? dp + (size_t)(depth + l) * B : nullptr;   // MLP branch
         if (!(share0 && l == 0)) {
             RUN(2, 0, launch_ln_fwd(P, x, W.ln1_w, W.ln1_b, T.xn, L.st1, M, s, c->split16 ? T.xn3 : nullptr, fm & 1));
             {
@@ -1126,6 +1158,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 // the cls rows, their backward) -- the proj GEMM runs on the B gathered cls rows; same k order, same bits for those rows
                 GemmArgs a; a.A = L.attn_o; a.a_map = c->cls_rows; a.W = W.proj_w; a.M = B; a.N = D; a.K = D; a.bias = W.proj_b;
                 a.resid = x; a.out_f32 = L.u; a.scale = 1.0f; a.row_map = c->cls_rows; SPLIT_F(a, W.proj_w3, W.proj_w3b, 1);
+                a.row_scale = dp1;
                 RUN_GEMM(EPI_AD_UP, a);
             } else {
                 GemmArgs a; a.A = L.attn_o; a.W = W.proj_w; a.Wp = W.proj_wp; a.M = M; a.N = D; a.K = D; a.bias = W.proj_b; a.resid = x;
@@ -1133,6 +1166,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 if (save16) { a.out_at = L.u16; a.save16 = true; }
                 if (ao3) SPLIT_READY(a, ao3);
                 if (fold) a.ln_part = L.ln_part;
+                a.row_scale = dp1;
                 RUN_GEMM(EPI_BIAS_RESID, a);
             }
             if (l == 0 && ev_b0_record) DYT_HIP_CHECK(hipEventRecord(ev_b0_record, s));
@@ -1153,7 +1187,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // adapter; the gate gradient <g, mlp(x)> is recovered in tok_bwd by subtracting <g, adapter(x)>, which the adapter's own
         // backward operands give for 128 B per token (TokBwdArgs::cat_*).  The masked mode keeps the two-launch form.
         const bool need_h = save && !complete && !tail;
-        const bool cat = c->fc2_cat && P != 0 && !masked_dense;
+        const bool cat = c->fc2_cat && P != 0 && !masked_dense && !dp2;   // (a scaled MLP branch cannot share its accumulator with the adapter's)
         L.h_has_adapter = cat && need_h;   // the saved "MLP output" of this block then includes the adapter: tok_bwd corrects <g, h>
         FORK(sb);
         {
@@ -1236,6 +1270,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
                 a.bias2 = base + c->off_ub; a.scale = c->cfg.adapter_scale; a.resid = L.u;
             }
+            a.row_scale = dp2;
             if (tail) { a.splitk_ws = (float*)T.dZ; a.splitk_ws_bytes = (size_t)M * DM * c->at; }   // (a backward-pass buffer: idle here)
             RUN_GEMM(EPI_FC2, a);
         }
@@ -1560,6 +1595,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.dtoken_logits = dtoken_logits ? dtoken_logits + (size_t)l * NP : nullptr;
             a.dtok = dtok; a.out_stride = depth * NP; a.training = training; a.tau = c->cfg.tau;
             a.du_at = (P != 0 && !first) ? T.du_at : nullptr; a.partial = S.tok_part[l]; a.M = M; a.write_du = !first;
+            a.branch_scale = (S.dp && l > 0) ? S.dp + (size_t)(depth + l) * B : nullptr;
             if (split_prod && !first) { a.du3 = T.g3; a.du3_scale = c->split_gs; a.du3_hi_only = c->split_bwd_parts == 1; }
             int nblk = 0;
             if (a.du_at) POISON(8, T.du_at, (size_t)M * D * atb);
@@ -1586,6 +1622,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.out_at = T.dO; if (split16) SPLIT_G(a, W.proj_wT3); if (split_prod) SPLIT_READY(a, T.g3);
             POISON(16, T.dO, (size_t)M * D * atb);
             ISO(8, RUN_GEMM(EPI_STORE_AT, a););
+            if (S.dp) RUN(2, 0, launch_scale_rows(P, T.dO, S.dp + (size_t)l * B, M, D, s));   // stochastic depth: the attention branch's factor
             CK("proj_dgrad dO", T.dO, (size_t)M * D * atb);
         }
         POISON(32, T.dqkv, (size_t)M * 3 * D * atb);
@@ -1876,6 +1913,14 @@ extern "C" int dyt_debug_dact(dyt_ctx* c, int slot, int layer, float* out, int* 
     else if (c->prec == DYT_PREC_FP32) DYT_HIP_CHECK(hipMemcpyAsync(out, L.d_act, n * 4, hipMemcpyDeviceToDevice, s));
     else hipLaunchKernelGGL(to_f32_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)L.d_act, out, n);
     DYT_HIP_CHECK(hipGetLastError());
+    return DYT_OK;
+}
+
+extern "C" int dyt_debug_drop_path(dyt_ctx* c, int slot, float* out, void* stream) {
+    if (!c || !out || slot < 0 || slot >= c->cfg.slots) { set_error("bad slot"); return DYT_ERR_ARG; }
+    const Slot& S = c->slots[slot];
+    if (S.batch < 1 || !S.dp) { set_error("slot %d: the last pass ran without stochastic depth", slot); return DYT_ERR_STATE; }
+    DYT_HIP_CHECK(hipMemcpyAsync(out, S.dp, (size_t)2 * c->cfg.depth * S.batch * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return DYT_OK;
 }
 

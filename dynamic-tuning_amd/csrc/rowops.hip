@@ -921,6 +921,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
             DYT_PIN2(cd, cz);
             if (a.maskf[t] != 0.f) dmk -= wave_sum(cd * cz) * a.cat_ddz_scale;   // dropped tokens have dmask = 0 and no saved h
         }
+        const float bs = a.branch_scale ? a.branch_scale[b] : 1.0f;   // stochastic depth on the MLP branch (uniform per image)
+        dmk *= bs;
         if (a.dad) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] += e.v[i] * a.inv_gs;
@@ -930,8 +932,9 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
                 dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
                 TK_ROWPIN(dy);
                 ln_bwd_row(dy, ur, ln2w, st2);
+                const float ds = a.inv_gs * bs;
 #pragma unroll
-                for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i] * a.inv_gs;
+                for (int i = 0; i < 12; ++i) du.v[i] += dy.v[i] * ds;
             }
         }
         if (gate) {
@@ -973,6 +976,45 @@ int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStre
     if (dbg_skip(8)) return 0;
     if (precision == 0) hipLaunchKernelGGL(tok_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(tok_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// stochastic depth (timm DropPath; reference models/vision_transformer_IN21K.py:121,131,148,159 with dpr = linspace(0, rate, depth), :285)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void drop_path_draw_kernel(float* __restrict__ scales, int depth, int batch, float rate, uint64_t seed,
+                                                             const uint64_t* __restrict__ seed_dev, uint64_t subseq_base) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // (branch, l, b)
+    if (i >= 2 * depth * batch) return;
+    const int b = i % batch, l = (i / batch) % depth, branch = i / (batch * depth);
+    const float drop = depth > 1 ? rate * (float)l / (float)(depth - 1) : 0.f;
+    float v = 1.0f;
+    if (drop > 0.f) {
+        const float keep = 1.0f - drop;
+        Philox ph(seed_dev ? *seed_dev : seed, subseq_base + (uint64_t)(2 * l + branch), (uint64_t)b);
+        v = ph.u01(0) < keep ? 1.0f / keep : 0.0f;
+    }
+    scales[i] = v;
+}
+int launch_drop_path_draw(float* scales, int depth, int batch, float rate, uint64_t seed, const uint64_t* seed_dev, uint64_t subseq_base, hipStream_t s) {
+    hipLaunchKernelGGL(drop_path_draw_kernel, dim3((2 * depth * batch + 255) / 256), dim3(256), 0, s, scales, depth, batch, rate, seed, seed_dev, subseq_base);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <class AT>
+__global__ __launch_bounds__(256) void scale_rows_kernel(AT* __restrict__ x, const float* __restrict__ scale, int M, int ld) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;   // 4 consecutive elements of a row (ld % 4 == 0)
+    if (i >= (size_t)M * ld) return;
+    const float sc = scale[(int)(i / ld) / NT];
+    float v[4];
+    load4(x + i, v);
+    store4(x + i, v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+}
+int launch_scale_rows(int precision, void* x, const float* scale, int M, int ld, hipStream_t s) {
+    const unsigned grid = (unsigned)(((size_t)M * ld / 4 + 255) / 256);
+    if (precision == 0) hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, scale, M, ld);
+    else hipLaunchKernelGGL(scale_rows_kernel<bf16>, dim3(grid), dim3(256), 0, s, (bf16*)x, scale, M, ld);
     LAUNCH_CHECK();
     return 0;
 }

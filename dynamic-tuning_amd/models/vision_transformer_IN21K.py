@@ -200,8 +200,11 @@ class VisionTransformer(nn.Module):
                 raise NotImplementedError("%s=%r: the HIP path implements vit_base_patch16_224_in21k (%s=%r)" % (k, got, k, want))
         if max(drop_rate, pos_drop_rate, patch_drop_rate, proj_drop_rate, attn_drop_rate) > 0:
             raise NotImplementedError("dropout rates other than the adapter's are 0 in every reference entry point")
-        if drop_path_rate:
-            raise NotImplementedError("drop_path_rate=%r: train_IN21K.sh / train_vtab.sh run with drop_path 0.0" % drop_path_rate)
+        if not 0.0 <= float(drop_path_rate) < 1.0:
+            raise ValueError("drop_path_rate=%r" % (drop_path_rate,))
+        # stochastic depth (reference :285 dpr = linspace(0, drop_path_rate, depth); :121,131 DropPath(dpr[i]) on both branches of block i,
+        # :148,159): per-image branch factors in the residual epilogues of the proj / fc2 GEMMs, training passes only (dyt_set_drop_path)
+        self.drop_path_rate = float(drop_path_rate)
         assert tuning_config is not None and select_config is not None
         # select_config.open / keep_layers reach the reference's Block only as its `select` argument (:311), which Block.__init__ never
         # reads (:106, :138: every block gets its TokenSelect): they change nothing there, so every value is accepted here as well
@@ -280,6 +283,8 @@ class VisionTransformer(nn.Module):
                             threshold=self.blocks[0].mlp_token_select.threshold, frames=self._frames or 1)
             self._engine = eng
             self._sync_state = None
+        if getattr(eng, "drop_path_rate", 0.0) != self.drop_path_rate:
+            eng.set_drop_path(self.drop_path_rate)
         self._sync(eng)
         return eng
 

@@ -375,6 +375,30 @@ class DyTEngine:
         OPT_COUNT_FLOPS_TOKENS takes the token count n (0 = off) of Block.forward_count_flops."""
         self._ck(self.L.dyt_ctx_set_option(self.h, int(option), int(value)))
 
+    def set_drop_path(self, rate):
+        """Stochastic depth of the training passes (timm DropPath as the reference's blocks use it, models/vision_transformer_IN21K.py:121,131,
+        285: block l drops a sample's attention / MLP branch with probability rate * l / (depth - 1)); 0 = off, the reference scripts' default."""
+        self._ck(self.L.dyt_set_drop_path(self.h, ctypes.c_float(float(rate))))
+        self.drop_path_rate = float(rate)
+        self._graphs = {}
+
+    def debug_drop_path(self, slot, batch):
+        """The stochastic-depth factors [2, depth, batch] the last pass of `slot` ran with (tests)."""
+        out = torch.empty(2, self.depth, batch, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self.L.dyt_debug_drop_path(self.h, int(slot), ptr(out), stream_ptr()))
+        return out
+
+    def set_drop_path_scales(self, slot, scales):
+        """Injected branch factors [2, depth, B] (0 or 1 / keep; [0] attention branch, [1] MLP branch) for the next training passes of `slot`
+        (0 = student, 1 = complete_model pass of step_fwd_bwd) instead of the library's own draws; None restores them.  The tensor is kept alive here."""
+        if not hasattr(self, "_dp_keep"):
+            self._dp_keep = {}
+        if scales is not None:
+            assert scales.is_cuda and scales.dtype == torch.float32 and scales.is_contiguous() and scales.shape[:2] == (2, self.depth)
+        self._dp_keep[slot] = scales
+        self._ck(self.L.dyt_set_drop_path_scales(self.h, int(slot), ptr(scales)))
+
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on):
         self._ck(self.L.dyt_profile_enable(self.h, 1 if on else 0))

@@ -220,6 +220,20 @@ int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 /* the process-wide options (DYT_OPT_ATTN_BWD_FUSED, DYT_OPT_ATTN_V2, DYT_OPT_GEMM_SPLITK) without a context: unit entries such as dyt_attention() see them too */
 int dyt_set_global_option(int option, int value);
 
+/* Stochastic depth -- timm's DropPath as the reference's blocks use it (models/vision_transformer_IN21K.py:121,131 construct it with
+ * dpr[l] = linspace(0, drop_path_rate, depth)[l], :285; :148 x + drop_path1(attn(norm1 x)), :159 drop_path2(mlp(norm2 x));
+ * main_image.py:118,213 --drop_path).  In every TRAINING forward pass (DYT_F_TRAINING) block l > 0 multiplies the attention branch and
+ * the MLP branch of image b by two independent factors: 1 / keep_l with probability keep_l = 1 - rate * l / (depth - 1), else 0
+ * (scale_by_keep); evaluation passes and rate 0 (the default, what every reference script runs) do nothing.  The factors ride in the
+ * residual epilogues of the proj and fc2 GEMMs; the backward pass scales the two branch gradients by the same factors.  Each pass
+ * (student, complete_model) draws its own, from the call's Philox seed (sub-stream 0x10000 + 2 l + branch of the slot).
+ * With a rate > 0 the 16-bit modes run the adapter's up-projection as its own launch again (DYT_OPT_FC2_CAT has no scaled form). */
+int dyt_set_drop_path(dyt_ctx* ctx, float rate);
+/* Tests / reproducibility across frameworks: the factors of the next training passes of `slot` are read from `scales` (device,
+ * [2][depth][batch of the call]: [0] attention branch, [1] MLP branch; row 0 = block 0 is ignored, it is never dropped) instead of being
+ * drawn; the pointer is kept, not copied; null restores the library's own draws. */
+int dyt_set_drop_path_scales(dyt_ctx* ctx, int slot, const float* scales);
+
 /* Copy one FROZEN parameter (fp32, reference state_dict layout) into the context; the library
  * keeps its own copies in the layouts/dtypes its kernels want (incl. transposes for dgrad).
  * Replaces load_state_dict(...) for the frozen keys -- main_image.py:245. */
@@ -333,6 +347,8 @@ int dyt_debug_dispatch(dyt_ctx* ctx, int slot, int layer, int32_t* row_src, int3
 /* Test accessor: the adapter bottleneck relu(down(u)) (x dropout scale) a saved pass holds for `layer`, as fp32 [rows, 64] (64 = the
  * padded rank); *rows_out = B*197, or B when the last block ran in the cls-only tail form.  out: device memory for B*197*64 floats. */
 int dyt_debug_dact(dyt_ctx* ctx, int slot, int layer, float* out, int* rows_out, void* stream);
+/* tests: the stochastic-depth factors [2][depth][batch] the last pass of `slot` ran with (drawn or injected); DYT_ERR_STATE when it ran without */
+int dyt_debug_drop_path(dyt_ctx* ctx, int slot, float* out, void* stream);
 
 /* ---- sub-module entry points: they allocate scratch and synchronise; not for the hot loop ---- */
 /* Adapter.forward (models/dynamic_adapter.py:120-140, layernorm option "none"): out[M,768] = [residual +] scale *

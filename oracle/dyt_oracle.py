@@ -98,9 +98,23 @@ def mlp(sd, p, x):
     return F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
 
 
+def drop_path_scales(keep_draws, rate, depth=DEPTH):
+    """timm==0.9.12 ``drop_path`` (timm/layers/drop.py; not under /root/reference) as the reference's blocks use it: block i holds
+    DropPath(dpr[i]) on each branch with dpr = linspace(0, rate, depth) (models/vision_transformer_IN21K.py:285,121,131; Identity where
+    dpr[i] == 0), and in training mode multiplies the branch by ``bernoulli(keep) / keep`` drawn per SAMPLE (shape [B,1,1], scale_by_keep).
+    ``keep_draws``: [2, depth, B] uniforms in [0,1) standing for the Bernoulli draws (branch 0 = attention, 1 = MLP) -> factors [2, depth, B]."""
+    dpr = torch.linspace(0, rate, depth)
+    keep = (1.0 - dpr).reshape(1, depth, 1)
+    s = (keep_draws < keep).float() / keep
+    s[:, dpr == 0] = 1.0
+    return s
+
+
 def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="masked",
-          tau=5.0, threshold=0.5, drop_p=0.1, count_flops_tokens=0):
+          tau=5.0, threshold=0.5, drop_p=0.1, count_flops_tokens=0, dp1=None, dp2=None):
     """Block.forward, models/vision_transformer_IN21K.py:144-165.
+
+    dp1 / dp2: stochastic-depth factors [B] of this block's attention / MLP branch (drop_path1 :148, drop_path2 :159; None = Identity).
 
     mode="masked":   the reference's training semantics -- MLP on every token, multiplied by
                      the straight-through mask (:159-162).
@@ -111,7 +125,10 @@ def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="ma
                      (forward-only use; same values as "masked").
     """
     p = "blocks.%d." % i
-    x = x + attention(sd, p, layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))  # :148
+    att = attention(sd, p, layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+    if dp1 is not None:
+        att = att * dp1.reshape(-1, 1, 1)
+    x = x + att  # :148
     sel, logits = token_select(sd, p, x, g1, g2, training, tau, threshold)  # :150-152
     adapt = adapter(sd, p, x, scale, keep_mask, drop_p)  # :157
     if count_flops_tokens:  # Block.forward_count_flops :167-185: MLP on the first n tokens, gate result unused
@@ -121,6 +138,8 @@ def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="ma
         return out, sel, logits
     if complete_model or mode != "gather":
         h = mlp(sd, p, layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))  # :159
+        if dp2 is not None:
+            h = h * dp2.reshape(-1, 1, 1)
         if not complete_model:
             if mode == "compact":
                 h = h * sel.detach()
@@ -130,6 +149,7 @@ def block(sd, i, x, g1, g2, keep_mask, scale, complete_model, training, mode="ma
         flat = x.reshape(B * N, C)
         idx = sel.reshape(-1).nonzero()[:, 0]  # model_speed_test.py:300
         hk = mlp(sd, p, layer_norm(flat[idx], sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+        assert dp2 is None
         h = torch.zeros_like(flat)
         h[idx] = hk  # :302-304
         h = h.reshape(B, N, C)
@@ -162,8 +182,10 @@ def attentive_pool(sd, t, frames):
 
 def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=False,
             training=True, mode="masked", tau=5.0, threshold=0.5, drop_p=0.1, depth=DEPTH,
-            return_blocks=False, frames=1, count_flops_tokens=0):
+            return_blocks=False, frames=1, count_flops_tokens=0, drop_scales=None):
     """VisionTransformer.forward, models/vision_transformer_IN21K.py:343-385.
+
+    drop_scales: [2, depth, B] stochastic-depth factors of this pass (drop_path_scales(); training only) or None.
 
     g1, g2: [depth, B, 196] Gumbel draws (None in eval); keep_masks: [depth, B*197, r]
     uint8/bool adapter-dropout keep masks or None.
@@ -181,8 +203,10 @@ def forward(sd, x, g1=None, g2=None, keep_masks=None, scale=0.1, complete_model=
         km = None
         if training and keep_masks is not None:
             km = keep_masks[i].reshape(B, NTOK, -1)
+        ds = drop_scales if (training and drop_scales is not None and i > 0) else None
         t, sel, lg = block(sd, i, t, a, b, km, scale, complete_model, training, mode,
-                           tau, threshold, drop_p, count_flops_tokens)
+                           tau, threshold, drop_p, count_flops_tokens,
+                           None if ds is None else ds[0, i], None if ds is None else ds[1, i])
         sels.append(sel)
         logs.append(lg)
         xs.append(t)
@@ -211,16 +235,18 @@ def ada_loss(logits, token_sel, y, token_target_ratio=0.5, token_loss_ratio=2.0,
 
 def step_loss(sd, x, y, g1, g2, keep_masks, scale=0.1, mode="masked", token_target_ratio=0.5,
               token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0, depth=DEPTH,
-              drop_p=0.1, frames=1):
+              drop_p=0.1, frames=1, drop_scales=None):
     """Loss of one fine-tune step, engine_finetune.py:47-65: student + teacher forward,
+    (drop_scales: [2 passes, 2, depth, B] stochastic-depth factors, each forward call of the reference draws its own; None = drop_path 0)
     KL(student || teacher.detach()), teacher CE, AdaLoss(student)  (video: the identical body of
     train_video_one_epoch, engine_finetune.py:138-155, with frames > 1).
 
     g1/g2: [2, depth, B, 196] (pass 0 = student, 1 = teacher; the teacher pass also draws
     gate noise although its mask is discarded, :152,161); keep_masks [2, depth, B*197, r]."""
     km = (None, None) if keep_masks is None else (keep_masks[0], keep_masks[1])
-    out_s, tok = forward(sd, x, g1[0], g2[0], km[0], scale, False, True, mode, depth=depth, drop_p=drop_p, frames=frames)
-    out_t, _ = forward(sd, x, g1[1], g2[1], km[1], scale, True, True, mode, depth=depth, drop_p=drop_p, frames=frames)
+    dps = (None, None) if drop_scales is None else (drop_scales[0], drop_scales[1])
+    out_s, tok = forward(sd, x, g1[0], g2[0], km[0], scale, False, True, mode, depth=depth, drop_p=drop_p, frames=frames, drop_scales=dps[0])
+    out_t, _ = forward(sd, x, g1[1], g2[1], km[1], scale, True, True, mode, depth=depth, drop_p=drop_p, frames=frames, drop_scales=dps[1])
     kl = F.kl_div(F.log_softmax(out_s, dim=-1), F.log_softmax(out_t.detach(), dim=-1),
                   reduction="batchmean", log_target=True)  # :52-57
     teacher = F.cross_entropy(out_t, y)  # :60

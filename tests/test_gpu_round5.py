@@ -211,3 +211,143 @@ def test_complete_model_attention_of_the_exact_forward_modes_on_the_round5_kerne
     print("%s B=%d teacher logits %.2e, student logits %.2e, gradient (relative norm) %.2e vs the round-4 one-part kernel" % (precision, B, dt, ds, dg))
     assert dt < 1e-4 and dg < 1e-3 and ds == 0.0
     assert torch.isfinite(new[3]).all()
+
+
+# ---- stochastic depth (dyt_set_drop_path; reference models/vision_transformer_IN21K.py:121,131,148,159,285) ----
+def _drop_path_model(g, precision, mode, rate):
+    import gpu_diag as D
+    import synth
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    C, r = int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = synth.make_state_dict(C, r, seed=int(g["meta_seed"]), kind="test", gate_bias=float(g["meta_gate_bias"]))
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar=str(float(g["meta_scale"])), ffn_num=r, d_model=768)
+    m = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=rate, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                   precision=precision, train_mode=mode)
+    m.load_state_dict(sd, strict=True)
+    for n, p in m.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    return m.cuda(), sd
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16", "bf16"])
+def test_drop_path_step_vs_reference_golden_and_oracle(precision):
+    """drop_path_rate = 0.3 with the reference's recorded Bernoulli draws injected (tests/golden/drop_path_step.npz: the REAL reference model
+    stepped through its own train_one_epoch; 31 of the two passes' 88 branch instances dropped): logits, masks, the five loss components and
+    the gradients of a step against the reference's (masked mode) and against the oracle's compact-mode semantics, in the exact mode, the
+    parity mode and both fast modes, at the bounds the drop_path 0 goldens are held to (tests/gpu_diag.py TOL)."""
+    import os
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "drop_path_step.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    scales = torch.from_numpy(g["drop_scales"])
+    tol = D.TOL[precision]
+    for mode in ("masked", "compact"):
+        model, sd = _drop_path_model(g, precision, mode, float(g["meta_rate"]))
+        model.train()
+        eng = model.engine(B, torch.device("cuda", 0))
+        assert eng.drop_path_rate == pytest.approx(0.3)
+        sc = [scales[p].cuda().contiguous() for p in range(2)]
+        eng.set_drop_path_scales(0, sc[0])
+        eng.set_drop_path_scales(1, sc[1])
+        ls, lt = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        ts = torch.zeros(B, 12, 196, device="cuda")
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                  g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+        assert torch.equal(eng.debug_drop_path(0, B).cpu(), scales[0]) and torch.equal(eng.debug_drop_path(1, B).cpu(), scales[1])
+        es = float(np.abs(ls.cpu().numpy() - g["logits_student"]).max())
+        et = float(np.abs(lt.cpu().numpy() - g["logits_teacher"]).max())
+        flips = int((ts.cpu().numpy().astype(np.uint8) != g["token_select"][..., 0]).sum())
+        el = max(abs(float(losses[i]) - float(g["stat_" + k])) / max(1.0, abs(float(g["stat_" + k])))
+                 for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")))
+        if mode == "masked":
+            gref = {n[len("grad/"):]: torch.from_numpy(v) for n, v in g.items() if n.startswith("grad/")}
+        else:
+            _, gref, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=float(g["meta_scale"]), mode="compact", drop_scales=scales)
+        worst = {}
+        items = [(n, eng.trainable_view(n, gr.shape, eng.grad).cpu(), gr) for n, gr in gref.items()]
+        if precision != "fp32":   # the 12 one-number gate bias gradients as one vector (gpu_diag.report_grads)
+            sc1 = [it for it in items if it[2].numel() == 1]
+            items = [it for it in items if it[2].numel() > 1]
+            if sc1:
+                items.append(("mlp_token_select.mlp_head.bias (12 blocks)", torch.stack([a.reshape(()) for _, a, _ in sc1]), torch.stack([b.reshape(()) for _, _, b in sc1])))
+        for n, got, ref in items:
+            e = float((got - ref).norm() / max(float(ref.norm()), 1e-20))
+            k = D.grad_kind(n) if precision in ("fp16", "bf16") else "all"
+            if e > worst.get(k, (0.0, ""))[0]:
+                worst[k] = (e, n)
+        print("drop_path %s/%s: logits %.2e / %.2e, %d of %d decisions differ, losses %.1e, gradients %s" %
+              (precision, mode, es, et, flips, ts.numel(), el, {k: "%.1e" % v[0] for k, v in worst.items()}))
+        assert es <= tol["logits"] and et <= tol["logits"] and flips <= tol["step_flips"] and el <= tol["loss"]
+        for k, (e, n) in worst.items():
+            bound = 2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else
+                                                     (D.FP16_GRAD_TOL_SMALL_B if precision == "fp16" else D.BF16_GRAD_TOL_SMALL_B)[k])
+            assert e <= bound, (mode, k, n, e, bound)
+        eng.set_drop_path_scales(0, None)
+        eng.set_drop_path_scales(1, None)
+        del model, eng
+        torch.cuda.empty_cache()
+
+
+def test_drop_path_library_draws_eval_and_rate_zero():
+    """The library's own draws: factors are 0 or 1 / keep_l with keep_l = 1 - rate l / 11, block 0 never dropped, the two passes and the two
+    branches draw independently, the kept fraction of 2 x 11 x 64 draws per pass is within 4 sigma of its expectation; the same seed gives the same
+    step bit for bit, another seed another; evaluation passes and rate 0 are untouched (bit-identical to a model built without drop_path)."""
+    import synth
+    g = {"meta_num_classes": 10, "meta_ffn_num": 8, "meta_seed": 5, "meta_gate_bias": 0.3, "meta_scale": 1.0}
+    B, rate = 64, 0.4
+    x, y = synth.make_batch(B, 10, seed=61)
+    xd, yd = x.cuda(), y.cuda()
+
+    def step(model, seed):
+        eng = model.engine(B, torch.device("cuda", 0))
+        ls = torch.empty(B, 10, device="cuda")
+        losses = eng.step_fwd_bwd(xd, yd, 0.5, 2.0, 0.0, 0.0, seed=seed, logits_s=ls).clone()
+        torch.cuda.synchronize()
+        return eng, losses.cpu(), ls.cpu(), eng.grad.clone().cpu()
+
+    m, _ = _drop_path_model(g, "fp16", "compact", rate)
+    m.train()
+    eng, l1, s1, g1_ = step(m, 1234)
+    f0, f1 = eng.debug_drop_path(0, B).cpu(), eng.debug_drop_path(1, B).cpu()
+    dpr = torch.linspace(0, rate, 12)
+    for f in (f0, f1):
+        assert bool((f[:, 0] == 1).all())
+        for l in range(1, 12):
+            k = 1.0 - float(dpr[l])
+            v = f[:, l]
+            assert bool(((v == 0) | ((v - 1.0 / k).abs() < 1e-6)).all()), l
+        kept = float((f[:, 1:] > 0).float().mean())
+        want = float((1.0 - dpr[1:]).mean())
+        sigma = float(((dpr[1:] * (1 - dpr[1:])).sum() * 2 * B).sqrt() / (2 * 11 * B))
+        assert abs(kept - want) < 4 * sigma, (kept, want, sigma)
+    assert not torch.equal(f0, f1) and not torch.equal(f0[0], f0[1])
+    _, l2, s2, g2_ = step(m, 1234)
+    assert torch.equal(l1, l2) and torch.equal(s1, s2) and torch.equal(g1_, g2_)
+    _, l3, s3, _ = step(m, 99)
+    assert not torch.equal(s1, s3)
+    # the captured step (hipGraph replay, seed on the device) draws the factors the eager step with the same seed draws
+    eng.step_graph(xd, yd, 0.5, 2.0, 0.0, 0.0, seed=1234)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grad.cpu(), g1_) and torch.equal(eng.debug_drop_path(0, B).cpu(), f0)
+    # evaluation: no stochastic depth; rate 0: the plain model
+    m0, _ = _drop_path_model(g, "fp16", "compact", 0.0)
+    m.eval(); m0.eval()
+    with torch.no_grad():
+        a, _ = m(xd[:8])
+        b, _ = m0(xd[:8])
+    assert torch.equal(a, b)
+    m0.train()
+    e0, p1, q1, r1 = step(m0, 1234)
+    with pytest.raises(Exception):
+        e0.debug_drop_path(0, B)   # that pass ran without
+    m.drop_path_rate = 0.0
+    m.train()
+    _, p2, q2, r2 = step(m, 1234)
+    assert torch.equal(q1, q2) and torch.equal(r1, r2)

@@ -80,8 +80,9 @@ def test_unsupported_configs_are_rejected():
                  ffn_adapter_scalar="0.1", ffn_num=8, d_model=768)
     with pytest.raises(NotImplementedError):
         VisionTransformer(embed_dim=384, num_heads=6, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
-    with pytest.raises(NotImplementedError):
-        VisionTransformer(drop_path_rate=0.1, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
+    with pytest.raises(ValueError):
+        VisionTransformer(drop_path_rate=1.0, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
+    assert VisionTransformer(drop_path_rate=0.1, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0)).drop_path_rate == 0.1   # (round 5: supported)
     from models.dynamic_adapter import Adapter
     with pytest.raises(NotImplementedError):
         Adapter(d_model=768, bottleneck=8, adapter_layernorm_option="in")

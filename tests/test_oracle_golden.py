@@ -249,3 +249,34 @@ def test_chunked_step_grads_equal_step_grads(frames):
         for k in g:
             e = float((g2_[k] - g[k]).norm() / max(float(g[k].norm()), 1e-4))   # floor: norm_k.bias has an exactly-zero true gradient
             assert e < (5e-4 if g[k].numel() == 1 else 5e-5), (chunk, k, e)   # fp32 summation order; the 1-element gate biases are sums of signed terms
+
+
+def test_drop_path_step_vs_reference(golden_dir):
+    """Stochastic depth: the reference model built with drop_path_rate = 0.3, one step through its own train_one_epoch with recorded
+    Bernoulli uniforms (tests/golden/make_golden_drop_path.py; 31 of the 88 branch instances of the two passes dropped) against the
+    oracle's restatement: factors, logits, masks, loss components and all 74 gradients."""
+    g = load(golden_dir, "drop_path_step.npz")
+    B, C, r = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = state(g)
+    x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    keep = synth.make_dropout_masks(B, r, seed=int(g["meta_seed"]) + 3)
+    u = torch.from_numpy(g["drop_uniforms"])
+    scales = torch.stack([O.drop_path_scales(u[p], float(g["meta_rate"])) for p in range(2)])
+    assert torch.equal(scales, torch.from_numpy(g["drop_scales"]))
+    assert int((scales[:, :, 1:] == 0).sum()) >= 6 and bool((scales[:, :, 0] == 1).all())
+    d, grads, outs = O.step_grads(sd, x, y, torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"]), keep, scale=float(g["meta_scale"]),
+                                  mode="masked", drop_scales=scales)
+    assert np.abs(outs[0].detach().numpy() - g["logits_student"]).max() < 2e-5
+    assert np.abs(outs[1].detach().numpy() - g["logits_teacher"]).max() < 2e-5
+    assert np.array_equal(outs[2]["token_select"].detach().numpy().astype(np.uint8), g["token_select"])
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(float(d[k]) - float(g["stat_" + k])) < 1e-5 * max(1.0, abs(float(g["stat_" + k]))), k
+    assert len(grads) == 74
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-9, n
+        if "grad/" + n in g:
+            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-9, n
+    # and it is not the drop_path 0 step: without the factors the student logits move by far more than the tolerance
+    d0, _, outs0 = O.step_grads(sd, x, y, torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"]), keep, scale=float(g["meta_scale"]), mode="masked")
+    assert np.abs(outs0[0].detach().numpy() - g["logits_student"]).max() > 1e-2
