@@ -351,3 +351,59 @@ def test_drop_path_library_draws_eval_and_rate_zero():
     m.train()
     _, p2, q2, r2 = step(m, 1234)
     assert torch.equal(q1, q2) and torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_drop_path_video_model_vs_oracle(precision):
+    """The video model (2 clips x 2 frames: DropPath acts per FRAME there, the trunk sees [(b t), 197, 768],
+    video_models/video_vision_transformer_IN21K.py:437) with injected factors against the oracle: logits, masks, losses, all gradients
+    (trunk + pooling head), compact mode."""
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    from video_models.video_vision_transformer_IN21K import vit_base_patch16_224_in21k
+    clips, frames, C, r, seed, rate = 2, 2, 10, 8, 21, 0.35
+    B = clips * frames
+    sd = synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3, video=True)
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="1.0", ffn_num=r, d_model=768)
+    model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=rate, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                       precision=precision, train_mode="compact")
+    model.load_state_dict(sd, strict=True)
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    model = model.cuda()
+    x, _ = synth.make_batch(B, C, seed=seed)
+    xc = x.reshape(clips, frames, 3, 224, 224).permute(0, 2, 1, 3, 4).contiguous()
+    y = torch.tensor([3, 7])
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = synth.make_noise(B, seed=seed + 1)
+    gen = torch.Generator().manual_seed(seed + 5)
+    scales = torch.stack([O.drop_path_scales(torch.rand(2, 12, B, generator=gen), rate) for _ in range(2)])
+    assert int((scales == 0).sum()) >= 8
+    model.train()
+    model.fold_input(xc)
+    eng = model.engine(B, torch.device("cuda", 0))
+    sc = [scales[p].cuda().contiguous() for p in range(2)]
+    eng.set_drop_path_scales(0, sc[0])
+    eng.set_drop_path_scales(1, sc[1])
+    ls, lt = torch.empty(clips, C, device="cuda"), torch.empty(clips, C, device="cuda")
+    ts = torch.zeros(B, 12, 196, device="cuda")
+    losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(),
+                              keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+    d, gref, outs = O.step_grads(sd, x, y, g1, g2, keep, scale=1.0, mode="compact", frames=frames, drop_scales=scales)
+    es, et = float((ls.cpu() - outs[0]).abs().max()), float((lt.cpu() - outs[1]).abs().max())
+    flips = int((ts.cpu() != outs[2]["token_select"][..., 0]).sum())
+    worst, wn = 0.0, ""
+    for n, gr in gref.items():
+        got = eng.trainable_view(n, tuple(sd[n].shape), eng.grad).cpu()
+        e = float((got - gr).norm() / max(float(gr.norm()), 1e-4 if precision == "fp32" else 3e-4))
+        if gr.numel() > 1 and e > worst:
+            worst, wn = e, n
+    print("drop_path video %s: logits %.2e / %.2e, %d decisions differ, loss %.1e, worst gradient %.1e (%s)" %
+          (precision, es, et, flips, abs(float(losses[0]) - float(d["loss"])), worst, wn))
+    tol = D.TOL[precision]
+    assert es <= tol["vlogits"] and et <= tol["vlogits"] and flips <= tol["vstep_flips"]
+    assert abs(float(losses[0]) - float(d["loss"])) <= tol["vloss"] * max(1.0, abs(float(d["loss"])))
+    assert worst <= (2e-3 if precision == "fp32" else 0.20), (wn, worst)
