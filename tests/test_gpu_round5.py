@@ -230,7 +230,7 @@ def _drop_path_model(g, precision, mode, rate):
     return m.cuda(), sd
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "fp16x3q", "fp16", "bf16"])
 def test_drop_path_step_vs_reference_golden_and_oracle(precision):
     """drop_path_rate = 0.3 with the reference's recorded Bernoulli draws injected (tests/golden/drop_path_step.npz: the REAL reference model
     stepped through its own train_one_epoch; 31 of the two passes' 88 branch instances dropped): logits, masks, the five loss components and
