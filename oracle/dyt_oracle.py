@@ -14,9 +14,10 @@ noise and dropout masks, and commits the results as ``tests/golden/*.npz``;
 The reference itself holds no tests or golden vectors for this path.
 
 Third-party arithmetic restated here because it is not under /root/reference:
-timm==0.9.12 ``PatchEmbed`` (Conv2d k=s=16 + flatten + transpose) and ``Mlp``
-(fc1 -> exact-erf GELU -> fc2), torch ``LayerNorm`` / ``scaled_dot_product_attention`` /
-``AdamW``.  Every function cites the reference file:line it follows (paths relative to
+timm==0.9.12 ``PatchEmbed`` (Conv2d k=s=16 + flatten + transpose), ``Mlp``
+(fc1 -> exact-erf GELU -> fc2) and ``DropPath`` (per-sample Bernoulli / keep, ``drop_path_scales``;
+pinned by tests/golden/drop_path_step.npz = the reference model stepped with drop_path_rate 0.3),
+torch ``LayerNorm`` / ``scaled_dot_product_attention`` / ``AdamW``.  Every function cites the reference file:line it follows (paths relative to
 /root/reference).
 
 Floating point: everything is fp32 on CPU, exactly like the reference's CPU path
