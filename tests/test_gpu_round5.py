@@ -128,12 +128,13 @@ def test_fast_modes_vs_oracle_over_seeds(prec, seed):
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
-@pytest.mark.parametrize("B", [5, 23])
+@pytest.mark.parametrize("B", [5, 23, 130])
 def test_splitk_cls_tail_gemms_agree_with_the_tile_kernels_and_are_reproducible(precision, B):
     """DYT_OPT_GEMM_SPLITK (csrc/gemm_skinny.h): the two K = 3072 GEMMs of the cls-only last block -- fc2 forward with the adapter's operand
     pair, fc1 dgrad -- as 256-wide k slices + a reduce launch that runs the epilogue functor.  Against the same step on the 128x128 tile
     kernels: identical masks, logits / losses / the flat gradient to the rounding of a different fp32 summation order; the split form itself
-    twice: identical bits.  B = 5 and 23 leave partial 32-row groups (rows past the batch are neither read nor stored)."""
+    twice: identical bits.  B = 5 and 23 leave partial 32-row groups (rows past the batch are neither read nor stored); B = 130 takes a second,
+    mostly empty 128-row workgroup row."""
     import _lib
     import synth
     from test_gpu_parity import _bench_model
