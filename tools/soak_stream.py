@@ -1,7 +1,7 @@
 """Soak on CHANGING data: 224 fused fine-tune steps over 32 distinct synthetic batches (B=128: class-dependent
 patterns under N(0,1) noise, so there is something to learn), the same images / labels / Philox seeds in every precision; the loss curves of
 the fp16 (headline) and fp16x3q (parity) modes are compared with the exact-fp32 mode's step for step.
-Run from the repo root on an MI355X: python tools/soak_stream.py [out.json]"""
+Run from the repo root on an MI355X: [DROP_PATH=0.1] [PPRECS=fp32,fp16] python tools/soak_stream.py [out.json]"""
 import json, math, os, sys, time, types
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "dynamic-tuning_amd"))
 import torch
@@ -22,6 +22,7 @@ curves, rates = {}, {}
 for prec in os.environ.get("PPRECS", "fp32,fp16,fp16x3q,bf16").split(","):
     args = types.SimpleNamespace(classes=C, ffn_num=64, precision=prec, batch=B, mode="compact", video_frames=0)
     model = bench.build_model(args, dev)
+    model.drop_path_rate = float(os.environ.get("DROP_PATH", "0"))   # stochastic depth: the same Philox draws in every precision (same seeds)
     bench.calibrate_gates(model, batches[0][0], 0.7)
     opt = FusedAdamW(model, lr=5e-4, weight_decay=0.01)
     opt.growth_interval = 100      # exercise the loss-scale growth path inside the soak (GradScaler default: 2000)
