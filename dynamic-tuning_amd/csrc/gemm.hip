@@ -1372,6 +1372,10 @@ int launch_gemm_raw(const void* A, const void* W, void* C, int M, int N, int K, 
         case 10: return launch_bf16_cfg<256, 256, 2, 4, 0>(a, epi, s);
         case 19: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, epi, s);
         case 30: return run_bf16(a, epi, s);                               // the product dispatch (incl. the split-row scheme)
+        // residual epilogues with the phase timers: C is read as the fp32 residual stream [M,N] (the same bytes as bf16 [2M,N]), updated in place
+        case 21: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiFc2<bf16, true>{nullptr, static_cast<float*>(C), nullptr, nullptr, nullptr, static_cast<const float*>(C), nullptr, 0.f}, s);
+        case 22: return launch_bf16_cfg<128, 128, 2, 2, 9>(a, EpiBiasResid<bf16>{nullptr, static_cast<const float*>(C), static_cast<float*>(C), nullptr, N}, s);
+        case 23: return launch_bf16_cfg<256, 256, 2, 4, 9>(a, EpiBiasResid<bf16>{nullptr, static_cast<const float*>(C), static_cast<float*>(C), nullptr, N}, s);
         case 40: case 41: case 42: {   // C = A2 W2^T + A W^T, A2 [M,64] stored behind A, W2 [N,64] behind W (leading k-tile form)
             a.A2 = static_cast<const bf16*>(A) + (size_t)M * K; a.W2 = static_cast<const bf16*>(W) + (size_t)N * K;
             if (variant == 40) return launch_bf16_cfg<128, 128, 2, 2, 0, EpiStoreAT<bf16>, true>(a, epi, s);

@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-DBG = (9, 19, 79)
+DBG = (9, 19, 79, 21, 22, 23)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dynamic-tuning_amd"))
