@@ -14,8 +14,9 @@ import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdyt_hip.so")
-LIB_PATH_F16 = os.path.join(_HERE, "libdyt_hip_f16.so")   # the same sources with IEEE-half operands (precision "fp16")
+_LIB_DIR = os.environ.get("DYT_LIB_DIR", _HERE)   # development knob: A/B against another build of the two libraries
+LIB_PATH = os.path.join(_LIB_DIR, "libdyt_hip.so")
+LIB_PATH_F16 = os.path.join(_LIB_DIR, "libdyt_hip_f16.so")   # the same sources with IEEE-half operands (precision "fp16")
 
 PREC_FP32, PREC_BF16 = 0, 1
 PREC_FP16 = 2   # host-side name only: libdyt_hip_f16.so with its 16-bit mode (DYT_PREC_BF16 = 1 inside that library)

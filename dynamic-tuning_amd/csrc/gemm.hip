@@ -806,6 +806,9 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
         // single barrier of a stage sits between the two MFMA blocks, and the DMA of stage kt+2 is issued
         // right after it.  Invariant at the top of iteration kt: Fa holds (kt, ks=0); slot kt&1 holds
         // stage kt; slot (kt+1)&1 holds or is receiving stage kt+1.
+        // (Round 5: an L2 prefetch of the stage 2-3 k-tiles ahead -- one global_load_dword per wave into a dead register behind the DMA pieces,
+        // counted vmcnt(1) in front of the barrier -- was built to shorten the launch on operands that are not in the Infinity Cache (112 vs
+        // 79 us, tools/gemm_bench.py COLD=1): cold launches unchanged, step 24.19 vs 24.01 ms same-box.  Not kept)
         bf16x8 faA[TM], fwA[TN], faB[TM], fwB[TN];
         auto read_a = [&](int buf) {   // (stage in `buf`, ks = 0) -> set A
             const char* base = smem + buf * STAGE;
