@@ -26,14 +26,14 @@ PREC_FP16F8 = 6   # host-side name only: PREC_FP16X3H with the forward GEMMs' co
 PREC_FP16X3Q = 7  # host-side name only: PREC_FP16X3H with the attention branch's GEMMs (qkv, proj) in the fp8-correction form, the MLP three-part (DYT_OPT_F32_SPLIT16 = 5)
 PREC_FP16X3 = 3   # host-side name only: libdyt_hip_f16.so in its fp32 mode with DYT_OPT_F32_SPLIT16 (frozen-weight GEMMs as three IEEE-half products)
 F_TRAINING, F_COMPLETE, F_SAVE, F_MASKED_DENSE, F_GATE_ALWAYS, F_ACCUM_GRAD, F_DEVICE_SEED, F_TOKENS_IN, F_TOKENS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
-OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2, OPT_FC2_CAT, OPT_ATTN_BWD_FUSED, OPT_F32_SPLIT16, OPT_ATTN_V2, OPT_GEMM_SPLITK = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_GRAD_SCALE_LOG2, OPT_FC2_CAT, OPT_ATTN_BWD_FUSED, OPT_F32_SPLIT16, OPT_ATTN_V2, OPT_GEMM_SPLITK, OPT_LEARNABLE_SCALE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 # enum dyt_param (include/dyt_hip.h)
 (P_CLS, P_POS, P_PE_W, P_PE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_PROJ_W, P_PROJ_B, P_LN2_W, P_LN2_B,
  P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_NORM_W, P_NORM_B, P_AD_DOWN_W, P_AD_DOWN_B, P_AD_UP_W, P_AD_UP_B,
  P_GATE_W, P_GATE_B, P_HEAD_W, P_HEAD_B,
  P_POOL_QUERY, P_POOL_NQ_W, P_POOL_NQ_B, P_POOL_NK_W, P_POOL_NK_B, P_POOL_NV_W, P_POOL_NV_B, P_POOL_Q_W, P_POOL_K_W,
- P_POOL_V_W, P_POOL_Q_BIAS, P_POOL_V_BIAS, P_POOL_PROJ_W, P_POOL_PROJ_B, P_COUNT) = range(41)
+ P_POOL_V_W, P_POOL_Q_BIAS, P_POOL_V_BIAS, P_POOL_PROJ_W, P_POOL_PROJ_B, P_AD_SCALE, P_COUNT) = range(42)
 
 # reference state_dict key suffix -> param id  
 GLOBAL_KEYS = {
@@ -59,6 +59,7 @@ BLOCK_KEYS = {
     "adaptmlp.down_proj.weight": P_AD_DOWN_W, "adaptmlp.down_proj.bias": P_AD_DOWN_B,
     "adaptmlp.up_proj.weight": P_AD_UP_W, "adaptmlp.up_proj.bias": P_AD_UP_B,
     "mlp_token_select.mlp_head.weight": P_GATE_W, "mlp_token_select.mlp_head.bias": P_GATE_B,
+    "adaptmlp.scale": P_AD_SCALE,   # only with ffn_adapter_scalar == "learnable_scalar"
 }
 
 

@@ -44,28 +44,61 @@ template <class AT>
 __global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t layer_stride, int64_t off_dw, int64_t off_db,
                                      int64_t off_uw, int r, AT* __restrict__ down_w, AT* __restrict__ down_wT,
                                      AT* __restrict__ up_w, AT* __restrict__ up_wT, float* __restrict__ down_b,
-                                     AT* __restrict__ up_ws, float scale) {
+                                     AT* __restrict__ up_ws, float scale, int64_t off_sc, int64_t off_ub, float* __restrict__ up_bp) {
+    // off_sc >= 0 ("learnable_scalar", DYT_OPT_LEARNABLE_SCALE): the up-projection copies and up_bp [depth][768] carry the block's trainable
+    // scale s = flat[off_sc] (W' = s W_up, b' = s b_up), and every kernel downstream runs with scale 1
     const int l = blockIdx.y;
     const float* base = flat + (int64_t)l * layer_stride;
+    const float ls = off_sc >= 0 ? base[off_sc] : 1.0f;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     constexpr int SZ = RP * D;
     if (idx >= SZ) return;
     {   // idx -> (j, c) of [RP,768]
         const int j = idx / D, c = idx - j * D;
         const float dw = j < r ? base[off_dw + (int64_t)j * D + c] : 0.f;   // down_proj.weight [r,768]
-        const float uw = j < r ? base[off_uw + (int64_t)c * r + j] : 0.f;   // up_proj.weight [768,r]
+        const float uw = j < r ? ls * base[off_uw + (int64_t)c * r + j] : 0.f;   // up_proj.weight [768,r]
         down_w[(size_t)l * SZ + idx] = from_f32<AT>(dw);
         up_wT[(size_t)l * SZ + idx] = from_f32<AT>(uw);
     }
     {   // idx -> (c, j) of [768,RP]
         const int c = idx / RP, j = idx - c * RP;
         const float dw = j < r ? base[off_dw + (int64_t)j * D + c] : 0.f;
-        const float uw = j < r ? base[off_uw + (int64_t)c * r + j] : 0.f;
+        const float uw = j < r ? ls * base[off_uw + (int64_t)c * r + j] : 0.f;
         down_wT[(size_t)l * SZ + idx] = from_f32<AT>(dw);
         up_w[(size_t)l * SZ + idx] = from_f32<AT>(uw);
         if (up_ws) up_ws[(size_t)l * SZ + idx] = from_f32<AT>(scale * uw);
     }
     if (idx < RP) down_b[l * RP + idx] = idx < r ? base[off_db + idx] : 0.f;
+    if (up_bp && idx < D) up_bp[l * D + idx] = ls * base[off_ub + idx];
+}
+
+// "learnable_scalar": the backward has left G' = dL/dW', gb' = dL/db' of the PRIMED up-projection (W' = s W_up, b' = s b_up) of every block
+// in scr (the slot's scratch, flat layout); chain rule into the gradient buffer: dW_up += s G', db_up += s gb', ds += <G', W_up> + <gb', b_up>.
+// One workgroup per block, fixed reduction order.
+__global__ __launch_bounds__(256) void learn_scale_fixup_kernel(const float* __restrict__ scr, const float* __restrict__ flat, float* __restrict__ grad,
+                                                                int64_t layer_stride, int64_t off_uw, int64_t off_ub, int64_t off_sc, int r, int l0) {
+    __shared__ float red[256];
+    const int l = l0 + blockIdx.x, tid = threadIdx.x;
+    const int64_t b = (int64_t)l * layer_stride;
+    const float ls = flat[b + off_sc];
+    float dot = 0.f;
+    for (int i = tid; i < D * r; i += 256) {
+        const float g = scr[b + off_uw + i];
+        dot = fmaf(g, flat[b + off_uw + i], dot);
+        grad[b + off_uw + i] += ls * g;
+    }
+    for (int i = tid; i < D; i += 256) {
+        const float g = scr[b + off_ub + i];
+        dot = fmaf(g, flat[b + off_ub + i], dot);
+        grad[b + off_ub + i] += ls * g;
+    }
+    red[tid] = dot;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) grad[b + off_sc] += red[0];
 }
 
 template <class AT>
@@ -169,6 +202,7 @@ struct Slot {
     // stochastic depth (dyt_set_drop_path): the per-image branch factors [2][depth][batch] of this slot's passes -- drawn by the library
     // into dp_own at every training forward, or the caller's (dp_inject, dyt_set_drop_path_scales); dp = what the SAVED pass used (null: none)
     float* dp_own = nullptr; const float* dp_inject = nullptr; const float* dp = nullptr;
+    float* gscr = nullptr;   // DYT_OPT_LEARNABLE_SCALE: [depth * layer_stride] the backward's up-projection gradients before the chain rule through the scale
 };
 struct ProfRec { int cat; double flops; hipEvent_t a, b; const int* m_dev; int M; };
 
@@ -238,6 +272,10 @@ struct dyt_ctx {
     bool ov_pass = true, ov_branch = false;  // student / teacher passes on two streams; adapter branch on its own stream
     bool ov_bwd_serial = false;          // the teacher's backward starts after the student's (bit-reproducible schedule)
     bool share_block0 = true;  // step: the teacher pass reuses the student's embedding + block-0 attention branch
+    bool learn_scale = false;    // DYT_OPT_LEARNABLE_SCALE: tuning_config.ffn_adapter_scalar == "learnable_scalar" (dynamic_adapter.py:101-102): the scale is
+                                 // the trainable word off_sc of every block (a padding slot of the flat layout behind the gate bias)
+    int64_t off_sc = 0;
+    float* ad_up_bp = nullptr;   // [depth][768] s * up_proj.bias (prep_adapters_kernel)
     float drop_path_rate = 0.f;  // timm DropPath rate of the LAST block (block l: rate * l / (depth - 1)); training forward passes only
     int count_flops_tokens = 0;  // > 0: Block.forward_count_flops -- MLP on the first n tokens of every image
     // profiling
@@ -371,6 +409,7 @@ static void layout(dyt_ctx* c, bool dry) {
         T.wg_partial2 = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
         Slot& S = c->slots[sl];
         S.dp_own = carve<float>(c, 2 * depth * B, dry);
+        S.gscr = carve<float>(c, (size_t)depth * c->layer_stride, dry);
         S.wg_part.resize(depth); S.wg_part2.resize(depth); S.tok_part.resize(depth);
         for (size_t l = 0; l < depth; ++l) {
             S.wg_part[l] = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
@@ -379,6 +418,7 @@ static void layout(dyt_ctx* c, bool dry) {
         }
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
+    c->ad_up_bp = carve<float>(c, depth * D, dry);
     c->cls_rows = carve<int>(c, B, dry);
     c->seed_dev = carve<uint64_t>(c, 2, dry);
     c->clip_scratch = carve<float>(c, 256, dry);
@@ -486,7 +526,7 @@ static void trainable_layout(dyt_ctx* c) {
     c->off_uw = o; o = a4(o + (int64_t)D * r);
     c->off_ub = o; o = a4(o + D);
     c->off_gw = o; o += D;       // gate weight and bias stay adjacent (one 769-wide reduction)
-    c->off_gb = o; o = a4(o + 1);
+    c->off_gb = o; c->off_sc = o + 1; o = a4(o + 2);   // + the adapter's learnable scale (used under DYT_OPT_LEARNABLE_SCALE; a zero padding word otherwise)
     c->layer_stride = o;
     o = c->layer_stride * c->cfg.depth;
     c->off_hw = o; o = a4(o + C * D);
@@ -618,6 +658,9 @@ extern "C" int dyt_trainable_offset(const dyt_ctx* c, int param, int layer, int6
         case DYT_P_AD_UP_B: *off = base + c->off_ub; *numel = D; break;
         case DYT_P_GATE_W: *off = base + c->off_gw; *numel = D; break;
         case DYT_P_GATE_B: *off = base + c->off_gb; *numel = 1; break;
+        case DYT_P_AD_SCALE:
+            if (layer < 0 || layer >= c->cfg.depth) { set_error("layer %d out of range", layer); return DYT_ERR_ARG; }
+            *off = base + c->off_sc; *numel = 1; break;
         case DYT_P_HEAD_W: *off = c->off_hw; *numel = C * D; break;
         case DYT_P_HEAD_B: *off = c->off_hb; *numel = C; break;
         case DYT_P_POOL_QUERY: case DYT_P_POOL_NQ_W: case DYT_P_POOL_NQ_B: case DYT_P_POOL_NK_W: case DYT_P_POOL_NK_B:
@@ -858,6 +901,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_ATTN_BWD_FUSED: set_attn_bwd_fused(value); return DYT_OK;   // process-wide
         case DYT_OPT_ATTN_V2: set_attn_v2(value & 3); return DYT_OK;             // process-wide
         case DYT_OPT_GEMM_SPLITK: set_gemm_splitk(value); return DYT_OK;         // process-wide
+        case DYT_OPT_LEARNABLE_SCALE: c->learn_scale = value != 0; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
             c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
@@ -926,20 +970,21 @@ extern "C" int dyt_profile_read(dyt_ctx* c, int category, double* ms, int64_t* l
 // ------------------------------------------------------------------------------------------
 static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     const dim3 grid((RP * D + 255) / 256, c->cfg.depth);
+    const int64_t sc_off = c->learn_scale ? c->off_sc : -1;
     if (c->prec == 0) {
         hipLaunchKernelGGL(prep_adapters_kernel<float>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (float*)c->ad_down_w, (float*)c->ad_down_wT, (float*)c->ad_up_w,
-                           (float*)c->ad_up_wT, c->ad_down_b, (float*)nullptr, 0.f);
+                           (float*)c->ad_up_wT, c->ad_down_b, (float*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
         if (c->bwd16) {   // + the 16-bit transposes the 16-bit backward's adapter dgrads multiply by
             bf16* scr = (bf16*)c->ad_scratch16;
             hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                                c->off_uw, c->cfg.ffn_num, scr, (bf16*)c->ad_down_wT16, scr + (size_t)c->cfg.depth * RP * D,
-                               (bf16*)c->ad_up_wT16, c->ad_down_b, (bf16*)nullptr, 0.f);
+                               (bf16*)c->ad_up_wT16, c->ad_down_b, (bf16*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
         }
     } else
         hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (bf16*)c->ad_down_w, (bf16*)c->ad_down_wT, (bf16*)c->ad_up_w,
-                           (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)nullptr, 0.f);
+                           (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1137,6 +1182,9 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* x = S.xs[l];
         float* xo = S.xs[l + 1];
+        // learnable scale: the up-projection copies / up_bp are already multiplied by it (prep_adapters_kernel)
+        const float ad_scale = c->learn_scale ? 1.0f : c->cfg.adapter_scale;
+        const float* up_bias = c->learn_scale ? c->ad_up_bp + (size_t)l * D : base + c->off_ub;
         const float* dp1 = (dp && l > 0) ? dp + (size_t)l * B : nullptr;             // attention branch (block 0: rate 0, never dropped)
         const float* dp2 = (dp && l > 0) ? dp + (size_t)(depth + l) * B : nullptr;   // MLP branch
         if (!(share0 && l == 0)) {
@@ -1197,12 +1245,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
             a.row_map = tail ? c->cls_rows : nullptr;
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1); a.seed_dev = seed_dev;
-            if (cat) { a.out_at2 = T.dact_s; a.scale = c->cfg.adapter_scale; }
+            if (cat) { a.out_at2 = T.dact_s; a.scale = ad_scale; }
             if (save16) { a.out_at2 = L.dact16; a.scale = 1.0f; a.save16 = true; }
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
         GemmArgs up; up.A = L.d_act; up.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); up.M = Mr; up.N = D; up.K = RP;
-        up.bias = base + c->off_ub; up.resid = L.u; up.out_f32 = xo; up.scale = c->cfg.adapter_scale;
+        up.bias = up_bias; up.resid = L.u; up.out_f32 = xo; up.scale = ad_scale;
         up.row_map = tail ? c->cls_rows : nullptr;
         if (!cat) RUN_ON(sb, 0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
         int* counts = S.counts + (size_t)l * B;
@@ -1268,7 +1316,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             if (cat) {
                 a.A2 = T.dact_s; a.W2 = at_off(c, c->ad_up_w, (size_t)l * RP * D);   // [s d_act | h] x [W_up | W2]^T
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)
-                a.bias2 = base + c->off_ub; a.scale = c->cfg.adapter_scale; a.resid = L.u;
+                a.bias2 = up_bias; a.scale = ad_scale; a.resid = L.u;
             }
             a.row_scale = dp2;
             if (tail) { a.splitk_ws = (float*)T.dZ; a.splitk_ws_bytes = (size_t)M * DM * c->at; }   // (a backward-pass buffer: idle here)
@@ -1466,7 +1514,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     const bool student = !complete;
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const float scale = c->cfg.adapter_scale;
+    const float scale = c->learn_scale ? 1.0f : c->cfg.adapter_scale;   // (learnable: the dgrad matrices carry it, the weight gradients get it in learn_scale_fixup_kernel)
+    if (c->learn_scale) DYT_HIP_CHECK(hipMemsetAsync(S.gscr, 0, (size_t)depth * c->layer_stride * sizeof(float), s));
     const float gs = P == 0 ? 1.0f : c->gs, inv_gs = 1.0f / gs;   // 16-bit gradient operands carry gs (dyt_ctx: gs)
     float* g = T.g;
     hipStream_t sb = nullptr;
@@ -1483,6 +1532,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         { const int l = depth; CK("head_bwd g", cls_tail ? S.gcls : g, (size_t)(cls_tail ? B : M) * D * 4); CK("head_bwd dW", grad + c->off_hw, (size_t)c->cfg.num_classes * D * 4); }
     }
 
+    int fix_hi = depth;   // learnable scale: blocks [0, fix_hi) still await learn_scale_fixup_kernel
     ReduceQueue rq;   // adapter weight-gradient / gate-gradient reductions: queued per block, flushed where the gradients must be final
     bool prepped = false;  // the previous iteration's ln_bwd already produced g_at / dmask for this block
     bool g3_ready = false; // ... and (fp32 split form) T.g3 = g as the 16-bit split operand of this block's GELU' dgrad
@@ -1492,6 +1542,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         LayerS& L = S.L[l];
         const float* base = trainable + (int64_t)l * c->layer_stride;
         float* gbase = grad + (int64_t)l * c->layer_stride;
+        float* ubase = c->learn_scale ? S.gscr + (int64_t)l * c->layer_stride : gbase;   // where the up-projection's weight / bias gradients go
         const bool first = l == 0;
         // saved tensors / dgrad matrices in this backward's operand type
         const void* Lh = b16 ? L.h16 : L.h; const void* Ldact = b16 ? L.dact16 : L.d_act; const void* Lz = b16 ? L.z16 : L.z;
@@ -1532,8 +1583,8 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             WgradArgs w[2];
             WgradArgs& a = w[0];
             a.X = A_g; a.Y = Ldact; a.M = Mr; a.r = r; a.partial = S.wg_part[l];
-            a.out_w = gbase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale * inv_gs;       // up_proj.weight [768, r]  (X = g_at carries gs)
-            a.out_xsum = gbase + c->off_ub; a.alpha_x = scale * inv_gs;                      // up_proj.bias
+            a.out_w = ubase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale * inv_gs;       // up_proj.weight [768, r]  (X = g_at carries gs)
+            a.out_xsum = ubase + c->off_ub; a.alpha_x = scale * inv_gs;                      // up_proj.bias
             WgradArgs& b = w[1];
             b.X = tail ? ucls : Luat; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = S.wg_part2[l];
             b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = inv_gs;      // down_proj.weight [r, 768]  (Y = ddz carries gs)
@@ -1609,6 +1660,11 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             if (student) CK("tok_bwd gate grad", gbase + c->off_gw, (size_t)(D + 1) * 4);
         }
         if (l == split || first || dbg_ck_on()) RUN(2, 0, flush_reductions(rq, s));   // the gradients of blocks >= l are final after this
+        if (c->learn_scale && ev_split && l == split && l > 0) {   // the upper blocks' up-projection / scale gradients must be final before the event as well
+            hipLaunchKernelGGL(learn_scale_fixup_kernel, dim3(fix_hi - l), dim3(256), 0, s, S.gscr, trainable, grad, c->layer_stride, c->off_uw, c->off_ub, c->off_sc, r, l);
+            DYT_HIP_CHECK(hipGetLastError());
+            fix_hi = l;
+        }
         if (ev_split && l == split) {
             // video model: the pooling head's k / v weight gradients (side stream, part 0 of the flat buffer) must be final
             // before the "upper gradients are final" event that the gradient sum and the early all-reduce wait for
@@ -1650,6 +1706,10 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         }
     }
     if (S.pool.wpending) { DYT_HIP_CHECK(hipStreamWaitEvent(s, S.pool.ev_wj, 0)); S.pool.wpending = false; }
+    if (c->learn_scale && fix_hi > 0) {
+        hipLaunchKernelGGL(learn_scale_fixup_kernel, dim3(fix_hi), dim3(256), 0, s, S.gscr, trainable, grad, c->layer_stride, c->off_uw, c->off_ub, c->off_sc, r, 0);
+        DYT_HIP_CHECK(hipGetLastError());
+    }
     return DYT_OK;
 }
 

@@ -106,9 +106,10 @@ class Adapter(nn.Module):
             raise NotImplementedError("adapter_layernorm_option=%r: the reference's entry points only use 'none' "
                                       "(main_image.py:190, main_vtab.py:183)" % adapter_layernorm_option)
         self.adapter_layer_norm_before = None
-        if adapter_scalar == "learnable_scalar":
-            raise NotImplementedError("learnable_scalar: the reference's entry points use a fixed scalar")
-        self.scale = float(adapter_scalar)
+        if adapter_scalar == "learnable_scalar":   # reference :101-102: trainable (the freeze rule keeps every "adaptmlp." tensor), DYT_OPT_LEARNABLE_SCALE
+            self.scale = nn.Parameter(torch.ones(1))
+        else:
+            self.scale = float(adapter_scalar)
         self.down_proj = _LinearParams(self.n_embd, self.down_size)
         self.up_proj = _LinearParams(self.down_size, self.n_embd)
         self.dropout = dropout

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from _lib import (Config, DyTError, F_ACCUM_GRAD, F_COMPLETE, F_DEVICE_SEED, F_GATE_ALWAYS, F_MASKED_DENSE, F_SAVE, F_TOKENS_IN, F_TOKENS_OUT,
-                  F_TRAINING, OPT_F32_SPLIT16, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16F8, PREC_FP16X3F, PREC_FP16X3H, PREC_FP16X3Q, PREC_FP32,
+                  F_TRAINING, OPT_F32_SPLIT16, OPT_LEARNABLE_SCALE, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16F8, PREC_FP16X3F, PREC_FP16X3H, PREC_FP16X3Q, PREC_FP32,
                   check, is_trainable_param, key_to_param, lib, ptr, stream_ptr)
 
 NP, NT, DIM = 196, 197, 768
@@ -53,9 +53,12 @@ class DyTEngine:
         # "fp16f8" = "fp16x3h" with the two correction products of every forward GEMM on the fp8 matrix cores (not bit-identical to fp16x3)
         split = {PREC_FP16X3: 1, PREC_FP16X3F: 2, PREC_FP16X3H: 3, PREC_FP16F8: 4, PREC_FP16X3Q: 5}.get(self.precision, 0)
         lib_prec = PREC_BF16 if self.precision == PREC_FP16 else (PREC_FP32 if split else self.precision)
+        # adapter_scale: tuning_config.ffn_adapter_scalar as a number, or -- "learnable_scalar" -- the block's nn.Parameter: the scale is then
+        # the trainable word DYT_P_AD_SCALE of every block (key blocks.i.adaptmlp.scale), DYT_OPT_LEARNABLE_SCALE
+        self.learnable_scale = isinstance(adapter_scale, torch.Tensor)
         self.cfg = Config(int(num_classes), int(ffn_num), int(depth), lib_prec,
-                          int(max_batch), int(slots), float(adapter_scale), float(adapter_dropout), float(tau), float(threshold),
-                          int(frames))
+                          int(max_batch), int(slots), 1.0 if self.learnable_scale else float(adapter_scale), float(adapter_dropout), float(tau),
+                          float(threshold), int(frames))
         self.frames = max(1, int(frames))   # > 1: video model, every batch is clips * frames images
         self.L = lib(fp16=self.precision == PREC_FP16 or split != 0)
         h = ctypes.c_void_p()
@@ -65,6 +68,8 @@ class DyTEngine:
         if split:
             with torch.cuda.device(self.device):
                 self._ck(self.L.dyt_ctx_set_option(self.h, OPT_F32_SPLIT16, split))
+        if self.learnable_scale:
+            self._ck(self.L.dyt_ctx_set_option(self.h, OPT_LEARNABLE_SCALE, 1))
         n = ctypes.c_int64()
         self._ck(self.L.dyt_trainable_numel(self.h, ctypes.byref(n)))
         self.n_train = n.value

@@ -131,6 +131,15 @@ def make_state_dict(num_classes=100, ffn_num=64, seed=0, kind="test", depth=DEPT
     return sd
 
 
+def add_learnable_scales(sd, seed=0, depth=DEPTH):
+    """``blocks.i.adaptmlp.scale`` [1] for ``ffn_adapter_scalar == "learnable_scalar"`` (reference init 1.0; here distinct values in
+    0.4 .. 1.6 so that a wrong block or a missing factor shows)."""
+    g = torch.Generator().manual_seed(9000 + seed)
+    for i in range(depth):
+        sd["blocks.%d.adaptmlp.scale" % i] = 0.4 + 1.2 * torch.rand(1, generator=g)
+    return sd
+
+
 def make_batch(batch, num_classes=100, seed=0):
     """Images ``N(0,1)`` [B,3,224,224] fp32 and int64 targets."""
     x = _normal("images", (batch, 3, 224, 224), seed, 1.0)

@@ -96,6 +96,7 @@ enum dyt_param {
     DYT_P_POOL_Q_W, DYT_P_POOL_K_W, DYT_P_POOL_V_W,   /* T attentive_blocks.cross_attn.{q,k,v}.weight [768,768] */
     DYT_P_POOL_Q_BIAS, DYT_P_POOL_V_BIAS,             /* T attentive_blocks.cross_attn.{q_bias,v_bias} [768] */
     DYT_P_POOL_PROJ_W, DYT_P_POOL_PROJ_B,             /* T attentive_blocks.cross_attn.proj [768,768] */
+    DYT_P_AD_SCALE,     /* T blocks.i.adaptmlp.scale [1] -- only with tuning_config.ffn_adapter_scalar == "learnable_scalar" (DYT_OPT_LEARNABLE_SCALE) */
     DYT_P_COUNT
 };
 
@@ -216,6 +217,14 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           128x128 (csrc/gemm_skinny.h).  Slices are summed in a fixed order: deterministic; agrees with the tile kernels to
  *                           fp32 rounding of the k sums, not bit for bit.  PROCESS-wide. */
 #define DYT_OPT_GEMM_SPLITK 10
+/*   DYT_OPT_LEARNABLE_SCALE     default 0.  1: tuning_config.ffn_adapter_scalar == "learnable_scalar" (models/dynamic_adapter.py:101-102, 138: the
+ *                           adapter output is multiplied by a trainable nn.Parameter(torch.ones(1)) per block instead of a constant).  The
+ *                           parameter is DYT_P_AD_SCALE of the flat buffer (one word per block, behind the gate bias; set it like any
+ *                           trainable tensor), dyt_config.adapter_scale is ignored.  The per-step adapter copies carry the scale
+ *                           (W' = s W_up, b' = s b_up), so every kernel runs as with scale 1; the backward leaves dL/dW', dL/db' in a
+ *                           scratch buffer and one small kernel applies the chain rule: dW_up = s dW', db_up = s db',
+ *                           ds = <dW', W_up> + <db', b_up>.  Set before the first forward pass. */
+#define DYT_OPT_LEARNABLE_SCALE 11
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 /* the process-wide options (DYT_OPT_ATTN_BWD_FUSED, DYT_OPT_ATTN_V2, DYT_OPT_GEMM_SPLITK) without a context: unit entries such as dyt_attention() see them too */
 int dyt_set_global_option(int option, int value);

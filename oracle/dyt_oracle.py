@@ -90,6 +90,8 @@ def adapter(sd, p, x, scale, keep_mask=None, drop_p=0.1):
     if keep_mask is not None:
         down = down * keep_mask.to(down.dtype) * (1.0 / (1.0 - drop_p))
     up = F.linear(down, sd[p + "adaptmlp.up_proj.weight"], sd[p + "adaptmlp.up_proj.bias"])
+    if p + "adaptmlp.scale" in sd:   # adapter_scalar == "learnable_scalar": nn.Parameter(torch.ones(1)), :101-102 (trainable: an "adaptmlp." tensor)
+        scale = sd[p + "adaptmlp.scale"]
     return up * scale  # :130
 
 

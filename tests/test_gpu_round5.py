@@ -408,3 +408,134 @@ def test_drop_path_video_model_vs_oracle(precision):
     assert es <= tol["vlogits"] and et <= tol["vlogits"] and flips <= tol["vstep_flips"]
     assert abs(float(losses[0]) - float(d["loss"])) <= tol["vloss"] * max(1.0, abs(float(d["loss"])))
     assert worst <= (2e-3 if precision == "fp32" else 0.20), (wn, worst)
+
+
+# ---- tuning_config.ffn_adapter_scalar = "learnable_scalar" (DYT_OPT_LEARNABLE_SCALE; reference models/dynamic_adapter.py:101-102,138) ----
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16", "bf16"])
+def test_learnable_scalar_step_vs_reference_golden(precision):
+    """The reference model with a trainable adapter scale per block, stepped through its own train_one_epoch
+    (tests/golden/learnable_scalar_step.npz, twelve distinct scales): logits, masks, losses and all 86 gradients -- the twelve d(scale)
+    included -- of the fused step, masked mode against the reference's values and compact mode against the oracle's; fp32 also the
+    parameters after one AdamW update (the scales are ordinary words of the flat buffer)."""
+    import os
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "learnable_scalar_step.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    sd = synth.add_learnable_scales(synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3), seed=seed)
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="learnable_scalar", ffn_num=r, d_model=768)
+    tol = D.TOL[precision]
+    for mode in ("masked", "compact"):
+        model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                           precision=precision, train_mode=mode)
+        msg = model.load_state_dict(sd, strict=True)
+        for n, p in model.named_parameters():
+            p.requires_grad = synth.is_trainable(n)
+        model = model.cuda()
+        assert sum(p.requires_grad for p in model.parameters()) == 86
+        model.train()
+        eng = model.engine(B, torch.device("cuda", 0))
+        assert eng.learnable_scale
+        ls, lt = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        ts = torch.zeros(B, 12, 196, device="cuda")
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                  g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+        es = float(np.abs(ls.cpu().numpy() - g["logits_student"]).max())
+        et = float(np.abs(lt.cpu().numpy() - g["logits_teacher"]).max())
+        flips = int((ts.cpu().numpy().astype(np.uint8) != g["token_select"][..., 0]).sum())
+        el = max(abs(float(losses[i]) - float(g["stat_" + k])) / max(1.0, abs(float(g["stat_" + k])))
+                 for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")))
+        if mode == "masked":
+            gref = {n[len("grad/"):]: torch.from_numpy(v) for n, v in g.items() if n.startswith("grad/")}
+        else:
+            _, gref, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=float("nan"), mode="compact")
+        items = [(n, eng.trainable_view(n, gr.shape, eng.grad).cpu(), gr) for n, gr in gref.items()]
+        sc = [it for it in items if it[0].endswith("adaptmlp.scale")]
+        assert len(sc) == 12
+        gs_got, gs_ref = torch.stack([a.reshape(()) for _, a, _ in sc]), torch.stack([b.reshape(()) for _, _, b in sc])
+        e_scale = float((gs_got - gs_ref).norm() / gs_ref.norm())
+        items = [it for it in items if not it[0].endswith("adaptmlp.scale")]
+        if precision != "fp32":
+            sc1 = [it for it in items if it[2].numel() == 1]
+            items = [it for it in items if it[2].numel() > 1]
+            if sc1:
+                items.append(("mlp_token_select.mlp_head.bias (12 blocks)", torch.stack([a.reshape(()) for _, a, _ in sc1]), torch.stack([b.reshape(()) for _, _, b in sc1])))
+        worst = {}
+        for n, got, ref in items:
+            e = float((got - ref).norm() / max(float(ref.norm()), 1e-20))
+            k = D.grad_kind(n) if precision in ("fp16", "bf16") else "all"
+            if e > worst.get(k, (0.0, ""))[0]:
+                worst[k] = (e, n)
+        print("learnable_scalar %s/%s: logits %.2e / %.2e, %d decisions differ, losses %.1e, d(scale) x12 %.1e, gradients %s" %
+              (precision, mode, es, et, flips, el, e_scale, {k: "%.1e" % v[0] for k, v in worst.items()}))
+        assert es <= tol["logits"] and et <= tol["logits"] and flips <= tol["step_flips"] and el <= tol["loss"]
+        assert e_scale <= (2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else (0.02 if precision == "fp16" else 0.10)))
+        for k, (e, n) in worst.items():
+            bound = 2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else
+                                                     (D.FP16_GRAD_TOL_SMALL_B if precision == "fp16" else D.BF16_GRAD_TOL_SMALL_B)[k])
+            assert e <= bound, (mode, k, n, e, bound)
+        if precision == "fp32" and mode == "masked":
+            D.D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
+            for key in g:
+                if key.startswith("param_after/"):
+                    n = key.split("/", 1)[1]
+                    got = eng.trainable_view(n, g[key].shape).cpu().numpy()
+                    assert np.abs(got - g[key]).max() < 2e-5, n
+        del model, eng
+        torch.cuda.empty_cache()
+
+
+def test_learnable_scalar_gradient_accumulation_and_default_layout():
+    """The up-projection / scale gradients go through a scratch buffer and a chain-rule kernel; with accumulate=True they must ADD to what
+    the gradient buffer holds (micro-batches), exactly like every other tensor.  And the scale lives in a padding word of the flat layout:
+    a model with a fixed scalar has the same number of trainable words and never touches that word."""
+    import gpu_diag as D
+    import synth
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    B, C, r, seed = 3, 10, 8, 13
+
+    def build(scalar):
+        tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                       ffn_adapter_scalar=scalar, ffn_num=r, d_model=768)
+        m = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                       precision="fp32", train_mode="compact")
+        sd = synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3)
+        if scalar == "learnable_scalar":
+            synth.add_learnable_scales(sd, seed=seed)
+        m.load_state_dict(sd, strict=True)
+        for n, p in m.named_parameters():
+            p.requires_grad = synth.is_trainable(n)
+        return m.cuda().train()
+
+    m = build("learnable_scalar")
+    eng = m.engine(B, torch.device("cuda", 0))
+    batches = []
+    for i in range(2):
+        x, y = synth.make_batch(B, C, seed=seed + i)
+        g1, g2 = synth.make_noise(B, seed=seed + 10 + i)
+        batches.append((x.cuda(), y.cuda(), g1.cuda().contiguous(), g2.cuda().contiguous(), synth.make_dropout_masks(B, r, seed=seed + 20 + i).cuda().contiguous()))
+    single = []
+    for x, y, g1, g2, km in batches:
+        eng.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, g1=g1, g2=g2, keep_mask=km)
+        single.append(eng.grad.clone())
+    x, y, g1, g2, km = batches[0]
+    eng.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, g1=g1, g2=g2, keep_mask=km)
+    x, y, g1, g2, km = batches[1]
+    eng.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, g1=g1, g2=g2, keep_mask=km, accumulate=True)
+    want = single[0] + single[1]
+    assert float((eng.grad - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    off, num = eng.trainable_slice("blocks.5.adaptmlp.scale")
+    assert num == 1 and float(single[0][off].abs()) > 0
+    m0 = build("0.7")
+    e0 = m0.engine(B, torch.device("cuda", 0))
+    assert e0.n_train == eng.n_train and not e0.learnable_scale
+    x, y, g1, g2, km = batches[0]
+    e0.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, g1=g1, g2=g2, keep_mask=km)
+    assert float(e0.grad[off]) == 0.0 and float(e0.flat[off]) == 0.0

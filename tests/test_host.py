@@ -107,7 +107,10 @@ def test_key_mapping_covers_state_dict():
         pid, layer = _lib.key_to_param(k)
         assert _lib.is_trainable_param(pid) == synth.is_trainable(k)
         seen.add(pid)
-    assert seen == set(range(_lib.P_COUNT))
+    assert seen == set(range(_lib.P_AD_SCALE))
+    # "learnable_scalar": one more trainable word per block
+    pid, layer = _lib.key_to_param("blocks.7.adaptmlp.scale")
+    assert pid == _lib.P_AD_SCALE == _lib.P_COUNT - 1 and layer == 7 and _lib.is_trainable_param(pid) and synth.is_trainable("blocks.7.adaptmlp.scale")
 
 
 def test_video_module_parameter_surface():

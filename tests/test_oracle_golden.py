@@ -280,3 +280,25 @@ def test_drop_path_step_vs_reference(golden_dir):
     # and it is not the drop_path 0 step: without the factors the student logits move by far more than the tolerance
     d0, _, outs0 = O.step_grads(sd, x, y, torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"]), keep, scale=float(g["meta_scale"]), mode="masked")
     assert np.abs(outs0[0].detach().numpy() - g["logits_student"]).max() > 1e-2
+
+
+def test_learnable_scalar_step_vs_reference(golden_dir):
+    """ffn_adapter_scalar == "learnable_scalar": the reference model stepped through its own train_one_epoch with twelve distinct scales
+    (tests/golden/make_golden_learnable_scalar.py) against the oracle: logits, masks, losses, all 86 gradients incl. the twelve d(scale)."""
+    g = load(golden_dir, "learnable_scalar_step.npz")
+    B, C, r = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = synth.add_learnable_scales(state(g), seed=int(g["meta_seed"]))
+    x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    keep = synth.make_dropout_masks(B, r, seed=int(g["meta_seed"]) + 3)
+    d, grads, outs = O.step_grads(sd, x, y, torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"]), keep, scale=float("nan"), mode="masked")
+    assert np.abs(outs[0].detach().numpy() - g["logits_student"]).max() < 2e-5
+    assert np.abs(outs[1].detach().numpy() - g["logits_teacher"]).max() < 2e-5
+    assert np.array_equal(outs[2]["token_select"].detach().numpy().astype(np.uint8), g["token_select"])
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(float(d[k]) - float(g["stat_" + k])) < 1e-5 * max(1.0, abs(float(g["stat_" + k]))), k
+    assert len(grads) == 86 and sum(n.endswith("adaptmlp.scale") for n in grads) == 12
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-8, n
+        if "grad/" + n in g:
+            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-8, n
