@@ -539,3 +539,49 @@ def test_learnable_scalar_gradient_accumulation_and_default_layout():
     x, y, g1, g2, km = batches[0]
     e0.step_fwd_bwd(x, y, 0.5, 2.0, 0.0, 0.0, g1=g1, g2=g2, keep_mask=km)
     assert float(e0.grad[off]) == 0.0 and float(e0.flat[off]) == 0.0
+
+
+def test_learnable_scalar_through_the_mirror_training_loop():
+    """engine_finetune.train_one_epoch + FusedAdamW on a learnable-scalar model (fp32 mode): the loop's freeze-rule check accepts the 86
+    trainable tensors, the returned statistics are the reference's, and the twelve scales (and block 6's adapter) after the AdamW step
+    are the reference's parameters after its own step."""
+    import os
+    import types
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from engine_finetune import FusedAdamW, train_one_epoch
+    from models.losses import AdaLoss
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "learnable_scalar_step.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    sd = synth.add_learnable_scales(synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3), seed=seed)
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="learnable_scalar", ffn_num=r, d_model=768)
+    model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                       precision="fp32", train_mode="masked")
+    model.load_state_dict(sd, strict=True)
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    model = model.cuda()
+    lr, wd = float(g["meta_lr"]), float(g["meta_wd"])
+    opt = FusedAdamW(model, lr=lr, weight_decay=wd)
+    crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0)
+    args = types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=0.0, warmup_epochs=0, epochs=10, metric="accuracy", nb_classes=C)
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    loader = [(x, y, (torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])), keep)]
+    stats = train_one_epoch(model, crit, loader, opt, torch.device("cuda", 0), 0, None, 0, None, None, args=args)
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        ref = float(g["stat_" + k])
+        assert abs(stats[k] - ref) < 1e-4 * max(1.0, abs(ref)), (k, stats[k], ref)
+    params = dict(model.named_parameters())
+    n_checked = 0
+    for key in g:
+        if key.startswith("param_after/"):
+            n = key.split("/", 1)[1]
+            assert np.abs(params[n].detach().cpu().numpy() - g[key]).max() < 5e-5, n
+            n_checked += 1
+    assert n_checked >= 16
+    # and a checkpoint of it carries the scales under the reference's key names
+    assert all(("blocks.%d.adaptmlp.scale" % i) in model.state_dict() for i in range(12))
