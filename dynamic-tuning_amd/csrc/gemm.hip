@@ -1180,7 +1180,12 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     // with a pre-shuffled weight, i.e. the proj forward too -- measured 81.7 vs 73.3 us for that one, and the row kernels that read
     // its fp32 output right after it got slower; 2 = default: those without a residual epilogue)
     static const int bpre_k768 = getenv("DYT_BPRE_K768") ? atoi(getenv("DYT_BPRE_K768")) : 2;
-    static const int bpre_maxk = getenv("DYT_BPRE_STORE_MAXK") ? atoi(getenv("DYT_BPRE_STORE_MAXK")) : D;   // measurement knob: plain-store N = 768 GEMMs up to this K
+    // DYT_BPRE_STORE_MAXK: plain-store N = 768 GEMMs up to this K take the kernel as well.  Round 5: 3072 = the qkv dgrad (K = 2304) and the fc1 dgrad
+    // (K = 3072, compacted in the student pass) too.  In the serial profile they are slower there (GEMM family 20.2 -> 20.7 ms per step: the
+    // 256x256 kernel has the better main loop on warm operands), but the step -- what `value` measures -- is 23.85 vs 24.3 ms same-box, four
+    // alternations: 64 KB workgroups share CUs with the other pass's kernels, and the four-slot ring loses less on operands that come from
+    // HBM (tools/gemm_bench.py COLD=1: +22 % vs +42 %).  768 restores the round-4 routing (proj dgrad only).
+    static const int bpre_maxk = getenv("DYT_BPRE_STORE_MAXK") ? atoi(getenv("DYT_BPRE_STORE_MAXK")) : 3072;
     const bool k768 = (a.K == D && bpre_k768 == 1) || (bpre_k768 == 2 && std::is_same<Epi, EpiStoreAT<bf16>>::value && a.K <= bpre_maxk);
     if (takes_bpre(a, k768)) {
         GemmArgs b = a; b.W = a.Wp;
