@@ -275,6 +275,7 @@ struct dyt_ctx {
     bool learn_scale = false;    // DYT_OPT_LEARNABLE_SCALE: tuning_config.ffn_adapter_scalar == "learnable_scalar" (dynamic_adapter.py:101-102): the scale is
                                  // the trainable word off_sc of every block (a padding slot of the flat layout behind the gate bias)
     int64_t off_sc = 0;
+    bool pass_ran = false;       // a forward pass has run in this context: DYT_OPT_LEARNABLE_SCALE may no longer change
     float* ad_up_bp = nullptr;   // [depth][768] s * up_proj.bias (prep_adapters_kernel)
     float drop_path_rate = 0.f;  // timm DropPath rate of the LAST block (block l: rate * l / (depth - 1)); training forward passes only
     int count_flops_tokens = 0;  // > 0: Block.forward_count_flops -- MLP on the first n tokens of every image
@@ -901,7 +902,15 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
         case DYT_OPT_ATTN_BWD_FUSED: set_attn_bwd_fused(value); return DYT_OK;   // process-wide
         case DYT_OPT_ATTN_V2: set_attn_v2(value & 3); return DYT_OK;             // process-wide
         case DYT_OPT_GEMM_SPLITK: set_gemm_splitk(value); return DYT_OK;         // process-wide
-        case DYT_OPT_LEARNABLE_SCALE: c->learn_scale = value != 0; for (auto& S : c->slots) S.valid = false; return DYT_OK;
+        case DYT_OPT_LEARNABLE_SCALE:
+            // The scale words are the CALLER's (DYT_P_AD_SCALE of the flat trainable buffer handed to every call): a padding word -- zero -- until
+            // the caller writes the reference's initial value 1.0 (models/dynamic_adapter.py:102).  Switching the meaning of that word between
+            // passes would silently turn the adapters off (s = 0) or rescale them, so the option is fixed once a pass has run.
+            if ((value != 0) != c->learn_scale && c->pass_ran) {
+                set_error("DYT_OPT_LEARNABLE_SCALE must be set before the first forward pass of the context");
+                return DYT_ERR_STATE;
+            }
+            c->learn_scale = value != 0; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_COUNT_FLOPS_TOKENS:
             if (value < 0 || value > NT) { set_error("count_flops tokens %d out of range 0..197", value); return DYT_ERR_ARG; }
             c->count_flops_tokens = value; for (auto& S : c->slots) S.valid = false; return DYT_OK;
@@ -1332,6 +1341,7 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         RUN(2, 0, launch_head_fwd(S.xs[depth], c->norm_w, c->norm_b, trainable + c->off_hw, trainable + c->off_hb, S.cls_n,
                                   S.head_stats, logits, B, c->cfg.num_classes, s));
     }
+    c->pass_ran = true;
     S.batch = B; S.flags = flags; S.valid = save && !tokens_in && !tokens_out; S.trainable = trainable; S.saved16 = save16;   // token-level passes are forward only
     return DYT_OK;
 }

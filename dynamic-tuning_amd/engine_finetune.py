@@ -36,6 +36,16 @@ def _trainable_names(model):
     return [(n, p) for n, p in model.named_parameters() if is_trainable_param(key_to_param(n)[0])]
 
 
+def gradscaler_dict(scale_log2, growth_tracker, skipped, growth_interval):
+    """The gradient-scale state in ``torch.cuda.amp.GradScaler.state_dict()``'s layout (what the reference stores under the
+    checkpoint's 'scaler' key, misc.py:274-278,350-351, and feeds to ``GradScaler.load_state_dict``: scale, growth_factor,
+    backoff_factor, growth_interval, _growth_tracker) plus two keys of our own: ``scale_log2`` (None: an arithmetic mode that
+    carries no scale -- bf16 / fp32 operands) and ``skipped``."""
+    return dict(scale=float(2.0 ** scale_log2) if scale_log2 is not None else 1.0, growth_factor=2.0, backoff_factor=0.5,
+                growth_interval=int(growth_interval), _growth_tracker=int(growth_tracker),
+                scale_log2=None if scale_log2 is None else int(scale_log2), skipped=int(skipped))
+
+
 class FusedAdamW:
     """Stands where ``torch.optim.AdamW([trainable params], lr, weight_decay)`` stands in main_image.py:285; the update
     itself is libdyt_hip's flat AdamW kernel.  Exposes ``param_groups`` so ``lr_sched.adjust_learning_rate`` works
@@ -70,6 +80,7 @@ class FusedAdamW:
         self._clean_run = 0            # applied updates since the last skip / the last growth
         self._applied_seen = 0
         self._scale_log2 = None        # last scale this optimizer set or loaded (persisted: a resumed run / a re-created engine starts from it)
+        self._torch = None             # the driver's torch.optim.AdamW this optimizer was adopted from (as_fused)
 
     def zero_grad(self, set_to_none=True):
         pass  # dyt_step_fwd_bwd zeroes the flat gradient buffer itself
@@ -155,21 +166,62 @@ class FusedAdamW:
         return new
 
     def scaler_state(self):
-        """What GradScaler.state_dict() holds, in our terms (goes into the checkpoint's 'scaler' entry and the optimizer's own dict)."""
+        """What GradScaler.state_dict() holds, in its own layout (goes into the checkpoint's 'scaler' entry: the reference's
+        ``loss_scaler.load_state_dict(checkpoint['scaler'])``, misc.py:350-351, accepts it)."""
         eng = self.model._engine
         k = getattr(eng, "grad_scale_log2", None) if eng is not None else None
-        return dict(scale_log2=self._scale_log2 if k is None else k, growth_tracker=int(self._clean_run), skipped=int(self._skips_seen),
-                    growth_interval=int(self.growth_interval))
+        return gradscaler_dict(self._scale_log2 if k is None else k, self._clean_run, self._skips_seen, self.growth_interval)
 
     def load_scaler_state(self, st):
+        """Our own dict (``scale_log2``; also the round-5 form with ``growth_tracker``) or a reference GradScaler dict (``scale`` a
+        power of two, 65536 by default: log2 of it, capped at GROW_MAX_LOG2)."""
         if not st:
             return
-        self._clean_run = int(st.get("growth_tracker", 0))
+        self._clean_run = int(st.get("_growth_tracker", st.get("growth_tracker", 0)))
         self.growth_interval = int(st.get("growth_interval", self.growth_interval))
-        self._scale_log2 = st.get("scale_log2", None)
+        k = st.get("scale_log2", None)
+        if k is None and "scale_log2" not in st and st.get("scale"):
+            k = min(self.GROW_MAX_LOG2, max(0, int(round(math.log2(float(st["scale"]))))))
+        self._scale_log2 = k
         eng = self.model._engine
         if eng is not None and self._scale_log2 is not None and getattr(eng, "grad_scale_log2", None) is not None:
             eng.set_grad_scale_log2(int(self._scale_log2))
+
+    # ---- the driver's torch.optim.AdamW (main_image.py:285) as the handle onto this optimizer -----------------------------
+    def adopt_torch_state(self):
+        """Take over what ``optimizer.load_state_dict`` (misc.load_model, :347) put into the driver's torch optimizer."""
+        topt = self._torch
+        if topt is None:
+            return
+        pending, step = {}, 0
+        for name, p in _trainable_names(self.model):
+            st = topt.state.get(p)
+            if not st or "exp_avg" not in st:
+                continue
+            if self.exp_avg is not None and st["exp_avg"].untyped_storage().data_ptr() == self.exp_avg.untyped_storage().data_ptr():
+                return   # these are our own views (publish_torch_state): nothing was loaded
+            pending[name] = dict(exp_avg=st["exp_avg"].detach().clone(), exp_avg_sq=st["exp_avg_sq"].detach().clone())
+            step = max(step, int(float(st["step"])))
+        if pending:
+            self._pending, self.step_count, self.opt_state = pending, step, None
+            if self.model._engine is not None:
+                self._state(self.model._engine)
+
+    def publish_torch_state(self):
+        """``optimizer.state[p]`` of the driver's torch optimizer = views into the flat moment buffers + the applied-update count,
+        so ``optimizer.state_dict()`` (misc.save_model, :306) is the fused optimizer's state at any time after a step."""
+        topt, eng = self._torch, self.model._engine
+        if topt is None or eng is None or self.exp_avg is None:
+            return
+        if self.guard and self.opt_state is not None:
+            self.step_count = self.applied_and_skipped()[0]
+        if self.step_count == 0 and self._pending is None:
+            return
+        m, v = self._state(eng)
+        step = torch.tensor(float(self.step_count))
+        for name, p in _trainable_names(self.model):
+            off, num = eng.trainable_slice(name)
+            topt.state[p] = dict(step=step.clone(), exp_avg=m[off:off + num].view(p.shape), exp_avg_sq=v[off:off + num].view(p.shape))
 
     def state_dict(self):
         names = _trainable_names(self.model)
@@ -189,7 +241,9 @@ class FusedAdamW:
                 state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=ea, exp_avg_sq=es)
         # exactly torch.optim.AdamW.state_dict()'s keys (checkpoint interchange); the gradient-scale state travels in the checkpoint's 'scaler'
         # entry like the reference's GradScaler state (misc.save_model / load_model -> scaler_state / load_scaler_state)
-        return dict(state=state, param_groups=[dict(self.param_groups[0])])
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(names)))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW.state_dict() of the reference (or our own): tensors may live on any device
@@ -220,7 +274,42 @@ class FusedAdamW:
             self._state(self.model._engine)
 
 
+def as_fused(optimizer, model):
+    """The optimizer ``train_one_epoch`` steps with.  A ``FusedAdamW`` is taken as it is; the ``torch.optim.AdamW`` the reference's
+    drivers build (main_image.py:285, main_vtab.py:269, main_video.py:316: ONE group over ``[p for p in named_parameters() if
+    p.requires_grad]``) is ADOPTED on first use: its hyper-parameter group becomes the fused optimizer's (one dict object, so
+    ``lr_sched.adjust_learning_rate`` and any later edit reach the kernel), state it may hold from ``misc.load_model`` is taken
+    over, and from then on its ``state`` aliases the fused moments -- no driver line changes.  Anything the flat AdamW kernel
+    does not implement raises."""
+    if isinstance(optimizer, FusedAdamW):
+        return optimizer
+    m = getattr(model, "module", model)
+    fused = getattr(optimizer, "_dyt_fused", None)
+    if fused is not None and fused.model is m:
+        return fused
+    if not isinstance(optimizer, torch.optim.AdamW):
+        raise DyTError("train_one_epoch drives the fused HIP step: pass the torch.optim.AdamW of main_image.py:285 or an "
+                       "engine_finetune.FusedAdamW (got %s)" % type(optimizer).__name__)
+    if len(optimizer.param_groups) != 1:
+        raise NotImplementedError("the fused AdamW kernel updates one parameter group (got %d)" % len(optimizer.param_groups))
+    g = optimizer.param_groups[0]
+    if g.get("amsgrad") or g.get("maximize"):
+        raise NotImplementedError("amsgrad / maximize are not implemented by the fused AdamW kernel")
+    names = _trainable_names(m)
+    if len(g["params"]) != len(names) or any(a is not b for a, (_, b) in zip(g["params"], names)):
+        raise NotImplementedError("the optimizer must hold exactly the reference's trainable tensors in named_parameters() order "
+                                  "(adapters, gates, head: main_image.py:250-256,285); got %d tensors, the model trains %d"
+                                  % (len(g["params"]), len(names)))
+    fused = FusedAdamW(m, lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
+    fused.param_groups = optimizer.param_groups
+    fused._torch = optimizer
+    fused.adopt_torch_state()
+    optimizer._dyt_fused = fused
+    return fused
+
+
 _native_rccl_failed = False
+_native_rccl_agreed = False   # the collective agreement below ran in this process (once, whatever engine asked: ADVICE round 5)
 
 
 def allreduce_grads(engine, group=None, overlap=True):
@@ -233,8 +322,13 @@ def allreduce_grads(engine, group=None, overlap=True):
     if engine.grad.is_cuda and group is None and os.environ.get("DYT_NATIVE_RCCL", "1") != "0" and hasattr(engine, "allreduce_native"):
         # the collective behind the C ABI (dyt_allreduce_grads): RCCL called by the library on a communicator of its own (one per
         # process).  If that communicator cannot be made (no librccl, several ranks on one GPU) the torch.distributed path below runs.
-        global _native_rccl_failed
+        global _native_rccl_failed, _native_rccl_agreed
         if not _native_rccl_failed:
+            if _native_rccl_agreed and getattr(engine, "_rccl_comm", None) is None:
+                # a re-created engine (larger eval / last batch on THIS rank only) takes the process's cached communicator without any
+                # collective: the other ranks are not in this branch and would never join one
+                import _lib
+                engine._rccl_comm = _lib.rccl_comm_shared(engine.device)
             if getattr(engine, "_rccl_comm", None) is None:
                 # Creating the communicator can fail on SOME ranks only (no librccl on one host, two ranks on one GPU); a rank that fell back
                 # to torch.distributed on its own would then wait in a collective the others never issue.  The ranks agree twice, by a MIN
@@ -264,6 +358,7 @@ def allreduce_grads(engine, group=None, overlap=True):
                         _native_rccl_failed = True
                         engine._rccl_comm = None
                         _lib.rccl_comm_destroy_all()
+                _native_rccl_agreed = True
                 if _native_rccl_failed:
                     print("[dyt] native RCCL all-reduce off on every rank%s: using torch.distributed.all_reduce" % ((" (rank %d: %s)" % (dist.get_rank(), why)) if why else ""))
             if not _native_rccl_failed:
@@ -336,12 +431,15 @@ def _check_supported(model, criterion):
 
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
                     mixup_fn=None, log_writer=None, args=None, logger=None):
-    """Reference engine_finetune.py:16-106.  ``optimizer`` must be a FusedAdamW; ``loss_scaler`` is
-    unused (bf16 operands / fp32 accumulation need no loss scaling -- the reference's GradScaler,
-    misc.py:252-272, only exists for its fp16 autocast); ``max_norm`` (--clip_grad) clips the global
-    gradient norm on the device before the update.  ``args.hip_graph`` replays the step from a hipGraph."""
-    if not isinstance(optimizer, FusedAdamW):
-        raise DyTError("train_one_epoch drives the fused HIP step; pass engine_finetune.FusedAdamW(model, ...)")
+    """Reference engine_finetune.py:16-106.  ``optimizer`` is the ``torch.optim.AdamW`` the drivers build (main_image.py:285;
+    adopted by a FusedAdamW on first use, ``as_fused``) or a FusedAdamW; ``loss_scaler`` (the drivers' ``NativeScaler()``,
+    main_image.py:290) is bound to that optimizer's gradient-scale state -- the loss scaling itself (the reference's GradScaler,
+    misc.py:252-272) is the library's power-of-two scale on 16-bit gradient operands plus the device-side overflow guard;
+    ``max_norm`` (--clip_grad) clips the global gradient norm on the device before the update.  ``args.hip_graph`` replays the
+    step from a hipGraph."""
+    optimizer = as_fused(optimizer, model)
+    if loss_scaler is not None and hasattr(loss_scaler, "bind"):
+        loss_scaler.bind(optimizer)
     if mixup_fn is not None:
         raise NotImplementedError("mixup is not used by train_IN21K.sh / train_vtab.sh / train_video.sh")
     accum_iter = max(1, int(getattr(args, "accum_iter", 1) or 1)) if args is not None else 1
@@ -392,6 +490,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             pending = 0
     stats = {k: v / max(count, 1) for k, v in sums.items()}
     stats["lr"] = lr
+    optimizer.publish_torch_state()   # an adopted torch.optim.AdamW now reports this epoch's moments / step count (misc.save_model)
     if is_dist_avail_and_initialized():  # metric_logger.synchronize_between_processes(), reference :104
         t = torch.tensor([stats[k] for k in LOSS_KEYS], device=device, dtype=torch.float64)
         dist.all_reduce(t)
@@ -449,7 +548,7 @@ def evaluate(data_loader, model, device, logger=None, base_flops=None, flops_dic
     metric = getattr(args, "metric", "accuracy")
     if metric == "accuracy":
         acc1, acc5 = accuracy(predictions, targets, topk=(1, 5))
-        status["metric"] = acc1.item()
+        status["metric"] = status["acc1"] = acc1.item()   # 'acc1' is what the drivers' --eval branch prints (main_image.py:323)
         status["acc5"] = acc5.item()
     elif metric == "mean_per_class_acc":
         status["metric"] = mean_per_class_accuracy(predictions, targets, args.nb_classes).item()
@@ -484,7 +583,7 @@ def evaluate_video(data_loader, model, device, logger=None, base_flops=None, flo
     metric = getattr(args, "metric", "accuracy")
     if metric == "accuracy":
         acc1, acc5 = accuracy(predictions, targets, topk=(1, 5))
-        status["metric"] = acc1.item()
+        status["metric"] = status["acc1"] = acc1.item()
         status["acc5"] = acc5.item()
     elif metric == "mean_per_class_acc":
         status["metric"] = mean_per_class_accuracy(predictions, targets, args.nb_classes).item()

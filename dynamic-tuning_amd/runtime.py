@@ -74,6 +74,12 @@ class DyTEngine:
         self._ck(self.L.dyt_trainable_numel(self.h, ctypes.byref(n)))
         self.n_train = n.value
         self.flat = torch.zeros(self.n_train, device=self.device, dtype=torch.float32)
+        if self.learnable_scale:   # the reference's init, nn.Parameter(torch.ones(1)) (dynamic_adapter.py:102): a zeroed word would mean "adapter off"
+            from _lib import P_AD_SCALE
+            off, num = ctypes.c_int64(), ctypes.c_int64()
+            for layer in range(int(depth)):
+                self._ck(self.L.dyt_trainable_offset(self.h, P_AD_SCALE, layer, ctypes.byref(off), ctypes.byref(num)))
+                self.flat[off.value:off.value + num.value] = 1.0
         self.grad = torch.zeros_like(self.flat)
         self.losses = torch.zeros(8, device=self.device, dtype=torch.float32)
         self._graphs = {}          # captured hipGraphs of the step, keyed by its static arguments
@@ -129,6 +135,13 @@ class DyTEngine:
         for k, v in sd.items():
             self.set_param(k, v)
 
+    def _dp_check(self, slots, batch):
+        """Injected stochastic-depth factors are [2, depth, B]: a training pass of another batch size would read past / short of them."""
+        for sl in slots:
+            n = getattr(self, "_dp_batch", {}).get(sl)
+            if n is not None and n != batch:
+                raise DyTError("injected drop-path factors of slot %d are for %d images, this pass has %d" % (sl, n, batch))
+
     # ---- passes -----------------------------------------------------------------------------
     def forward(self, images, slot=0, training=False, complete_model=False, save=False, masked_dense=False,
                 gate_always=False, g1=None, g2=None, keep_mask=None, seed=0, want_tokens=True, trainable=None):
@@ -140,6 +153,8 @@ class DyTEngine:
         ts = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32) if has_tok else None
         tl = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32) if has_tok else None
         tr = self.flat if trainable is None else trainable
+        if training:
+            self._dp_check((slot,), B)
         if save:
             self.generation[slot] += 1
         with torch.cuda.device(self.device):
@@ -186,6 +201,7 @@ class DyTEngine:
         (accumulate=True: are added to it -- gradient accumulation over micro-batches).  device_seed: the noise seed
         comes from the library's device-side word (seed_device()), advanced once per step."""
         B = images.shape[0]
+        self._dp_check((0, 1), B)
         for i in range(len(self.generation)):
             self.generation[i] += 1
         flags = (F_MASKED_DENSE if masked_dense else 0) | (F_ACCUM_GRAD if accumulate else 0) | (F_DEVICE_SEED if device_seed else 0)
@@ -279,34 +295,39 @@ class DyTEngine:
         self._ck(self.L.dyt_grad_part(self.h, int(part), ctypes.byref(off), ctypes.byref(num)))
         return off.value, num.value
 
-    def streams_concurrent(self, a, b, spin_cycles=400_000):
+    def streams_concurrent(self, a, b, spin_cycles=400_000, repeats=3):
         """True when work queued on streams `a` and `b` really runs at the same time.  HIP multiplexes a process's streams onto
         GPU_MAX_HW_QUEUES hardware queues (default 4; _lib.py / bench.py ask for 8 when they are imported before the runtime starts) and two
         streams on one queue run one after the other -- a DP rank's all-reduce stream sharing the step's queue costs 30.6 instead of 25.9
         ms per step.  Measured, not assumed: one ~0.2 ms spin kernel on each stream; together they take ~1x (separate
-        queues) or ~2x (same queue) the time of one."""
+        queues) or ~2x (same queue) the time of one.  Best of `repeats` trials, so that a busy or shared GPU (another process's kernel
+        landing between the two spins) does not read as "serialised" (ADVICE round 5).  Synchronises the device: must not be reached for
+        the first time under stream capture (comm_stream() is called by the first eager all-reduce)."""
+        best = None
         with torch.cuda.device(self.device):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             torch.cuda._sleep(1000)                     # warm the spin kernel up
-            torch.cuda.synchronize(self.device)
-            cur = torch.cuda.current_stream(self.device)
-            ev[0].record(cur)
-            a.wait_event(ev[0]); b.wait_event(ev[0])
-            with torch.cuda.stream(a):
-                ev[1].record(a); torch.cuda._sleep(spin_cycles); ev[2].record(a)
-            with torch.cuda.stream(b):
-                torch.cuda._sleep(spin_cycles); ev[3].record(b)
-            torch.cuda.synchronize(self.device)
-            one = ev[1].elapsed_time(ev[2])
-            both = max(ev[1].elapsed_time(ev[2]), ev[1].elapsed_time(ev[3]))
-            alone = None
-            with torch.cuda.stream(a):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(a); torch.cuda._sleep(spin_cycles); e1.record(a)
-            torch.cuda.synchronize(self.device)
-            alone = e0.elapsed_time(e1)
-        self._last_concurrency = (alone, one, both)
-        return both < 1.5 * alone
+            for _ in range(max(1, int(repeats))):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+                torch.cuda.synchronize(self.device)
+                cur = torch.cuda.current_stream(self.device)
+                ev[0].record(cur)
+                a.wait_event(ev[0]); b.wait_event(ev[0])
+                with torch.cuda.stream(a):
+                    ev[1].record(a); torch.cuda._sleep(spin_cycles); ev[2].record(a)
+                with torch.cuda.stream(b):
+                    torch.cuda._sleep(spin_cycles); ev[3].record(b)
+                torch.cuda.synchronize(self.device)
+                both = max(ev[1].elapsed_time(ev[2]), ev[1].elapsed_time(ev[3]))
+                with torch.cuda.stream(a):
+                    ev[4].record(a); torch.cuda._sleep(spin_cycles); ev[5].record(a)
+                torch.cuda.synchronize(self.device)
+                alone = ev[4].elapsed_time(ev[5])
+                if best is None or both / alone < best[1] / best[0]:
+                    best = (alone, both)
+                if both < 1.5 * alone:
+                    break
+        self._last_concurrency = (best[0], best[0], best[1])
+        return best[1] < 1.5 * best[0]
 
     def comm_stream(self):
         """Side stream of the early gradient all-reduce: one that is VERIFIED to run beside the step's stream (up to eight candidates; streams
@@ -400,8 +421,14 @@ class DyTEngine:
         if not hasattr(self, "_dp_keep"):
             self._dp_keep = {}
         if scales is not None:
-            assert scales.is_cuda and scales.dtype == torch.float32 and scales.is_contiguous() and scales.shape[:2] == (2, self.depth)
+            assert scales.is_cuda and scales.dtype == torch.float32 and scales.is_contiguous() and scales.dim() == 3 and scales.shape[:2] == (2, self.depth)
+            if scales.shape[2] > int(self.cfg.max_batch):
+                raise DyTError("drop-path factors for %d images, the context holds at most %d" % (scales.shape[2], int(self.cfg.max_batch)))
         self._dp_keep[slot] = scales
+        if not hasattr(self, "_dp_batch"):
+            self._dp_batch = {}
+        self._dp_batch[slot] = None if scales is None else int(scales.shape[2])   # the passes that read them must have exactly this batch (_dp_check)
+        self._graphs = {}   # a captured step carries the old pointer in its kernel arguments
         self._ck(self.L.dyt_set_drop_path_scales(self.h, int(slot), ptr(scales)))
 
     # ---- measurement ------------------------------------------------------------------------

@@ -223,7 +223,10 @@ int dyt_ctx_bytes(const dyt_ctx* ctx, int64_t* bytes);
  *                           trainable tensor), dyt_config.adapter_scale is ignored.  The per-step adapter copies carry the scale
  *                           (W' = s W_up, b' = s b_up), so every kernel runs as with scale 1; the backward leaves dL/dW', dL/db' in a
  *                           scratch buffer and one small kernel applies the chain rule: dW_up = s dW', db_up = s db',
- *                           ds = <dW', W_up> + <db', b_up>.  Set before the first forward pass. */
+ *                           ds = <dW', W_up> + <db', b_up>.  The scale words belong to the caller's flat buffer and are whatever it holds:
+ *                           write the reference's initial value 1.0 (models/dynamic_adapter.py:102) before the first pass -- a zeroed
+ *                           buffer means s = 0, i.e. adapters off and no up-projection gradient.  Must be set before the first forward
+ *                           pass of the context; changing it afterwards returns DYT_ERR_STATE. */
 #define DYT_OPT_LEARNABLE_SCALE 11
 int dyt_ctx_set_option(dyt_ctx* ctx, int option, int value);
 /* the process-wide options (DYT_OPT_ATTN_BWD_FUSED, DYT_OPT_ATTN_V2, DYT_OPT_GEMM_SPLITK) without a context: unit entries such as dyt_attention() see them too */

@@ -1,0 +1,162 @@
+"""GPU tests added in round 6 (pytest -m gpu), all through the C ABI.
+  * the reference's DRIVER sequence (main_image.py:212-346) replayed with this package's modules and the objects the driver itself
+    builds -- ``torch.optim.AdamW``, ``NativeScaler()``, ``misc.load_model / save_model`` -- against the FusedAdamW route, bit for bit,
+    including a resume from the checkpoint the driver's objects wrote."""
+import os
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _driver_objects(precision, C=10, r=64, seed=0, lr=2e-3, wd=0.01):
+    """main_image.py:183-307 with this package's modules: factory, non-strict checkpoint load, freeze rule from missing_keys,
+    ``.to(device)``, ``torch.optim.AdamW`` over the trainable parameters, ``NativeScaler()``, ``AdaLoss``."""
+    import gpu_diag as D
+    import synth
+    from misc import NativeScalerWithGradNormCount as NativeScaler
+    from models.losses import AdaLoss
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+    select = D.Cfg(open=True, keep_layers=0, token_ratio=2., token_target_ratio=0.5, token_minimal=0., token_minimal_weight=0.)
+    model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=select, precision=precision,
+                                       train_mode="compact")
+    full = synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.85)
+    ckpt = {k: v for k, v in full.items() if not synth.is_trainable(k)}          # a timm checkpoint has no adapters / gates / head of this size
+    msg = model.load_state_dict(ckpt, strict=False)
+    with torch.no_grad():                                                        # (give the zero-initialised up-projections something to do)
+        for k, p in model.named_parameters():
+            if synth.is_trainable(k):
+                p.copy_(full[k])
+    for name, p in model.named_parameters():                                     # main_image.py:250-256
+        p.requires_grad = name in msg.missing_keys
+    for _, p in model.head.named_parameters():
+        p.requires_grad = True
+    device = torch.device("cuda", 0)
+    model.to(device)
+    optimizer = torch.optim.AdamW([p for name, p in model.named_parameters() if p.requires_grad], lr=lr, weight_decay=wd)   # :285
+    loss_scaler = NativeScaler()                                                                                              # :290
+    criterion = AdaLoss(base_criterion=torch.nn.CrossEntropyLoss(), layer_target_ratio=0.5, layer_loss_ratio=2.0, layer_diverse_ratio=0.0,
+                        layer_entropy_weight=0.0, layer_minimal_weight=0.0, layer_minimal=0.0, token_target_ratio=select.token_target_ratio,
+                        token_loss_ratio=select.token_ratio, token_minimal=select.token_minimal, token_minimal_weight=select.token_minimal_weight)
+    return model, optimizer, loss_scaler, criterion, device
+
+
+def _loader(B, C, steps, seed):
+    import synth
+    return [synth.make_batch(B, C, seed=seed + i) for i in range(steps)]
+
+
+def _args(tmp, C, lr, epochs=4, resume=""):
+    return types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=1e-5, warmup_epochs=1, epochs=epochs, metric="accuracy", nb_classes=C,
+                                 output_dir=str(tmp), save_freq=1, auto_remove=False, resume=resume, start_epoch=0, eval=False,
+                                 tuning_config=types.SimpleNamespace(ffn_num=64))
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3q"])
+def test_driver_sequence_with_the_drivers_own_optimizer_and_scaler(precision, tmp_path):
+    """Three runs over the same seeded batches.  (A) the driver's sequence as main_image.py writes it -- torch.optim.AdamW, NativeScaler(),
+    misc.load_model (no resume), train_one_epoch x 2, evaluate, misc.save_model, then two more epochs; (B) the same with a FusedAdamW in
+    the optimizer's place (round 1-5's documented route); (C) a NEW set of driver objects that resumes from the checkpoint A's objects
+    wrote after epoch 1 and runs epochs 2-3.  All three end with bit-identical parameters, the torch optimizer's state_dict() is the
+    fused optimizer's state (moments, step count), and the checkpoint's 'scaler' entry loads into a real GradScaler."""
+    import misc
+    from block_flops_dict import get_base_flops, get_block_flops
+    from engine_finetune import FusedAdamW, evaluate, train_one_epoch
+    B, C, lr = 8, 10, 2e-3
+    train, val = _loader(B, C, 3, 100), _loader(B, C, 2, 900)
+    log = types.SimpleNamespace(info=lambda *a, **k: None)
+
+    def run(kind, tmp, first_epoch=0, last_epoch=4, resume=""):
+        torch.manual_seed(7)
+        model, optimizer, loss_scaler, criterion, device = _driver_objects(precision, C=C, lr=lr)
+        if kind == "fused":
+            optimizer = FusedAdamW(model, lr=lr, weight_decay=0.01)
+        args = _args(tmp, C, lr, resume=resume)
+        model_without_ddp = model
+        misc.load_model(args=args, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)      # :310
+        base_flops, flops_dict = get_base_flops(args), get_block_flops(args)                                                # :317-318
+        assert args.start_epoch == first_epoch
+        stats = None
+        for epoch in range(args.start_epoch, last_epoch):
+            train_stats = train_one_epoch(model, criterion, train, optimizer, device, epoch, loss_scaler, max_norm=None,   # :329-336
+                                          log_writer=None, args=args, logger=log)
+            assert set(train_stats) >= {"loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss", "lr"}
+            test_stats = evaluate(val, model, device, log, base_flops=base_flops, flops_dict=flops_dict, args=args)       # :340
+            assert 0.0 <= test_stats["metric"] <= 100.0 and test_stats["acc1"] == test_stats["metric"]
+            misc.save_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer,             # :344-346
+                            loss_scaler=loss_scaler, epoch=epoch, save_force=True)
+            stats = train_stats
+        torch.cuda.synchronize()
+        return model, optimizer, loss_scaler, stats
+
+    ma, oa, sa, stats_a = run("torch", tmp_path / "a")
+    mb, ob, sb, stats_b = run("fused", tmp_path / "b")
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    for n in pa:
+        assert torch.equal(pa[n].detach(), pb[n].detach()), "driver route vs FusedAdamW route differ in %s" % n
+    assert stats_a == stats_b and stats_a["lr"] < lr
+
+    # the driver's torch optimizer reports the fused state: step count = applied updates, moments = the flat buffers
+    sd_a, sd_b = oa.state_dict(), ob.state_dict()
+    assert len(sd_a["state"]) == 74 and sd_a["param_groups"][0]["lr"] == stats_a["lr"] and sd_a["param_groups"][0]["params"] == list(range(74))
+    for i in range(74):
+        assert float(sd_a["state"][i]["step"]) == 12.0 == float(sd_b["state"][i]["step"])
+        assert torch.equal(sd_a["state"][i]["exp_avg"], sd_b["state"][i]["exp_avg"])
+        assert torch.equal(sd_a["state"][i]["exp_avg_sq"], sd_b["state"][i]["exp_avg_sq"])
+    assert float(sd_a["state"][5]["exp_avg_sq"].abs().max()) > 0
+    # the checkpoint on disk: the reference's keys, a GradScaler-loadable scaler entry, compact per-parameter tensors
+    ck = torch.load(tmp_path / "a" / "checkpoint-1.pth", map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch", "scaler", "args"} and ck["epoch"] == 1
+    assert float(ck["optimizer"]["state"][0]["step"]) == 6.0
+    assert all(v["exp_avg"].untyped_storage().nbytes() == v["exp_avg"].numel() * 4 for v in ck["optimizer"]["state"].values())
+    gs = torch.amp.GradScaler("cpu", enabled=True)
+    gs.load_state_dict(ck["scaler"])
+    assert gs.get_scale() == ck["scaler"]["scale"] == 2.0 ** ck["scaler"]["scale_log2"] == 4096.0
+    assert sa.state_dict() == oa._dyt_fused.scaler_state() and sa.state_dict()["scale"] == 4096.0
+
+    # (C) fresh driver objects resume from A's epoch-1 checkpoint (misc.load_model -> optimizer.load_state_dict -> adoption takes it over)
+    mc, oc, sc, stats_c = run("torch", tmp_path / "c", first_epoch=2, resume=str(tmp_path / "a" / "checkpoint-1.pth"))
+    pc = dict(mc.named_parameters())
+    for n in pa:
+        assert torch.equal(pa[n].detach(), pc[n].detach()), "resumed run differs in %s" % n
+    assert float(oc.state_dict()["state"][0]["step"]) == 12.0 and stats_c == stats_a
+
+
+def test_native_scaler_called_like_the_reference_loop_calls_it():
+    """The generic autograd route with the driver's objects, as the reference's own loop body runs it (engine_finetune.py:47-79):
+    two forwards, the loss assembled in torch, ``loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(),
+    update_grad=...)``, ``optimizer.zero_grad()`` -- parameters move, a non-finite loss skips the update and is counted."""
+    import torch.nn.functional as F
+    import synth
+    model, optimizer, loss_scaler, criterion, device = _driver_objects("fp16", C=10, lr=1e-3)
+    model.train(True)
+    x, y = synth.make_batch(4, 10, seed=5)
+    x, y = x.to(device), y.to(device)
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+
+    def loop_body(poison=False):
+        outputs, token_select = model(x)
+        teacher_outputs, _ = model(x, complete_model=True)
+        kl = F.kl_div(F.log_softmax(outputs, dim=-1), F.log_softmax(teacher_outputs.detach(), dim=-1), reduction='batchmean', log_target=True)
+        teacher_loss = criterion.base_criterion(teacher_outputs, y)
+        loss, loss_dict = criterion(dict(prediction=outputs, **token_select), y)
+        loss = loss + teacher_loss + kl
+        if poison:
+            loss = loss * float("inf")
+        norm = loss_scaler(loss, optimizer, clip_grad=None, parameters=model.parameters(), create_graph=False, update_grad=True)
+        optimizer.zero_grad()
+        return float(loss), norm
+
+    loss, norm = loop_body()
+    assert loss == loss and float(norm) > 0
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters() if p.requires_grad)
+    assert moved == 74
+    after = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    loop_body(poison=True)
+    assert loss_scaler.skipped == 1
+    assert all(torch.equal(after[n], p.detach()) for n, p in model.named_parameters() if p.requires_grad)
+    assert set(loss_scaler.state_dict()) >= {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}

@@ -268,11 +268,27 @@ def test_gradient_scale_backoff_and_growth_follow_gradscaler_update():
     counters[:] = [12, 2]
     assert opt.overflow_backoff(eng) == 0 and eng.grad_scale_log2 == 13
     st = opt.scaler_state()
-    assert st["scale_log2"] == 13 and st["skipped"] == 2 and st["growth_tracker"] == 0
+    assert st["scale_log2"] == 13 and st["skipped"] == 2 and st["_growth_tracker"] == 0
+    # ... in torch.cuda.amp.GradScaler.state_dict()'s layout: the reference's loss_scaler.load_state_dict(checkpoint['scaler'])
+    # (misc.py:350-351) takes it -- checked against the real GradScaler, which runs on CPU when disabled=False is forced
+    assert st["scale"] == 2.0 ** 13 and st["growth_factor"] == 2.0 and st["backoff_factor"] == 0.5 and st["growth_interval"] == 5
+    ref_scaler = torch.amp.GradScaler("cpu", enabled=True)
+    ref_scaler.load_state_dict(st)
+    assert ref_scaler.get_scale() == 2.0 ** 13 and ref_scaler.get_growth_interval() == 5
     eng2 = Eng()
     opt.model._engine = eng2
     opt.load_scaler_state(st)
     assert eng2.grad_scale_log2 == 13
+    # the other direction: a GradScaler dict written by the reference (default scale 65536) -> log2, capped at GROW_MAX_LOG2
+    eng3 = Eng()
+    opt.model._engine = eng3
+    opt.load_scaler_state(torch.amp.GradScaler("cpu", enabled=True, init_scale=2.0 ** 10, growth_interval=77).state_dict())
+    assert eng3.grad_scale_log2 == 10 and opt.growth_interval == 77
+    opt.load_scaler_state(torch.amp.GradScaler("cpu", enabled=True).state_dict())
+    assert eng3.grad_scale_log2 == 14                                            # 2^16 capped at this test's GROW_MAX_LOG2
+    opt.load_scaler_state(dict(scale_log2=13, growth_tracker=0, skipped=2, growth_interval=5))   # round-5 checkpoints
+    assert eng3.grad_scale_log2 == 13 and opt.growth_interval == 5
+    opt.model._engine = eng2
     for _ in range(4):                                                            # the cap
         counters[0] += 5
         opt.overflow_backoff(eng2)
