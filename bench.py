@@ -154,6 +154,10 @@ def main():
                     help="1: replay the step's forward+backward from a captured hipGraph.  Off by default: on ROCm 7.2 a replay "
                          "costs the host as much as the eager launches (DESIGN.md section 7) and the capture has to serialise "
                          "the teacher pass's adapter branch")
+    ap.add_argument("--host-batches", type=int, default=-1,
+                    help="N > 0: after the resident-data measurement, feed N DISTINCT pinned host batches through engine_finetune.train_one_epoch "
+                         "(the reference's loop: host -> device copy of every batch, reference engine_finetune.py:34-42; here prefetched on a copy "
+                         "stream) for --steps steps and report images/s beside `value` as `host_fed`.  -1 (default): 8 at N=1, 0 otherwise")
     ap.add_argument("--video-frames", type=int, default=0,
                     help="T > 1: BASELINE.json configs[4] shape instead of the headline one -- the video model, "
                          "--batch frames per GPU = batch/T clips of T frames (train_video.sh: 16 clips x 8 frames, 400 classes)")
@@ -164,6 +168,8 @@ def main():
         args.precision = "fp16"
     if args.video_frames > 1:
         assert args.batch % args.video_frames == 0, "--batch must be a multiple of --video-frames"
+    if args.host_batches < 0:
+        args.host_batches = 8 if (args.gpus == 1 and args.video_frames <= 1) else 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: start N ranks ourselves (one process per GPU over RCCL), exactly the command the
@@ -191,7 +197,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    head = measure(args, args.precision, args.mode, args.steps, args.warmup, device, world, rank)
+    head = measure(args, args.precision, args.mode, args.steps, args.warmup, device, world, rank, host_batches=args.host_batches)
     parity = None
     other = None
     if world == 1 and args.video_frames <= 1 and args.precision in ("fp16", "bf16") and not args.no_parity_mode:
@@ -304,6 +310,8 @@ def main():
             "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
             "roofline": head["roofline"],
         }
+        if head.get("host_fed") is not None:
+            out["host_fed"] = head["host_fed"]
         if dist_info is not None:
             out["distributed"] = dist_info
         if parity is not None:
@@ -320,7 +328,52 @@ def main():
         dist.destroy_process_group()
 
 
-def measure(args, precision, mode, steps, warmup, device, world, rank):
+def host_fed(args, model, opt, steps, warmup, device, world, resident_ms):
+    """The same step fed from the HOST the way the reference's loop is (engine_finetune.py:34-42): `n` distinct pinned batches cycled
+    through engine_finetune.train_one_epoch -- per-iteration lr schedule, host -> device copy of every batch (prefetched on a copy stream
+    into a second device buffer, DevicePrefetcher), the fused step, the loop's own bookkeeping and its sync every 20 steps."""
+    import types
+    from engine_finetune import train_one_epoch
+    from models.losses import AdaLoss
+    n = args.host_batches
+    batches = []
+    for i in range(n):
+        x, y = synth.make_batch(args.batch, args.classes, seed=500 + i)
+        batches.append((x.pin_memory(), y.pin_memory()))
+    crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=args.keep, token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0)
+    lr = opt.param_groups[0]["lr"]
+    la = types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=lr, warmup_epochs=0, epochs=10 ** 6, hip_graph=bool(args.hip_graph))
+    out = {}
+    resident = [(x.to(device), y.to(device)) for x, y in batches[:2]]
+    for name, env in (("prefetched", "1"), ("copy_on_compute_stream", "0"), ("loop_on_resident_batches", "1")):
+        os.environ["DYT_PREFETCH"] = env
+        src = resident if name == "loop_on_resident_batches" else batches
+        try:
+            train_one_epoch(model, crit, [src[i % len(src)] for i in range(max(warmup, 2))], opt, device, 0, None, args=la)
+            torch.cuda.synchronize()
+            if dist.is_initialized():
+                dist.barrier()
+            t0 = time.perf_counter()
+            train_one_epoch(model, crit, [src[i % len(src)] for i in range(steps)], opt, device, 1, None, args=la)
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            os.environ.pop("DYT_PREFETCH", None)
+    ms = out["prefetched"]
+    return {"value": round(args.batch * world / ms * 1e3, 2), "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps,
+            "distinct_batches": n, "pinned": True, "h2d_mb_per_step": round(args.batch * 3 * 224 * 224 * 4 / 1e6, 1),
+            "resident_ms_per_step": round(resident_ms, 3), "vs_resident": round(resident_ms / ms, 4),
+            "copy_on_compute_stream_ms_per_step": round(out["copy_on_compute_stream"], 3),
+            "loop_on_resident_batches_ms_per_step": round(out["loop_on_resident_batches"], 3),
+            "copy_stream_probe": getattr(model._engine, "_copy_stream_probe", (None, None))[1],
+            "loop": "engine_finetune.train_one_epoch (reference engine_finetune.py:16-106): lr schedule per iteration, H2D of every batch on a copy "
+                    "stream into the other of two device buffers (event hand-over), fused step, one host sync per 20 steps; "
+                    "`copy_on_compute_stream` = the reference's placement of the copy (DYT_PREFETCH=0)"}
+
+
+def measure(args, precision, mode, steps, warmup, device, world, rank, host_batches=0):
     """Build the model in one arithmetic / training mode, calibrate the keep ratio, time `steps` fused steps (barrier +
     synchronize on both sides, max over ranks) and take the dominant-kernel roofline of one extra event-profiled step."""
     from engine_finetune import FusedAdamW, train_step
@@ -459,6 +512,10 @@ def measure(args, precision, mode, steps, warmup, device, world, rank):
         comm = getattr(eng, "_rccl_comm", None)
         res["rccl_ranks"] = _lib.rccl_comm_ranks(comm) if comm is not None else None
         res["comm_stream_concurrent"] = bool(eng.streams_concurrent(torch.cuda.current_stream(device), eng.comm_stream()))
+    if host_batches > 0:
+        res["host_fed"] = host_fed(args, model, opt, steps, warmup, device, world, dt / steps * 1e3)
+        log("[%s/%s] host-fed loop: %.2f ms/step prefetched, %.2f with the copy on the compute stream (resident %.2f)" % (
+            precision, mode, res["host_fed"]["ms_per_step"], res["host_fed"]["copy_on_compute_stream_ms_per_step"], dt / steps * 1e3))
     del opt, model, eng
     torch.cuda.empty_cache()
     return res

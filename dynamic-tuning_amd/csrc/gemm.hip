@@ -375,6 +375,7 @@ struct EpiAdDown {
     const uint64_t* seed_dev;   // overrides `seed` when set (captured graphs draw fresh noise per replay)
     ST* out_s; float s_out;     // optional second copy s_out * result: the A2 operand of the fc2 + up-projection contraction (the adapter
                                 // scale goes on the O(1) activations, not on the possibly tiny up-projection weights: fp16 subnormals)
+    bf16* out3 = nullptr; float s3 = 1.f;   // split fp32 forms: s3 * result as a [rows][hi 64 | lo 64] image -- the up-projection's three-part operand
     typedef Bias4 Col;
     struct Pre { int trow; };
     __device__ __forceinline__ Col col_init(int col) const { return load_bias4(bias, col); }
@@ -397,6 +398,9 @@ struct EpiAdDown {
         }
         store4(out + (size_t)row * RP + col, v[0], v[1], v[2], v[3]);
         if (out_s) store4(out_s + (size_t)row * RP + col, v[0] * s_out, v[1] * s_out, v[2] * s_out, v[3] * s_out);
+        if constexpr (sizeof(AT) == 4) {
+            if (out3) store4_split3(out3 + (size_t)row * (SPLIT_A * RP) + col, RP, v[0] * s3, v[1] * s3, v[2] * s3, v[3] * s3);
+        }
     }
 };
 
@@ -405,6 +409,7 @@ struct EpiAdUp {
     const float* bias; const float* u; float* out; float scale; const int* row_map;
     const float* skip_mask;   // rows with skip_mask[row] != 0 are left alone (kept tokens: their fc2 launch adds the adapter itself)
     const float* rs = nullptr;   // MAPPED (cls-row proj of a complete_model pass's last block): stochastic-depth scale of image dst / 197
+    float bscale = -1.f;         // >= 0: out = u + scale * acc + bscale * bias (GemmArgs::bias_scale: the A operand already carries the adapter scale)
     typedef Bias4 Col;
     struct PreG { int dst; Raw4<float> r; };
     typedef typename std::conditional<MAPPED, PreG, Raw4<float>>::type Pre;
@@ -426,6 +431,11 @@ struct EpiAdUp {
         if constexpr (MAPPED) { p.r.get(r); dst = p.dst; } else { if (skip_mask && skip_mask[row] != 0.f) return; p.get(r); }
         float sc = scale;
         if constexpr (MAPPED) { if (rs) sc *= rs[dst / NT]; }
+        if (bscale >= 0.f) {   // (uniform branch)
+            store4(out + dst * D + col, r[0] + fmaf(bscale, c.b[0], sc * a[0]), r[1] + fmaf(bscale, c.b[1], sc * a[1]),
+                   r[2] + fmaf(bscale, c.b[2], sc * a[2]), r[3] + fmaf(bscale, c.b[3], sc * a[3]));
+            return;
+        }
         store4(out + dst * D + col, r[0] + sc * (a[0] + c.b[0]), r[1] + sc * (a[1] + c.b[1]),
                r[2] + sc * (a[2] + c.b[2]), r[3] + sc * (a[3] + c.b[3]));
     }
@@ -486,7 +496,12 @@ __device__ unsigned long long g_gemm_dbg[4];
 // gathered through a2_map) against W2 [N, 64] -- i.e. C = A2 W2^T + A W^T in one accumulator chain (adapter up-projection
 // riding on the fc2 GEMM: K = 64 + 3072).  The extra tile is stage 0 of the ring, so the main loop, its pointer
 // registers and its schedule are the plain kernel's (the A / W pointers are pre-decremented by one tile).
-struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; int a_ld; int f8_begin; const int* w_exp; };   // f8_begin / w_exp: F8 kernels -- first fp8 k-tile, device word with the weight image's exponent   // a_ld: row stride of split operands when the contraction runs over fewer than three parts (0: K - a_fold * 64)
+struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_scale; int a_fold; int a_ld; int f8_begin; const int* w_exp; };
+// LEAD (split fp32 forms, round 6): the second operand pair as THREE leading k-tiles of a three-part product -- A2 [rows][hi 64 | lo 64] (rows
+// optionally gathered through a2_map), W2 [N][hi 64 | lo 64]: tiles (A2_hi, W2_hi), (A2_hi, W2_lo), (A2_lo, W2_hi) -- contracted into the
+// accumulators by a small synchronous loop BEFORE the pipelined main loop starts (stage, wait, barrier, 2 x TM x TN MFMAs, barrier), so the
+// main loop -- three-part fold form or fp8-correction form -- its registers and its schedule stay exactly the plain kernel's.  Three exposed
+// tile latencies per workgroup against the fp32 read-modify-write launch of [M,768] this replaces (adapter up-projection riding on fc2).   // f8_begin / w_exp: F8 kernels -- first fp8 k-tile, device word with the weight image's exponent   // a_ld: row stride of split operands when the contraction runs over fewer than three parts (0: K - a_fold * 64)
 // a_fold: k-tiles of ONE part of split operands stored [hi | lo] (row stride K - a_fold * 64): k-tile kt reads A column tile kt - (kt >= a_fold ? a_fold : 0) and W column tile kt - (kt >= 2 a_fold ? 2 a_fold : 0), i.e. [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]; 0 = plain   // out_scale: accumulators x this before the epilogue functor (split fp32 form; 1 elsewhere)
 // One workgroup = one tile: `bid` of `nwg` logical workgroups that tile rows [m_begin, M).  A device function so that one launch
 // can hold workgroups of two tile shapes (gemm_bf16_rows_kernel below).
@@ -496,7 +511,7 @@ struct CatArgs { const bf16* A2; const bf16* W2; const int* a2_map; float out_sc
 // f16 MFMA per 64 k: the lane's 32 operand bytes are its two 16-B fragment chunks {g, 4 + g} of the row (the same k subset on both
 // sides, so the order inside the tile does not matter).  The E8M0 scale operand takes the images' powers of two back out:
 // 2^-(ew+11) for the A_hi8 x W_lo8 tiles (first half), 2^-(ew+12) for the A_lo8 x W_hi8 tiles.
-template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT, bool F8 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL, bool CAT, bool F8 = false, int LEAD = 0>
 __device__ __forceinline__ void gemm_bf16_nt_tile(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, int m_begin, const Epi& epi, const CatArgs& cat, int bid, int nwg) {
@@ -509,6 +524,7 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
     constexpr bool BOTH_KS = (TM + TN) * 2 * 4 <= 72;  // hold both k-substeps' fragments when registers allow
     static_assert(!(F8 && CAT), "the fp8-correction form has no leading k-tile variant");
+    static_assert(!(LEAD && CAT) && (LEAD == 0 || LEAD == 3), "LEAD: three leading tiles of a three-part product, split forms only");
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -649,6 +665,42 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (LEAD > 0) {
+        // ---- leading tiles of the second operand pair (see CatArgs): synchronous, slot 0 of the ring
+#pragma unroll 1
+        for (int t = 0; t < LEAD; ++t) {
+            const int ac = t == 2 ? BK : 0, wc = t == 1 ? BK : 0;   // [A2_hi | A2_hi | A2_lo] x [W2_hi | W2_lo | W2_hi]
+#pragma unroll
+            for (int q = 0; q < A_INSTR; ++q) {
+                int grow = min(m0 + (q * NW + wave) * 8 + lrow, Mv - 1);
+                if (cat.a2_map) grow = cat.a2_map[grow];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.A2 + (size_t)grow * (2 * BK) + ac + chunk * 8),
+                                                 (__attribute__((address_space(3))) void*)(smem + (q * NW + wave) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < B_INSTR; ++q) {
+                const int row = (q * NW + wave) * 8 + lrow;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.W2 + (size_t)(n0 + row) * (2 * BK) + wc + chunk * 8),
+                                                 (__attribute__((address_space(3))) void*)(smem + A_BYTES + (q * NW + wave) * 1024), 16, 0, 0);
+            }
+            dma_wait_all();
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = (ks == 0 ? fslot0 : fslot1) * 16;
+                bf16x8 la[TM], lw[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) la[i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 2048 + so);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) lw[j] = *reinterpret_cast<const bf16x8*>(smem + b_off + j * 2048 + so);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = DYT_MFMA_16x16x32(lw[j], la[i], acc[i][j]);
+            }
+            __syncthreads();   // every wave's reads of slot 0 have returned before it is overwritten
+        }
+    }
     const int nk = K / BK + (CAT ? 1 : 0);
     if (ABL == 9) t_loop0 = __builtin_readcyclecounter();
     // fp8 tiles: E8M0 scale operands of the two correction products (the W fragment is the MFMA's A operand: the whole factor goes there)
@@ -1011,12 +1063,12 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false, bool F8 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, class Epi, int ABL = 0, bool CAT = false, bool F8 = false, int LEAD = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, const int* __restrict__ m_dev,
     const int* __restrict__ a_map, int m_begin, Epi epi, CatArgs cat) {
     // rows [m_begin, M) are tiled by this launch
-    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT, F8>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x);
+    gemm_bf16_nt_tile<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT, F8, LEAD>(A, W, M, N, K, m_dev, a_map, m_begin, epi, cat, blockIdx.x, gridDim.x);
 }
 
 // Narrow-N GEMM (N = 768) in ONE launch: the first n_big workgroups take 256x256 tiles of rows [0, body) -- whole rounds of the
@@ -1050,14 +1102,14 @@ long long gemm_kernel_launch_count(int reset) {
     return n;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi, bool CAT = false, bool F8 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL, class Epi, bool CAT = false, bool F8 = false, int LEAD = 0>
 static int launch_bf16_cfg(const GemmArgs& a, const Epi& epi, hipStream_t s, int m_begin = 0, int m_end = -1) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     if (m_end < 0) m_end = a.M;
     if (m_end <= m_begin) return 0;
     const int grid = ((m_end - m_begin + BM - 1) / BM) * (a.N / BN);
     const size_t lds = 2 * (BM + BN) * 64 * 2;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT, F8>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, Epi, ABL, CAT, F8, LEAD>;
     static bool attr_set[64] = {};   // per device: the attribute belongs to the (kernel, device) pair
     int dev = 0;
     DYT_HIP_CHECK(hipGetDevice(&dev));
@@ -1127,29 +1179,30 @@ static int g_use_bpre = 1;        // wide-N GEMMs with a pre-shuffled frozen wei
 static int g_split_rows = 1;      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
 
 // the "fp16f8" split contraction (a.K = 2 x the logical K: K / 64 f16 tiles + K / 64 fp8 tiles): tile shapes as for the three-part form
-template <class Epi>
+template <class Epi, int LEAD = 0>
 static int run_f8(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 256 != 0 || a.M <= 0 || a.N % 128 != 0 || a.f8_begin * 128 != a.K) { set_error("gemm f8 form: K=%d N=%d M=%d", a.K, a.N, a.M); return -1; }
-    if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 2048 && !a.a_map) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true>(a, epi, s);
+    if (LEAD && (!a.A2 || !a.W2)) { set_error("gemm f8 form: leading tiles need A2 and W2"); return -1; }
+    if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 2048 && !a.a_map) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true, LEAD>(a, epi, s);
     if (a.N % 256 == 0 && !a.a_map) {   // (the 256x256 fp8 kernel takes no row gather)
         constexpr int NCU = 256;
         const int tn = a.N / 256, t256 = ((a.M + 255) / 256) * tn, rounds = t256 / NCU, rem = t256 - rounds * NCU;
         if (rounds >= 1 || rem >= 3 * NCU / 4) {
-            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true>(a, epi, s);
+            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true, LEAD>(a, epi, s);
             const int body = (rounds * NCU / tn) * 256;
-            int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true>(a, epi, s, 0, body);
+            int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true, LEAD>(a, epi, s, 0, body);
             if (rc) return rc;
-            return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true>(a, epi, s, body, a.M);
+            return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true, LEAD>(a, epi, s, body, a.M);
         }
     }
-    return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true>(a, epi, s);
+    return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true, LEAD>(a, epi, s);
 }
 
 // wide-N GEMM against a pre-shuffled frozen weight -> gemm_bf16_bpre_kernel (see run_bf16)
 static bool takes_bpre(const GemmArgs& a, bool k768 = false) {
     return a.Wp && g_use_bpre && a.N % 256 == 0 && a.K % 256 == 0 && (a.N >= g_big_tile_min_n || k768) && a.M >= 2048;
 }
-template <class Epi, bool CAT = false>
+template <class Epi, bool CAT = false, int LEAD = 0>
 static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0) { set_error("gemm_bf16: K=%d must be a multiple of 64, M=%d", a.K, a.M); return -1; }
     if constexpr (SplitKEpi<Epi>::value) {
@@ -1170,6 +1223,8 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     }
     if constexpr (CAT) {
         if (!a.A2 || !a.W2 || a.N % 128 != 0) { set_error("gemm_bf16: K-concatenated form needs A2, W2 and N %% 128 == 0 (N=%d)", a.N); return -1; }
+    } else if constexpr (LEAD > 0) {
+        if (!a.A2 || !a.W2 || a.N % 128 != 0 || !a.a_fold) { set_error("gemm_bf16: leading three-part tiles need A2, W2, the split form and N %% 128 == 0 (N=%d)", a.N); return -1; }
     } else {
         if (a.A2) { set_error("gemm_bf16: this epilogue has no K-concatenated form"); return -1; }
     // Wide-N GEMMs against a frozen weight: the pre-shuffled-weight kernel (128x256 tiles, two workgroups per CU, the
@@ -1196,16 +1251,16 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         // one-part split GEMMs with a wide N (GELU' dgrad of "fp16x3f": 12 k-tiles against an epilogue that reads gelu' and writes dZ):
         // the 256x256 kernel's exposed epilogue outweighs its main loop -> 128x128 tiles, two workgroups per CU (DYT_SPLIT_SHORTK_SMALL=0: off)
         static const int shortk_small = getenv("DYT_SPLIT_SHORTK_SMALL") ? atoi(getenv("DYT_SPLIT_SHORTK_SMALL")) : 1;   // 2: the N = 768 ones (proj dgrad) too
-        if (shortk_small && a.a_ld && a.K <= D && (a.N >= g_big_tile_min_n || shortk_small == 2) && a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
+        if (LEAD == 0 && shortk_small && a.a_ld && a.K <= D && (a.N >= g_big_tile_min_n || shortk_small == 2) && a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
     }
-    if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
+    if (a.N % 256 == 0 && a.N >= g_big_tile_min_n && a.M >= 2048) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT, false, LEAD>(a, epi, s);
     if constexpr (!CAT) {
         // K <= 768, N = 768 with a residual epilogue (proj forward, patch embedding): 12 k-steps against an epilogue that moves 194 MB -- the
         // launch is bound by its epilogue traffic, and 1182 tiles of 128x128 on 512 slots interleave main loops and epilogues where 255 big
         // tiles run them as two chip-wide phases: 74.6 vs 59 + 20.5 us (256x256 body + 128x128 row tail), step 24.98 vs 25.03 ms same-box,
         // one launch instead of two; same k order, same bits.  DYT_SHORTK_N768_SMALL=0: the split-row scheme for these too
         static const int shortk_n768 = getenv("DYT_SHORTK_N768_SMALL") ? atoi(getenv("DYT_SHORTK_N768_SMALL")) : 1;
-        if (shortk_n768 && a.K <= D && a.N % 128 == 0 && a.M >= 2048 && !a.a_ld) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
+        if (LEAD == 0 && shortk_n768 && a.K <= D && a.N % 128 == 0 && a.M >= 2048 && !a.a_ld) return launch_bf16_cfg<128, 128, 2, 2, 0>(a, epi, s);
     }
     if (a.N % 256 == 0 && a.K >= 256 && g_split_rows) {
         // Narrow-N GEMMs (N = 768): per row, 256x256 tiles are ~1.6x cheaper than 128x128 tiles (half the L2->LDS bytes
@@ -1217,20 +1272,20 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
         constexpr int NCU = 256;
         const int tn = a.N / 256, t256 = ((a.M + 255) / 256) * tn, rounds = t256 / NCU, rem = t256 - rounds * NCU;
         if (rounds >= 1 || rem >= 3 * NCU / 4) {
-            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s);
+            if (rem == 0 || rem >= 3 * NCU / 4) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT, false, LEAD>(a, epi, s);
             const int body = (rounds * NCU / tn) * 256;
             // DYT_GEMM_ROWS_ONE_LAUNCH=1: both tile shapes in one launch (gemm_bf16_rows_kernel).  Measured: serial step 29.48 -> 28.92 ms
             // (no second launch, no empty tail launches of compacted GEMMs), but the overlapped step 26.2-26.4 -> 26.7 ms: the tail
             // workgroups then hold 128 KB of LDS like the big ones and keep the other pass's 64 KB kernels off their CUs.  Off.
             static const bool one_launch = getenv("DYT_GEMM_ROWS_ONE_LAUNCH") && atoi(getenv("DYT_GEMM_ROWS_ONE_LAUNCH"));
-            if (one_launch) return launch_bf16_rows<Epi, CAT>(a, epi, s, body);
-            int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT>(a, epi, s, 0, body);
+            if constexpr (LEAD == 0) { if (one_launch) return launch_bf16_rows<Epi, CAT>(a, epi, s, body); }
+            int rc = launch_bf16_cfg<256, 256, 2, 4, 0, Epi, CAT, false, LEAD>(a, epi, s, 0, body);
             if (rc) return rc;
-            return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT>(a, epi, s, body, a.M);
+            return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT, false, LEAD>(a, epi, s, body, a.M);
         }
     }
-    if (a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT>(a, epi, s);
-    if constexpr (!CAT) { if (a.N % 64 == 0) return launch_bf16_cfg<128, 64, 2, 2, 0>(a, epi, s); }
+    if (a.N % 128 == 0) return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, CAT, false, LEAD>(a, epi, s);
+    if constexpr (!CAT && LEAD == 0) { if (a.N % 64 == 0) return launch_bf16_cfg<128, 64, 2, 2, 0>(a, epi, s); }
     set_error("gemm_bf16: N=%d must be a multiple of 64", a.N);
     return -1;
 }
@@ -1275,11 +1330,11 @@ template <> struct F8Epi<EpiAdUp<true>> : std::true_type {};    // cls-row proj 
 template <> struct F8Epi<EpiEmbed> : std::true_type {};
 template <> struct F8Epi<EpiBiasF32> : std::true_type {};       // unit entry dyt_linear_split
 // SPLIT: fp32 epilogue functors on the 16-bit MFMA kernels (the fp32 operands arrive as K-concatenated 16-bit hi / lo parts)
-template <class AT, bool SPLIT, class Epi>
+template <class AT, bool SPLIT, class Epi, int LEAD = 0>
 static int run(const GemmArgs& a, const Epi& epi, hipStream_t s) {
-    if constexpr (SPLIT && F8Epi<Epi>::value) { if (a.f8) return run_f8(a, epi, s); }
+    if constexpr (SPLIT && F8Epi<Epi>::value) { if (a.f8) return run_f8<Epi, LEAD>(a, epi, s); }
     if (a.f8) { set_error("gemm: this epilogue has no fp8-correction form"); return -1; }
-    if constexpr (sizeof(AT) == 2 || SPLIT) return run_bf16(a, epi, s);
+    if constexpr (sizeof(AT) == 2 || SPLIT) return run_bf16<Epi, false, LEAD>(a, epi, s);
     else return run_f32(a, epi, s);
 }
 
@@ -1333,8 +1388,18 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
                     if (!a.row_map && !a.row_mask)
                         return run_bf16<EpiFc2<AT, true>, true>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
                     return run_bf16<EpiFc2<AT, false>, true>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
+                } else if constexpr (SPLIT) {
+                    // split fp32 forms whose backward runs on 16-bit operands: the up-projection as three leading tiles of a three-part product (CatArgs: LEAD)
+                    if (!a.save16) {   // passes that save nothing (evaluation): the MLP output, if wanted at all, in fp32
+                        if (!a.row_map && !a.row_mask)
+                            return run<AT, SPLIT, EpiFc2<AT, true>, 3>(a, EpiFc2<AT, true>{a.bias, a.out_f32, nullptr, nullptr, (AT*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
+                        return run<AT, SPLIT, EpiFc2<AT, false>, 3>(a, EpiFc2<AT, false>{a.bias, a.out_f32, a.row_map, a.row_mask, (AT*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
+                    }
+                    if (!a.row_map && !a.row_mask)
+                        return run<AT, SPLIT, EpiFc2<AT, true, bf16>, 3>(a, EpiFc2<AT, true, bf16>{a.bias, a.out_f32, nullptr, nullptr, (bf16*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
+                    return run<AT, SPLIT, EpiFc2<AT, false, bf16>, 3>(a, EpiFc2<AT, false, bf16>{a.bias, a.out_f32, a.row_map, a.row_mask, (bf16*)a.h_out, resid, a.bias2, a.scale, a.row_scale}, s);
                 } else {
-                    set_error("gemm: the K-concatenated fc2 form exists in the 16-bit modes only");
+                    set_error("gemm: the K-concatenated fc2 form exists in the 16-bit and the 16-bit-backward split modes only");
                     return -1;
                 }
             }
@@ -1354,12 +1419,12 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
         case EPI_STORE_AT: return run<AT, SPLIT>(a, EpiStoreAT<AT>{(AT*)a.out_at, a.N}, s);
         case EPI_AD_DOWN:
             if constexpr (!SPLIT && sizeof(AT) == 4) {
-                if (a.save16) return run<AT, SPLIT>(a, EpiAdDown<AT, bf16>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (bf16*)a.out_at2, a.scale}, s);
+                if (a.save16) return run<AT, SPLIT>(a, EpiAdDown<AT, bf16>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (bf16*)a.out_at2, a.scale, (bf16*)a.out3, a.out3_scale}, s);
             }
-            return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (AT*)a.out_at2, a.scale}, s);
+            return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (AT*)a.out_at2, a.scale, (bf16*)a.out3, a.out3_scale}, s);
         case EPI_AD_UP:
             if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr, a.row_scale}, s);
-            return run<AT, SPLIT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask}, s);
+            return run<AT, SPLIT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask, nullptr, a.bias_scale}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT, SPLIT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);
         case EPI_EMBED: return run<AT, SPLIT>(a, EpiEmbed{a.bias, a.pos, a.out_f32}, s);
@@ -1515,7 +1580,7 @@ int launch_split3_w(const float* W, void* W3, int N, int K, hipStream_t s) {
 
 int launch_gemm(int precision, EpiKind kind, const GemmArgs& a, hipStream_t s) {
     if (precision == 0 && a.W3 && a.a3) {
-        if (a.K % 64 != 0 || a.A2) { set_error("gemm split form: K=%d %% 64", a.K); return -1; }
+        if (a.K % 64 != 0 || (a.A2 && kind != EPI_FC2)) { set_error("gemm split form: K=%d %% 64", a.K); return -1; }
         const size_t tasks = (size_t)a.M * (a.K / 8);
         if (!a.a3_ready)
         hipLaunchKernelGGL(split3_a_kernel, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(a.A), a.a_map,

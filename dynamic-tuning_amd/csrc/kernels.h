@@ -80,6 +80,7 @@ struct GemmArgs {
     const float* pos = nullptr;       // EMBED
     int r = 0;                        // adapter rank (columns >= r of the padded bottleneck are dead)
     float scale = 1.f;
+    float bias_scale = -1.f;          // AD_UP: the bias enters as bias_scale * bias instead of scale * bias (>= 0: set; the operand then carries the adapter scale itself)
     float inv_keep = 1.f;             // 1/(1-p) when training, else 1
     float drop_p = 0.f;               // >0 : apply dropout (Philox when keep == null)
     uint64_t seed = 0, subseq = 0;

@@ -160,6 +160,7 @@ struct LayerS {  // saved activations of one pass
 struct Transients {  // scratch of one pass (per slot, so two passes can run on two streams)
     void *xn, *h1, *g_at, *dZ, *ddz, *du_at, *dO, *dqkv, *dA2, *dxn, *dad;
     void* dact_s = nullptr;   // 16-bit modes: adapter_scale * d_act, the A2 operand of the fc2 + up-projection contraction
+    void* dact3 = nullptr;    // 16-bit-backward split modes: the same as a [M][hi 64 | lo 64] image (three-part up-projection, alone or as the fc2 GEMM's leading tiles)
     void* a3 = nullptr;   // fp32 mode: [M, 3 * 3072] 16-bit scratch for the split A operand of a GEMM
     void* g3 = nullptr;   // [M, 3*768]: the gradient stream as a split operand, written by ln_bwd (next block's GELU' dgrad) and tok_bwd (proj dgrad); attention output in the forward pass
     void *xn3 = nullptr, *h3 = nullptr, *dqkv3 = nullptr;   // dqkv3: [M, 3*2304] from the attention backward   // ... and the split operands producers write directly: LN output [M, 3*768], fc1 output / dZ [M, 3*3072]
@@ -224,6 +225,7 @@ struct dyt_ctx {
     int* pe_w_exp = nullptr; unsigned* f8_scratch = nullptr;
     bool bwd16 = false;         // "fp16x3h": the fp16x3 forward, the backward on the 16-bit mode's operands and kernels (DYT_OPT_F32_SPLIT16 = 3)
     void *ad_up_wT16 = nullptr, *ad_down_wT16 = nullptr, *ad_scratch16 = nullptr;   // bwd16: per-step 16-bit copies of the adapter matrices the dgrads read
+    void* ad_up_w3 = nullptr;   // bwd16: [depth][768][hi 64 | lo 64] image of the (fp32) up-projection copies: the three-part up-projection's weight operand
     // frozen
     float *cls, *pos, *pe_b, *norm_w, *norm_b;
     void* pe_w;
@@ -462,6 +464,7 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
         c->ad_up_wT16 = carve<uint16_t>(c, depth * RP * D, dry);
         c->ad_down_wT16 = carve<uint16_t>(c, depth * RP * D, dry);
         c->ad_scratch16 = carve<uint16_t>(c, 2 * depth * RP * D, dry);   // the two layouts of prep_adapters_kernel the backward does not read
+        c->ad_up_w3 = carve<uint16_t>(c, SA * depth * RP * D, dry);
     }
     for (int sl = 0; sl < cf.slots; ++sl) {
         Slot& S = c->slots[sl];
@@ -473,6 +476,7 @@ static void layout_aux(dyt_ctx* c, bool dry, bool bwd16) {
         T.h3 = carve<uint16_t>(c, Mp * SA * DM, dry);
         T.dqkv3 = carve<uint16_t>(c, M * SA * 3 * D, dry);
         if (!bwd16) continue;
+        T.dact3 = carve<uint16_t>(c, Mp * SA * RP, dry);
         T.dad16 = carve<uint16_t>(c, M * D, dry);
         T.qlo = carve<uint16_t>(c, M * D, dry); T.klo = carve<uint16_t>(c, M * D, dry); T.vlo = carve<uint16_t>(c, M * D, dry);
         S.ucls16 = carve<uint16_t>(c, B * D, dry);
@@ -989,6 +993,10 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
             hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                                c->off_uw, c->cfg.ffn_num, scr, (bf16*)c->ad_down_wT16, scr + (size_t)c->cfg.depth * RP * D,
                                (bf16*)c->ad_up_wT16, c->ad_down_b, (bf16*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
+            if (c->ad_up_w3) {   // [hi | lo] image of the fp32 up-projection copies just written (all blocks: depth * 768 rows of 64)
+                int rc = launch_split3_w((const float*)c->ad_up_w, c->ad_up_w3, c->cfg.depth * D, RP, s);
+                if (rc) return rc;
+            }
         }
     } else
         hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
@@ -1245,7 +1253,13 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // backward operands give for 128 B per token (TokBwdArgs::cat_*).  The masked mode keeps the two-launch form.
         const bool need_h = save && !complete && !tail;
         const bool cat = c->fc2_cat && P != 0 && !masked_dense && !dp2;   // (a scaled MLP branch cannot share its accumulator with the adapter's)
-        L.h_has_adapter = cat && need_h;   // the saved "MLP output" of this block then includes the adapter: tok_bwd corrects <g, h>
+        // Split fp32 forms whose backward runs on 16-bit operands ("fp16x3h", "fp16f8", "fp16x3q"; round 6): the same fusion with the up-projection as a
+        // THREE-part product -- s d_act leaves the down-projection epilogue as a [hi | lo] image, W_up is split once per step (prep_adapters) --
+        // contracted by the fc2 kernel as three leading tiles in front of its main loop (gemm.hip: LEAD); the dropped tokens' up-projection launch
+        // runs on the same two images.  Until round 5 these modes ran the up-projection on the exact-fp32 MFMA kernel: an fp32
+        // read-modify-write of [M,768] per block and pass (47 us) in front of the fc2 epilogue's own.
+        const bool cat3 = c->fc2_cat && P == 0 && c->split16 && c->bwd16 && T.dact3 && c->ad_up_w3 && !masked_dense && !dp2;
+        L.h_has_adapter = (cat || cat3) && need_h;   // the saved "MLP output" of this block then includes the adapter: tok_bwd corrects <g, h>
         FORK(sb);
         {
             GemmArgs a; a.A = tail ? S.ucls_at : L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
@@ -1256,12 +1270,14 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.seed = seed; a.subseq = ((uint64_t)slot << 32) | (uint64_t)(l * 2 + 1); a.seed_dev = seed_dev;
             if (cat) { a.out_at2 = T.dact_s; a.scale = ad_scale; }
             if (save16) { a.out_at2 = L.dact16; a.scale = 1.0f; a.save16 = true; }
+            if (cat3) { a.out3 = T.dact3; a.out3_scale = ad_scale; }
             RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DOWN, a, s));
         }
         GemmArgs up; up.A = L.d_act; up.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); up.M = Mr; up.N = D; up.K = RP;
         up.bias = up_bias; up.resid = L.u; up.out_f32 = xo; up.scale = ad_scale;
         up.row_map = tail ? c->cls_rows : nullptr;
-        if (!cat) RUN_ON(sb, 0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
+        if (!cat && !cat3) RUN_ON(sb, 0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
+        const uint16_t* up_w3 = cat3 ? (const uint16_t*)c->ad_up_w3 + (size_t)l * SPLIT_A * RP * D : nullptr;
         int* counts = S.counts + (size_t)l * B;
         if (use_gate) {
             GateArgs ga;
@@ -1306,8 +1322,10 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             RUN_GEMM(EPI_FC1, a);
         }
         JOIN(sb);  // x_out now holds u + adapter(u) (two-launch form) / d_act is complete
-        if (cat && !dense && !tail) {   // dropped tokens: x_out = u + adapter(u) (the kept ones are written by fc2 below)
-            if (fold2) {   // over the dispatcher's list of dropped rows (gather + scatter) instead of every row with the kept ones skipped
+        if ((cat || cat3) && !dense && !tail) {   // dropped tokens: x_out = u + adapter(u) (the kept ones are written by fc2 below)
+            if (cat3) {   // three-part on the [hi | lo] images; the operand carries the adapter scale, the bias takes it in the epilogue
+                up.W3 = up_w3; up.a3 = T.dact3; up.a3_ready = true; up.scale = 1.0f; up.bias_scale = ad_scale; up.row_mask = L.maskf;
+            } else if (fold2) {   // over the dispatcher's list of dropped rows (gather + scatter) instead of every row with the kept ones skipped
                 up.a_map = T.drop_src; up.row_map = T.drop_src; up.m_dev = L.total + 1;
             } else {
                 up.row_mask = L.maskf;
@@ -1322,6 +1340,11 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
             a.h_out = need_h ? L.h : nullptr;                           // cls rows carry no gate gradient
             if (save16 && need_h) { a.h_out = L.h16; a.save16 = true; }
             SPLIT_F(a, W.fc2_w3, W.fc2_w3b, 3); SPLIT_READY(a, T.h3);
+            if (cat3) {
+                a.A2 = T.dact3; a.W2 = up_w3;
+                a.a2_map = (dense || tail) ? nullptr : L.row_src;
+                a.bias2 = up_bias; a.scale = ad_scale; a.resid = L.u;
+            }
             if (cat) {
                 a.A2 = T.dact_s; a.W2 = at_off(c, c->ad_up_w, (size_t)l * RP * D);   // [s d_act | h] x [W_up | W2]^T
                 a.a2_map = (dense || tail) ? nullptr : L.row_src;   // d_act is indexed by token (cls tail: by image, like h1)

@@ -429,6 +429,111 @@ def _check_supported(model, criterion):
                                       "not supported" % (n, p.requires_grad))
 
 
+class DevicePrefetcher:
+    """Input feeding of the step loop (reference engine_finetune.py:34-42: ``samples.to(device, non_blocking=True)`` inside the
+    loop, on the compute stream -- 77 MB per B=128 step, stream-ordered in front of the step's first kernel).
+
+    Here the host->device copy of batch i+1 is issued on a COPY stream into the other of two device buffers while step i is
+    still running, and handed over by events: the compute stream waits for ``ready[k]`` (the copy), the copy stream waits for
+    ``free[k]`` (recorded on the compute stream after the step that read buffer k was enqueued) before it overwrites a buffer.
+    The buffers are allocated once per shape, so the caching allocator never sees cross-stream reuse.  Sources are expected
+    in pinned memory (the drivers' DataLoaders use ``pin_memory=True``, main_image.py:172); pageable sources still work, the
+    runtime then stages them.  Tensors that already live on the device pass through untouched.
+
+    The copy stream must not share a hardware queue with any stream of the step (HIP maps streams onto GPU_MAX_HW_QUEUES queues;
+    on a shared queue the copy's wait for ``free[k]`` holds up the step's second pass stream: 29.6 instead of 23.7 ms per step,
+    measured), so it is CHOSEN by measurement: ``pick_stream(samples, targets)`` is called once, with the first batch on the
+    device, and returns a verified stream (DyTEngine.find_independent_stream) or None -- then, and for the first batch, the
+    copy stays on the compute stream, the reference's placement.  Iterating yields ``(index, samples, targets, rest_of_batch)``;
+    the yielded device tensors are valid until the iteration after next."""
+
+    def __init__(self, loader, device, pick_stream=None, slots=2):
+        self.loader, self.device, self.slots = loader, torch.device(device), int(slots)
+        self.on = self.device.type == "cuda" and os.environ.get("DYT_PREFETCH", "1") != "0" and pick_stream is not None
+        self.pick_stream = pick_stream
+        self.copy_stream = None
+        self.buf = [[None, None] for _ in range(self.slots)]
+        self.ready = [None] * self.slots
+        self.free = [None] * self.slots
+        self.copied_bytes = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _into(self, k, j, t):
+        if not torch.is_tensor(t) or t.device == self.device:
+            return t
+        b = self.buf[k][j]
+        if b is None or b.dtype != t.dtype or b.numel() < t.numel():
+            b = self.buf[k][j] = torch.empty(max(t.numel(), 1), dtype=t.dtype, device=self.device)
+        dst = b[:t.numel()].view(t.shape)
+        dst.copy_(t, non_blocking=True)
+        self.copied_bytes += t.numel() * t.element_size()
+        return dst
+
+    def __iter__(self):
+        asked = False
+        if self.on and self.copy_stream is None:
+            self.copy_stream = self.pick_stream(None, None)   # a stream verified earlier (previous epoch): the first batch is prefetched too
+        for it, batch in enumerate(self.loader):
+            if self.copy_stream is None:   # the reference's placement: on the compute stream, in front of the step
+                xs, ys = batch[0].to(self.device, non_blocking=True), batch[1].to(self.device, non_blocking=True)
+                if self.on and not asked and xs is not batch[0]:
+                    asked = True
+                    self.copy_stream = self.pick_stream(xs, ys)
+                yield it, xs, ys, tuple(batch[2:])
+                continue
+            k = it % self.slots
+            cur = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self.copy_stream):
+                if self.free[k] is not None:
+                    self.copy_stream.wait_event(self.free[k])     # the step that read this buffer has finished on the device
+                elif self.buf[k][0] is None:
+                    self.copy_stream.wait_stream(cur)             # first use: order the allocation behind what the compute stream holds
+                xs, ys = self._into(k, 0, batch[0]), self._into(k, 1, batch[1])
+                if self.ready[k] is None:
+                    self.ready[k] = torch.cuda.Event()
+                self.ready[k].record(self.copy_stream)
+            cur.wait_event(self.ready[k])
+            yield it, xs, ys, tuple(batch[2:])
+            # resumed by the consumer's next(): its step on buffer k is enqueued on the compute stream by now
+            if self.free[k] is None:
+                self.free[k] = torch.cuda.Event()
+            self.free[k].record(torch.cuda.current_stream(self.device))
+
+
+def _copy_stream_picker(model, criterion, masked=None):
+    """pick_stream of the training loop's DevicePrefetcher: the engine's verified copy stream, found once per engine by timing a
+    side-effect-free step (gradients into the engine's buffer, which the next real step overwrites; no optimizer update)."""
+    m = getattr(model, "module", model)
+
+    def pick(samples, targets):
+        if samples is None:   # only what is already known
+            return getattr(getattr(m, "_engine", None), "_copy_stream_probe", (None, None))[0]
+        x = m.fold_input(samples.float()).contiguous()
+        eng = m.engine(x.shape[0], x.device)
+        if not hasattr(eng, "_copy_stream_probe"):
+            scratch = torch.zeros(8, device=x.device)
+            tr = getattr(criterion, "token_target_ratio", 0.5)
+
+            def run():
+                eng.step_fwd_bwd(x, targets, tr, 2.0, 0.0, 0.0, masked_dense=(m.train_mode == "masked"), seed=12345, losses=scratch)
+            eng._copy_stream_probe = eng.find_independent_stream(run)
+            if eng._copy_stream_probe[0] is None:
+                import warnings
+                warnings.warn("no stream runs beside the step's own (GPU_MAX_HW_QUEUES=%s, probe %s): input batches are copied on the compute "
+                              "stream" % (os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"), eng._copy_stream_probe[1]))
+        return eng._copy_stream_probe[0]
+    return pick
+
+
+def _verified_copy_stream(model):
+    """pick_stream of the evaluation loops: the copy stream a training epoch has verified for this engine, if any (a stream that runs
+    beside every stream of the training step also runs beside the forward pass's)."""
+    m = getattr(model, "module", model)
+    return lambda samples=None, targets=None: getattr(getattr(m, "_engine", None), "_copy_stream_probe", (None, None))[0]
+
+
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
                     mixup_fn=None, log_writer=None, args=None, logger=None):
     """Reference engine_finetune.py:16-106.  ``optimizer`` is the ``torch.optim.AdamW`` the drivers build (main_image.py:285;
@@ -455,15 +560,13 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     count, pending = 0, 0
     t0 = time.time()
     lr = optimizer.param_groups[0]["lr"]
-    for it, batch in enumerate(data_loader):
-        samples, targets = batch[0], batch[1]
+    # batch i+1 travels host -> device on a copy stream while step i runs (DevicePrefetcher); the reference's loop copies on the compute stream
+    for it, samples, targets, extra in DevicePrefetcher(data_loader, device, _copy_stream_picker(model, criterion)):
         # parity tests may append the random draws to inject: (samples, targets, (g1, g2), keep_mask)
-        gumbel = tuple(t.to(device).contiguous() for t in batch[2]) if len(batch) > 2 and batch[2] is not None else None
-        keep_mask = batch[3].to(device).contiguous() if len(batch) > 3 and batch[3] is not None else None
+        gumbel = tuple(t.to(device).contiguous() for t in extra[0]) if len(extra) > 0 and extra[0] is not None else None
+        keep_mask = extra[1].to(device).contiguous() if len(extra) > 1 and extra[1] is not None else None
         if it % accum_iter == 0:   # per-iteration schedule, reference :43-46
             lr = lr_sched.adjust_learning_rate(optimizer, it / nsteps + epoch, args)
-        samples = samples.to(device, non_blocking=True)
-        targets = targets.to(device, non_blocking=True)
         train_step(model, samples, targets, optimizer, criterion, losses_out=step_losses, seed=step_seed(epoch, it),
                    gumbel=gumbel, keep_mask=keep_mask, accumulate=(it % accum_iter != 0), update=((it + 1) % accum_iter == 0),
                    accum_iter=accum_iter, max_norm=max_norm or 0.0, graph=use_graph)
@@ -530,13 +633,11 @@ def evaluate(data_loader, model, device, logger=None, base_flops=None, flops_dic
     top-1 (or mean-per-class) accuracy in ``status["metric"]``."""
     model.eval()
     token_select, targets, predictions = [], [], []
-    for batch in data_loader:
-        images = batch[0].to(device, non_blocking=True)
-        target = batch[1].to(device, non_blocking=True)
+    for _, images, target, _ in DevicePrefetcher(data_loader, device, _verified_copy_stream(model)):
         output, aux = model(images)
         token_select.append(aux["token_select"].to(torch.uint8))  # {0,1}: 4x smaller gather than the reference's fp32
         predictions.append(output)
-        targets.append(target)
+        targets.append(target.clone())   # (the prefetcher's buffer is reused two batches later)
     targets = torch.cat(targets, dim=0)
     predictions = torch.cat(predictions, dim=0)
     token_select = torch.cat(token_select, dim=0)
@@ -564,9 +665,8 @@ def evaluate_video(data_loader, model, device, logger=None, base_flops=None, flo
     the per-view logits averaged per sample (:302-305), then the same gather + accuracy as ``evaluate``."""
     model.eval()
     token_select, targets, predictions = [], [], []
-    for batch in data_loader:
-        images = batch[0].to(device, non_blocking=True)
-        target = batch[1].to(device, non_blocking=True)
+    for _, images, target, _ in DevicePrefetcher(data_loader, device, _verified_copy_stream(model)):
+        target = target.clone()
         B, V = images.shape[0], images.shape[1]
         output, aux = model(images.flatten(0, 1))
         predictions.append(output.view(B, V, -1).mean(dim=1))

@@ -355,6 +355,44 @@ class DyTEngine:
             self.comm_stream_verified = self._comm_stream is not tried[0] or len(tried) == 1 or self.streams_concurrent(cur, self._comm_stream)
         return self._comm_stream
 
+    def find_independent_stream(self, run_step, tries=8, slack=1.2):
+        """A stream whose queued work does NOT hold up any stream the step uses -- for the host->device copies of the next batch
+        (engine_finetune.DevicePrefetcher).  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, and work on two
+        streams of one queue runs in order: a copy stream that lands on the queue of the step's second pass stream serialises the two
+        passes (measured: 29.6 instead of 23.7 ms per step).  The library's internal streams are not visible from here, so the test is
+        end to end: `run_step()` (one side-effect-free dyt_step_fwd_bwd) is timed with a ~2.5-step spin kernel parked on the candidate;
+        a candidate on any of the step's queues makes the step wait for the spin.  Returns (stream or None, report)."""
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+
+        def timed(spin_stream, cycles=0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            if spin_stream is not None:
+                with torch.cuda.stream(spin_stream):
+                    torch.cuda._sleep(cycles)
+            e0.record(cur)
+            run_step()
+            e1.record(cur)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1)
+        with torch.cuda.device(dev):
+            run_step()                                   # warm-up: kernel attributes, internal streams / events
+            base = min(timed(None), timed(None))
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # cycles per ms of the spin kernel's counter
+            c0.record(cur); torch.cuda._sleep(2_000_000); c1.record(cur); torch.cuda.synchronize(dev)
+            per_ms = 2_000_000 / max(c0.elapsed_time(c1), 1e-3)
+            cycles = int(2.5 * base * per_ms)
+            report = dict(base_ms=round(base, 3), tried=[])
+            for _ in range(tries):
+                st = torch.cuda.Stream(dev)
+                t = timed(st, cycles)
+                report["tried"].append(round(t, 3))
+                if t < slack * base:
+                    report["picked"] = len(report["tried"]) - 1
+                    return st, report
+        return None, report
+
     def allreduce_native(self, overlap=True):
         """dyt_allreduce_grads: SUM of the flat gradient over the ranks on the library's own RCCL communicator (created on
         first use over the default torch.distributed group); the upper part on the communication stream when `overlap`."""

@@ -146,7 +146,7 @@ def test_vtab_task_shapes_vs_oracle(B, C):
 
 
 @pytest.mark.parametrize("precision,mode", [("fp32", "compact"), ("bf16", "compact"), ("bf16", "masked"), ("fp16", "compact"), ("fp16x3h", "compact"),
-                                            ("fp16f8", "compact")])
+                                            ("fp16f8", "compact"), ("fp16x3q", "compact"), ("fp16x3q", "masked")])   # fp16x3q = bench.py's parity_mode (round 6)
 def test_full_size_backward_is_additive_over_sub_batches(precision, mode):
     """B=128 (the bench size): the gradient of the full batch for an injected upstream gradient equals the sum over 8
     sub-batches of 16 images (images never interact; only the summation order of the weight-gradient reductions differs).

@@ -189,12 +189,18 @@ def test_fp16x3f_forward_is_bitwise_the_fp16x3_forward(B):
     """DYT_OPT_F32_SPLIT16 = 2 changes gradient products only: logits of both passes, token-keep decisions and the
     loss components of a training step equal those of value 1 bit for bit (B = 16 and the bench size); the gradients differ
     (at the 1e-4 level) and stay finite."""
+    import _lib
     x, y = synth.make_batch(B, 100, seed=71)
     res = {}
-    for prec in ("fp16x3", "fp16x3f", "fp16x3h"):
-        m, _ = _bench_model(prec, "compact", B, 0.85)
+    # "fp16x3h+fused": round 6 -- fp16x3h's default runs the adapter up-projection as three leading tiles of the fc2 GEMM (a three-part product
+    # instead of the exact-fp32 MFMA kernel's): the same decisions, logits to the three-part products' round-off; DYT_OPT_FC2_CAT = 0 is the
+    # fp16x3 forward bit for bit, as before
+    for prec in ("fp16x3", "fp16x3f", "fp16x3h", "fp16x3h+fused"):
+        m, _ = _bench_model(prec.split("+")[0], "compact", B, 0.85)
         m.train()
         eng = m.engine(B, torch.device("cuda", 0))
+        if prec == "fp16x3h":
+            eng.set_option(_lib.OPT_FC2_CAT, 0)
         ls = torch.empty(B, 100, device="cuda"); lt = torch.empty(B, 100, device="cuda")
         ts = torch.zeros(B, 12, 196, device="cuda")
         losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.7, 2.0, 0.0, 0.0, seed=7, logits_s=ls, logits_t=lt, token_select=ts)
@@ -203,6 +209,11 @@ def test_fp16x3f_forward_is_bitwise_the_fp16x3_forward(B):
         del eng, m
         torch.cuda.empty_cache()
     a = res["fp16x3"]
+    f = res["fp16x3h+fused"]
+    assert torch.equal(a[2], f[2])
+    d_s, d_t = float((a[0] - f[0]).abs().max()), float((a[1] - f[1]).abs().max())
+    print("B=%d: fp16x3h with the fused up-projection vs fp16x3: logits %.2e student / %.2e teacher" % (B, d_s, d_t))
+    assert d_s < 1e-5 and d_t < 1e-5 and float((a[3][:5] - f[3][:5]).abs().max()) < 1e-5
     for other in ("fp16x3f", "fp16x3h"):
         b = res[other]
         for i, name in enumerate(("student logits", "teacher logits", "token_select")):

@@ -75,6 +75,7 @@ def test_driver_sequence_with_the_drivers_own_optimizer_and_scaler(precision, tm
         model, optimizer, loss_scaler, criterion, device = _driver_objects(precision, C=C, lr=lr)
         if kind == "fused":
             optimizer = FusedAdamW(model, lr=lr, weight_decay=0.01)
+        os.makedirs(tmp, exist_ok=True)                                            # (main_image.py:365: Path(args.output_dir).mkdir)
         args = _args(tmp, C, lr, resume=resume)
         model_without_ddp = model
         misc.load_model(args=args, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)      # :310
@@ -160,3 +161,81 @@ def test_native_scaler_called_like_the_reference_loop_calls_it():
     assert loss_scaler.skipped == 1
     assert all(torch.equal(after[n], p.detach()) for n, p in model.named_parameters() if p.requires_grad)
     assert set(loss_scaler.state_dict()) >= {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+
+
+@pytest.mark.parametrize("B,steps", [(16, 7), (2, 31)])
+def test_prefetched_host_batches_give_the_resident_data_loss_sequence(B, steps, monkeypatch):
+    """Input feeding (reference engine_finetune.py:34-42): train_one_epoch over DISTINCT pinned host batches --
+    every batch copied on the copy stream into one of two device buffers, handed over by events -- produces, step for step, the
+    loss components of the same batches resident on the device, and of the reference's placement of the copy (compute stream,
+    DYT_PREFETCH=0); the parameters after the epoch are bit-identical.  B=2 x 31 steps: steps much shorter than a copy, so every
+    hand-over (ready / free events, both buffers, the ragged last batch) is exercised many times."""
+    import engine_finetune as E
+    import synth
+    C = 10
+
+    def run(kind):
+        torch.manual_seed(3)
+        model, optimizer, loss_scaler, criterion, device = _driver_objects("fp16", C=C, lr=1e-3)
+        host = [synth.make_batch(B if i != steps - 1 else max(1, B - 1), C, seed=40 + i) for i in range(steps)]   # last batch ragged
+        if kind == "resident":
+            loader = [(x.to(device), y.to(device)) for x, y in host]
+        else:
+            loader = [(x.pin_memory(), y.pin_memory()) for x, y in host]
+        monkeypatch.setenv("DYT_PREFETCH", "0" if kind == "compute_stream" else "1")
+        seq = []
+        real = E.train_step
+
+        def spy(*a, **kw):
+            out = real(*a, **kw)
+            seq.append(kw["losses_out"].clone())
+            return out
+        monkeypatch.setattr(E, "train_step", spy)
+        args = _args("/tmp", C, 1e-3)
+        stats = E.train_one_epoch(model, criterion, loader, optimizer, device, 0, loss_scaler, max_norm=None, log_writer=None, args=args, logger=None)
+        monkeypatch.setattr(E, "train_step", real)
+        torch.cuda.synchronize()
+        return torch.stack(seq).cpu(), {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}, stats
+
+    seq_r, par_r, st_r = run("resident")
+    seq_p, par_p, st_p = run("prefetched")
+    seq_c, par_c, st_c = run("compute_stream")
+    assert seq_r.shape == (steps, 8) and torch.isfinite(seq_r).all()
+    assert len({float(v) for v in seq_r[:, 0]}) == steps          # distinct batches: distinct losses
+    assert torch.equal(seq_r, seq_p) and torch.equal(seq_r, seq_c)
+    assert st_r == st_p == st_c
+    for n in par_r:
+        assert torch.equal(par_r[n], par_p[n]) and torch.equal(par_r[n], par_c[n]), n
+
+
+@pytest.mark.parametrize("precision", ["fp16x3q", "fp16x3h", "fp16f8"])
+def test_split_modes_fc2_with_leading_adapter_tiles_vs_the_two_launch_form(precision):
+    """Round 6: in the split modes whose backward runs on 16-bit operands the adapter up-projection rides on the fc2 GEMM as three
+    leading tiles of a three-part product (gemm.hip: LEAD; 256x256 and 128x128 tiles, fold form and fp8-correction form, gathered
+    rows, the cls tail) and the dropped tokens' up-projection runs three-part on the same [hi | lo] images.  DYT_OPT_FC2_CAT = 0
+    restores the round-5 form (up-projection on the exact-fp32 MFMA kernel, two fp32 read-modify-write passes).  Same training
+    decisions; logits, eval logits and losses agree to the MODE's own round-off: 1e-5 where the pass is three-part throughout (fp16x3h),
+    5e-5 for fp16x3q's student pass (qkv / proj in the fp8-correction form: 2.4e-5 from the oracle) and 2e-4 for passes whose MLP
+    takes the fp8-correction form (fp16f8; fp16x3q's complete_model pass: 1e-4 from the oracle) -- there a 1e-7 change of the fc2
+    output moves e4m3 roundings of the next GEMM's correction operands, i.e. two equally accurate evaluations differ by the form's own
+    noise; gradients within the 16-bit backward's bound."""
+    from test_gpu_round3 import _step
+    from test_gpu_round2 import _grad_tol
+    a, b = _step(precision, "compact", 1, B=16), _step(precision, "compact", 0, B=16)
+    assert torch.equal(a["ts"], b["ts"]) and torch.equal(a["tse"], b["tse"])
+    for k in ("ls", "lt", "le", "lc"):
+        d = float((a[k] - b[k]).abs().max())
+        tol = {"fp16x3h": 1e-5, "fp16f8": 2e-4, "fp16x3q": 5e-5 if k in ("ls", "le") else 2e-4}[precision]
+        print("%s %s: max |fused - two-launch| = %.2e (bound %.0e)" % (precision, k, d, tol))
+        assert d < tol, (k, d)
+    assert float((a["losses"][:5] - b["losses"][:5]).abs().max()) < 2e-4
+    assert torch.equal(a["losses"][5:7], b["losses"][5:7])            # keep ratio, kept tokens
+    worst = 0.0
+    for n, ga in a["grads"].items():
+        gb = b["grads"][n]
+        if gb.numel() == 1:
+            continue
+        e = float((ga - gb).norm() / (gb.norm() + 1e-20))
+        worst = max(worst, e)
+        assert e < _grad_tol(n, precision), (n, e)
+    print("%s: worst gradient rel-L2 between the two forms %.2e" % (precision, worst))
