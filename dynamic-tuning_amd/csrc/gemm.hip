@@ -666,40 +666,46 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (LEAD > 0) {
-        // ---- leading tiles of the second operand pair (see CatArgs): synchronous, slot 0 of the ring
-#pragma unroll 1
-        for (int t = 0; t < LEAD; ++t) {
-            const int ac = t == 2 ? BK : 0, wc = t == 1 ? BK : 0;   // [A2_hi | A2_hi | A2_lo] x [W2_hi | W2_lo | W2_hi]
+        // ---- leading tiles of the second operand pair (see CatArgs).  The four operand tiles go out in ONE DMA round -- A2_hi / W2_hi into
+        // ring slot 0, A2_lo / W2_lo into slot 1 -- so the three products pay one exposed load latency and two barriers:
+        // (A2_hi, W2_hi), (A2_hi, W2_lo), (A2_lo, W2_hi)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
 #pragma unroll
             for (int q = 0; q < A_INSTR; ++q) {
                 int grow = min(m0 + (q * NW + wave) * 8 + lrow, Mv - 1);
                 if (cat.a2_map) grow = cat.a2_map[grow];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.A2 + (size_t)grow * (2 * BK) + ac + chunk * 8),
-                                                 (__attribute__((address_space(3))) void*)(smem + (q * NW + wave) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.A2 + (size_t)grow * (2 * BK) + part * BK + chunk * 8),
+                                                 (__attribute__((address_space(3))) void*)(smem + part * STAGE + (q * NW + wave) * 1024), 16, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < B_INSTR; ++q) {
                 const int row = (q * NW + wave) * 8 + lrow;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.W2 + (size_t)(n0 + row) * (2 * BK) + wc + chunk * 8),
-                                                 (__attribute__((address_space(3))) void*)(smem + A_BYTES + (q * NW + wave) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cat.W2 + (size_t)(n0 + row) * (2 * BK) + part * BK + chunk * 8),
+                                                 (__attribute__((address_space(3))) void*)(smem + part * STAGE + A_BYTES + (q * NW + wave) * 1024), 16, 0, 0);
             }
-            dma_wait_all();
-            __syncthreads();
+        }
+        dma_wait_all();
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < LEAD; ++t) {
+            const char* ab = smem + (t == 2 ? STAGE : 0);
+            const char* wb = smem + (t == 1 ? STAGE : 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int so = (ks == 0 ? fslot0 : fslot1) * 16;
                 bf16x8 la[TM], lw[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) la[i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 2048 + so);
+                for (int i = 0; i < TM; ++i) la[i] = *reinterpret_cast<const bf16x8*>(ab + a_off + i * 2048 + so);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) lw[j] = *reinterpret_cast<const bf16x8*>(smem + b_off + j * 2048 + so);
+                for (int j = 0; j < TN; ++j) lw[j] = *reinterpret_cast<const bf16x8*>(wb + b_off + j * 2048 + so);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = DYT_MFMA_16x16x32(lw[j], la[i], acc[i][j]);
             }
-            __syncthreads();   // every wave's reads of slot 0 have returned before it is overwritten
         }
+        __syncthreads();   // every wave's reads of the two slots have returned before the main loop's first stages land in them
     }
     const int nk = K / BK + (CAT ? 1 : 0);
     if (ABL == 9) t_loop0 = __builtin_readcyclecounter();

@@ -149,7 +149,7 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 // dx_out[row] = base[row] + LNbwd(dy[row]; x[row], stats[row], w)
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx_out, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  float gs, hipStream_t s, void* out3 = nullptr, float s3 = 1.0f, int out3_hi_only = 0);   // out3: + dx * s3 as a [rows][3*768] split operand (fp32 mode)   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
+                  float gs, hipStream_t s, void* out3 = nullptr, float s3 = 1.0f, int out3_hi_only = 0, const void* base_at = nullptr);   // base_at: the stream as a 16-bit gs-scaled operand copy instead of `base` (dx_out may then be null)   // out3: + dx * s3 as a [rows][3*768] split operand (fp32 mode)   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
 
 struct GateArgs {
     const float* u;          // [B*197,768] residual stream after attention
@@ -287,6 +287,10 @@ struct TokBwdArgs {
     // stochastic depth: the MLP branch of image b was multiplied by branch_scale[b] in the forward pass (GemmArgs::row_scale of FC2), so
     // its LN2-input gradient and the gate gradient <g, h> are too
     const float* branch_scale = nullptr;
+    // fp16 mode (round 6, dyt_ctx::g16): the gradient stream between the row kernels of the backward lives in ONE 16-bit, gs-scaled buffer per
+    // hop -- the copy each kernel writes for the GEMM behind it anyway (ln_bwd's g_at, this kernel's du_at) -- instead of also as an fp32
+    // [M,768] stream: du_in_at = the incoming gradient in that form (du is then not read), du == null: no fp32 copy is written
+    const void* du_in_at = nullptr;
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
 // stochastic depth (timm DropPath): scales[branch][l][b] for branch 0 (attention) / 1 (MLP), blocks l < depth, images b < batch: 1 with

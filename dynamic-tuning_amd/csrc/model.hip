@@ -277,6 +277,12 @@ struct dyt_ctx {
     bool learn_scale = false;    // DYT_OPT_LEARNABLE_SCALE: tuning_config.ffn_adapter_scalar == "learnable_scalar" (dynamic_adapter.py:101-102): the scale is
                                  // the trainable word off_sc of every block (a padding slot of the flat layout behind the gate bias)
     int64_t off_sc = 0;
+    // fp16 build, 16-bit mode (round 6): between the row kernels of the backward the gradient stream is carried by the 16-bit gs-scaled copy each
+    // of them writes for the GEMM behind it (ln_bwd: g_at, tok_bwd: du_at) instead of ALSO as an fp32 [M,768] stream that both read and
+    // write: -230 MB per block and pass (tok_bwd / ln_bwd 336 -> 221 MB each).  Every hop rounds the stream to 11 bits (at 2^12 x its
+    // value), so round-off accumulates over the 23 hops of a pass: not used by the split modes' 16-bit backward (their gradient bar is
+    // 2e-3), nor by the bfloat16 build (8 bits).  DYT_G16=0: the fp32 stream.
+    bool g16 = false;
     bool pass_ran = false;       // a forward pass has run in this context: DYT_OPT_LEARNABLE_SCALE may no longer change
     float* ad_up_bp = nullptr;   // [depth][768] s * up_proj.bias (prep_adapters_kernel)
     float drop_path_rate = 0.f;  // timm DropPath rate of the LAST block (block l: rate * l / (depth - 1)); training forward passes only
@@ -589,6 +595,10 @@ extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
 #endif
     if (const char* e = getenv("DYT_LN_FOLD")) c->ln_fold = atoi(e) != 0;
     if (c->prec == 0) c->ln_fold = false;
+#ifdef DYT_FP16
+    c->g16 = c->prec != 0;
+    if (const char* e = getenv("DYT_G16")) c->g16 = c->g16 && atoi(e) != 0;
+#endif
     trainable_layout(c);
     layout(c, true);
     c->arena_size = c->arena_used;
@@ -1258,7 +1268,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // contracted by the fc2 kernel as three leading tiles in front of its main loop (gemm.hip: LEAD); the dropped tokens' up-projection launch
         // runs on the same two images.  Until round 5 these modes ran the up-projection on the exact-fp32 MFMA kernel: an fp32
         // read-modify-write of [M,768] per block and pass (47 us) in front of the fc2 epilogue's own.
-        const bool cat3 = c->fc2_cat && P == 0 && c->split16 && c->bwd16 && T.dact3 && c->ad_up_w3 && !masked_dense && !dp2;
+        static const bool cat3_env = !(getenv("DYT_FC2_CAT3") && atoi(getenv("DYT_FC2_CAT3")) == 0);   // measurement switch: 0 = the round-5 two-launch form in the split modes only
+        const bool cat3 = cat3_env && c->fc2_cat && P == 0 && c->split16 && c->bwd16 && T.dact3 && c->ad_up_w3 && !masked_dense && !dp2;
         L.h_has_adapter = (cat || cat3) && need_h;   // the saved "MLP output" of this block then includes the adapter: tok_bwd corrects <g, h>
         FORK(sb);
         {
@@ -1551,6 +1562,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
     if (c->learn_scale) DYT_HIP_CHECK(hipMemsetAsync(S.gscr, 0, (size_t)depth * c->layer_stride * sizeof(float), s));
     const float gs = P == 0 ? 1.0f : c->gs, inv_gs = 1.0f / gs;   // 16-bit gradient operands carry gs (dyt_ctx: gs)
     float* g = T.g;
+    const bool g16 = c->g16 && P == 1 && !b16;   // the gradient stream between the row kernels as 16-bit operand copies only (dyt_ctx::g16)
     hipStream_t sb = nullptr;
     { int rc = branch_stream(c, S, &sb); if (rc) return rc; }
 
@@ -1665,7 +1677,9 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // ---- 4. per-token tail: LN2 backward scattered back, gate backward, AT copy of dL/du ----
         if (!first || student) {
             TokBwdArgs a;
-            a.du = g; a.dA2 = first ? nullptr : T.dA2; a.dst_of = (dense || tail) ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
+            a.du = g; a.dA2 = first ? nullptr : T.dA2;
+            a.dst_of = (dense || tail) ? nullptr : L.dst_of; a.u = L.u; a.stats2 = L.st2;
+            if (g16 && !first) { a.du = nullptr; a.du_in_at = tail ? nullptr : T.g_at; }   // in: ln_bwd's (or bwd_prep's) 16-bit copy; out: du_at only
             a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
             a.dmask = tail ? nullptr : T.dmask;
             a.g_cls = tail ? S.gcls : nullptr;
@@ -1685,7 +1699,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             if (a.du_at) POISON(8, T.du_at, (size_t)M * D * atb);
             ISO(2, RUN(2, 0, launch_tok_bwd(P, a, &nblk, s)););
             if (student && !dbg_skip(8)) { int _r = queue_tok_reduce(rq, S.tok_part[l], nblk, gbase + c->off_gw); if (_r) return _r; }
-            if (a.write_du) CK("tok_bwd g", g, (size_t)M * D * 4);
+            if (a.write_du && a.du) CK("tok_bwd g", g, (size_t)M * D * 4);
             if (a.dmask) CK("tok_in dmask", T.dmask, (size_t)M * 4);          // what tok_bwd consumed (unchanged by it)
             if (a.dA2) CK("tok_in dA2", T.dA2, (size_t)Mr * D * atb);
             if (a.dad) CK("tok_in dad", Tdad, (size_t)Mr * D * atb);
@@ -1728,11 +1742,11 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {   // LN1 backward, fused with the next block's prep (AT copy of g, <g, h> for the gate gradient)
             const LayerS& Ln = S.L[l - 1];
             if (g_at) POISON(256, g_at, (size_t)M * D * atb);
-            ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g, g, M, g_at, student ? (b16 ? Ln.h16 : Ln.h) : nullptr,
+            ISO(4, RUN(2, 0, launch_ln_bwd(P, T.dxn, S.xs[l], L.st1, W.ln1_w, g16 ? nullptr : g, g16 ? nullptr : g, M, g_at, student ? (b16 ? Ln.h16 : Ln.h) : nullptr,
                                     (!dense && !h_by_token) ? Ln.dst_of : nullptr, student ? T.dmask : nullptr, gs, s,
-                                    (split_prod && l > 1) ? T.g3 : nullptr, c->split_gs, c->split_bwd_parts == 1)););
+                                    (split_prod && l > 1) ? T.g3 : nullptr, c->split_gs, c->split_bwd_parts == 1, g16 ? T.du_at : nullptr)););
             g3_ready = split_prod && l > 1;
-            CK("ln_bwd g", g, (size_t)M * D * 4);
+            if (!g16) CK("ln_bwd g", g, (size_t)M * D * 4);
             if (g_at) CK("ln_bwd g_at", g_at, (size_t)M * D * atb);
             if (student) CK("ln_bwd dmask", T.dmask, (size_t)M * 4);
             prepped = true;

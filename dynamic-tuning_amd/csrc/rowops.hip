@@ -80,29 +80,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
                                                      const float* __restrict__ base, float* __restrict__ dx, int rows,
                                                      AT* __restrict__ g_at, const AT* __restrict__ h_next,
                                                      const int* __restrict__ dst_of_next, float* __restrict__ dmask_next,
-                                                     float gs, float inv_gs, bf16* __restrict__ out3, float s3, int hi3) {
+                                                     float gs, float inv_gs, bf16* __restrict__ out3, float s3, int hi3,
+                                                     const AT* __restrict__ base_at) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     // every load of the row is issued up front and completed by ONE full drain that names all of them (DYT_PIN*, dyt_common.h)
+    // base_at (round 6, fp16 mode): the gradient stream this row's LayerNorm gradient is added to arrives as the 16-bit, gs-scaled copy the
+    // kernel before wrote for its GEMM (tok_bwd's du_at) instead of as an fp32 [M,768] stream; dx == null: no fp32 copy is written either
     Row12 g, xr, wr, br;
     g.load_at(dy + (size_t)row * D, lane);
     xr.load_nt(x + (size_t)row * D, lane);   // residual snapshot of the forward pass: last use
     wr.load(w, lane);
     float2 st = stats[row];
     int r = dst_of_next ? dst_of_next[row] : row;
-    if (base) br.load(base + (size_t)row * D, lane);
+    if (base_at) br.load_at(base_at + (size_t)row * D, lane);
+    else if (base) br.load(base + (size_t)row * D, lane);
     LN_ROWPIN(g); LN_ROWPIN(xr); LN_ROWPIN(wr);
     LN_SCALPIN3(st.x, st.y, r);
-    if (base) LN_ROWPIN(br);
+    if (base || base_at) LN_ROWPIN(br);
     ln_bwd_row(g, xr, wr, st);
 #pragma unroll
     for (int i = 0; i < 12; ++i) g.v[i] *= inv_gs;   // dy carried the 16-bit gradient factor (1 in the bf16 / fp32 builds: exact)
-    if (base) {
+    if (base_at) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g.v[i] = fmaf(br.v[i], inv_gs, g.v[i]);
+    } else if (base) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) g.v[i] += br.v[i];
     }
-    g.store(dx + (size_t)row * D, lane);
+    if (dx) g.store(dx + (size_t)row * D, lane);
     if (out3) g.store_split3(out3 + (size_t)row * SPLIT_A * D, lane, s3, hi3 != 0);   // fp32 split form: the next block's GELU' dgrad operand
     if (g_at) {
         Row12 gsc;
@@ -138,14 +145,14 @@ int launch_ln_fwd_f32out(const float* x, const float* w, const float* b, float* 
 }
 int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* stats, const float* w, const float* base,
                   float* dx, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
-                  float gs, hipStream_t s, void* out3, float s3, int out3_hi_only) {
+                  float gs, hipStream_t s, void* out3, float s3, int out3_hi_only, const void* base_at) {
     if (dbg_skip(16)) return 0;
     if (precision == 0)
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)dy, x, stats, w, base, dx,
-                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next, 1.0f, 1.0f, (bf16*)out3, s3, out3_hi_only);
+                           rows, (float*)g_at, (const float*)h_next, dst_of_next, dmask_next, 1.0f, 1.0f, (bf16*)out3, s3, out3_hi_only, (const float*)nullptr);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)dy, x, stats, w, base, dx,
-                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next, gs, 1.0f / gs, (bf16*)nullptr, 1.0f, 0);
+                           rows, (bf16*)g_at, (const bf16*)h_next, dst_of_next, dmask_next, gs, 1.0f / gs, (bf16*)nullptr, 1.0f, 0, (const bf16*)base_at);
     LAUNCH_CHECK();
     return 0;
 }
@@ -887,7 +894,9 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         const bool gate = a.gate_w && n >= 1;
         const bool cat = gate && a.cat_dact && a.dmask;      // the saved MLP output includes the adapter's weight term (see TokBwdArgs)
         if (need_u) ur.load_nt(a.u + (size_t)t * D, lane);   // saved u of the forward pass: last use
-        if (a.write_du && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
+        const bool du16 = a.du_in_at && a.write_du && !a.g_cls;   // the incoming gradient as the 16-bit gs-scaled copy (TokBwdArgs::du_in_at)
+        if (du16) du.load_at(reinterpret_cast<const AT*>(a.du_in_at) + (size_t)t * D, lane);
+        else if (a.write_du && !a.g_cls) du.load(a.du + (size_t)t * D, lane);
         else if (a.write_du && n == 0) du.load(a.g_cls + (size_t)b * D, lane);
         else {
 #pragma unroll
@@ -923,6 +932,10 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         }
         const float bs = a.branch_scale ? a.branch_scale[b] : 1.0f;   // stochastic depth on the MLP branch (uniform per image)
         dmk *= bs;
+        if (du16) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) du.v[i] *= a.inv_gs;
+        }
         if (a.dad) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) du.v[i] += e.v[i] * a.inv_gs;
@@ -949,7 +962,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
             dbg += dlogit;
         }
         if (a.write_du) {
-            du.store(a.du + (size_t)t * D, lane);
+            if (a.du) du.store(a.du + (size_t)t * D, lane);
             if (a.du3) du.store_split3(reinterpret_cast<bf16*>(a.du3) + (size_t)t * SPLIT_A * D, lane, a.du3_scale, a.du3_hi_only);   // proj dgrad operand (fp32 split form)
             if (a.du_at) {
                 Row12 dsc;
