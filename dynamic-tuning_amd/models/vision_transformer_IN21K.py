@@ -346,8 +346,54 @@ class VisionTransformer(nn.Module):
                                          keep_mask=keep_mask, seed=seed)
         return logits, dict(token_select=ts.unsqueeze(-1), token_logits=tl.unsqueeze(-1))
 
-    def forward_features(self, x, complete_model=False):
-        raise DyTError("forward_features/forward_head are fused into one HIP call; use forward()")
+    @torch.no_grad()
+    def forward_features(self, x, complete_model=False, gumbel=None, keep_mask=None):
+        """Reference :343-371: the block stack's output after the final norm, ``(tokens [B,197,768], {"token_select", "token_logits"})``.
+        Runs the same HIP forward with DYT_F_TOKENS_OUT (every token of the last block is then computed: no cls-only tail) and the final
+        LayerNorm through the C ABI's ``dyt_layernorm``.  Forward only -- training goes through ``forward`` / the fused step."""
+        import ctypes
+        from _lib import check, lib, ptr, stream_ptr
+        if not x.is_cuda:
+            raise DyTError("DyT VisionTransformer runs on a HIP device only (input is on %s); there is no CPU path" % x.device)
+        if self._frames and self._frames > 1:
+            raise NotImplementedError("forward_features of the video model: its head pools every frame's tokens inside the fused forward")
+        x = self.fold_input(x.float()).contiguous()
+        eng = self.engine(x.shape[0], x.device)
+        g1 = g2 = None
+        if gumbel is not None:
+            g1, g2 = (t.to(x.device, torch.float32).contiguous() for t in gumbel)
+        if keep_mask is not None:
+            keep_mask = keep_mask.to(x.device, torch.uint8).contiguous()
+        self._seed_counter += 1
+        seed = (torch.initial_seed() * 1000003 + self._seed_counter) & (2 ** 63 - 1)
+        tok, ts, tl = eng.forward_features_tokens(x, training=self.training, complete_model=bool(complete_model),
+                                                  masked_dense=(self.training and self.train_mode == "masked"), g1=g1, g2=g2, keep_mask=keep_mask, seed=seed)
+        out = torch.empty_like(tok)
+        check(lib().dyt_layernorm(ptr(tok.view(-1, self.embed_dim)), ptr(self.norm.weight.detach().float().contiguous()),
+                                  ptr(self.norm.bias.detach().float().contiguous()), ptr(out.view(-1, self.embed_dim)),
+                                  tok.shape[0] * tok.shape[1], stream_ptr()))
+        return out, dict(token_select=ts.unsqueeze(-1), token_logits=tl.unsqueeze(-1))
+
+    @torch.no_grad()
+    def forward_head(self, x, pre_logits: bool = False):
+        """Reference :375-380: cls pooling (``global_pool='token'``; fc_norm / head_drop are identities) and the head, on the output of
+        ``forward_features``.  The head GEMM runs through ``dyt_linear`` in exact fp32 (class count padded to the kernel's 128-column
+        tile on the host).  Forward only."""
+        from _lib import check, lib, ptr, stream_ptr
+        if not x.is_cuda:
+            raise DyTError("forward_head runs on a HIP device only")
+        cls = x[:, 0].float().contiguous()
+        if pre_logits:
+            return cls
+        C = self.num_classes
+        Cp = -(-C // 128) * 128
+        w = torch.zeros(Cp, self.embed_dim, device=x.device)
+        b = torch.zeros(Cp, device=x.device)
+        w[:C].copy_(self.head.weight.detach())
+        b[:C].copy_(self.head.bias.detach())
+        out = torch.empty(cls.shape[0], Cp, device=x.device)
+        check(lib().dyt_linear(ptr(cls), ptr(w), ptr(b), ptr(out), cls.shape[0], Cp, self.embed_dim, 0, stream_ptr()))
+        return out[:, :C].contiguous()
 
 
 def vit_base_patch16_224_in21k(**kwargs):

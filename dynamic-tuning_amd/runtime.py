@@ -177,6 +177,23 @@ class DyTEngine:
                                      ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(out), ptr(ts), ptr(tl), stream_ptr()))
         return out, ts, tl
 
+    def forward_features_tokens(self, images, training=False, complete_model=False, masked_dense=False, g1=None, g2=None, keep_mask=None, seed=0):
+        """Images in, the block stack's output tokens out (DYT_F_TOKENS_OUT without DYT_F_TOKENS_IN): what the reference's forward_features
+        holds right before its final norm (vision_transformer_IN21K.py:343-368).  Forward only.  Returns (tokens [B,197,768],
+        token_select [B,depth,196], token_logits [B,depth,196])."""
+        B = images.shape[0]
+        flags = ((F_TRAINING if training else 0) | (F_COMPLETE if complete_model else 0) | (F_MASKED_DENSE if masked_dense else 0) |
+                 F_GATE_ALWAYS | F_TOKENS_OUT)
+        if training:
+            self._dp_check((0,), B)
+        out = torch.empty(B, NT, DIM, device=self.device, dtype=torch.float32)
+        ts = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32)
+        tl = torch.zeros(B, self.depth, NP, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self.L.dyt_forward(self.h, 0, ptr(images), B, flags, ptr(self.flat), ptr(g1), ptr(g2), ptr(keep_mask),
+                                     ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(out), ptr(ts), ptr(tl), stream_ptr()))
+        return out, ts, tl
+
     def backward(self, slot, dlogits, grad, dtoken_select=None, dtok=None, dtoken_logits=None):
         with torch.cuda.device(self.device):
             self._ck(self.L.dyt_backward(self.h, slot, ptr(dlogits), ptr(dtoken_select), ptr(dtok), ptr(dtoken_logits),

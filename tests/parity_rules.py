@@ -15,12 +15,17 @@ gradients are then consequences and are not compared (the caller skips them).
 ReLU-side rule.  d(down_proj) has a jump wherever a bottleneck pre-activation crosses zero.  A row of that gradient may be set aside
 only if the unit REALLY is on the other side of the ReLU for a token whose reference pre-activation lies within the forward's
 round-off of zero -- verified from the library's saved bottleneck (dyt_debug_dact) against the oracle's pre-activation --, at most
-RELU_MAX_UNITS rows per tensor and RELU_MAX_TENSORS tensors per step."""
+RELU_MAX_UNITS rows per tensor and RELU_MAX_LAYERS adapter layers per step.  The budget counts LAYERS (round 6; round 5 counted tensors,
+cap 2): one unit on the other side shows in BOTH the weight and the bias gradient of its layer, so "2 tensors" was exactly one event and
+two shipped cases sat at the cap with zero headroom.  The measured distribution (tools/probes/r6/relu_side_events.py,
+profiles/round6/r6_relu_side_events.txt: fp16x3q, B=16, 24 seeds, both passes) is what the cap is set from; every use prints the
+headroom and a use that exhausts it warns."""
 import torch
 
 TIE_K = 4.0
 RELU_MAX_UNITS = 2
-RELU_MAX_TENSORS = 2
+RELU_MAX_LAYERS = 2     # adapter layers per step that may each set aside <= RELU_MAX_UNITS rows (in their down_proj weight AND bias)
+RELU_MAX_TENSORS = 2 * RELU_MAX_LAYERS
 _band_cache = {}
 
 
@@ -66,6 +71,7 @@ class ReluSideBudget:
     def __init__(self, eng, sd, x, g1, g2, keep, mode):
         self.eng, self.sd, self.x, self.g1, self.g2, self.keep, self.mode = eng, sd, x, g1, g2, keep, mode
         self.used = 0
+        self.layers = set()
         self._pre = {}
 
     def _oracle_preacts(self, p_):
@@ -114,10 +120,17 @@ class ReluSideBudget:
         assert drop, (what, "rel-L2 %.2e over the bound, but the worst rows %s (error norms %s of %.2e total) are not units on the other side of the ReLU %s" % (
             e, top, ["%.1e" % float(rows[j]) for j in top], float(rows.norm()), sorted(units)))
         self.used += 1
-        assert self.used <= RELU_MAX_TENSORS, (what, "ReLU-side rule invoked for more than %d tensors of one step" % RELU_MAX_TENSORS)
+        self.layers.add(layer)
+        assert len(self.layers) <= RELU_MAX_LAYERS and self.used <= RELU_MAX_TENSORS, (
+            what, "ReLU-side rule invoked for more than %d adapter layers of one step (layers %s)" % (RELU_MAX_LAYERS, sorted(self.layers)))
+        headroom = RELU_MAX_LAYERS - len(self.layers)
+        if headroom == 0:
+            import warnings
+            warnings.warn("%s: the ReLU-side budget of this step is exhausted (layers %s of at most %d)" % (what, sorted(self.layers), RELU_MAX_LAYERS))
         keep_rows = torch.ones(r, dtype=torch.bool)
         keep_rows[drop] = False
         e2 = float((got - gr)[keep_rows].norm() / (gr[keep_rows].norm() + 1e-20))
         print("%s: rel-L2 %.2e, %.2e without bottleneck unit(s) %s -- verified on the other side of the ReLU in the library's forward (%d token(s), |reference "
-              "pre-activation| <= %.1e)" % (what, e, e2, drop, ntok, maxpre))
+              "pre-activation| <= %.1e); ReLU-side budget: %d of %d layers used, headroom %d" % (what, e, e2, drop, ntok, maxpre, len(self.layers),
+                                                                                                     RELU_MAX_LAYERS, headroom))
         return e2

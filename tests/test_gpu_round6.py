@@ -239,3 +239,35 @@ def test_split_modes_fc2_with_leading_adapter_tiles_vs_the_two_launch_form(preci
         worst = max(worst, e)
         assert e < _grad_tol(n, precision), (n, e)
     print("%s: worst gradient rel-L2 between the two forms %.2e" % (precision, worst))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_forward_features_and_forward_head_compose_to_forward(precision):
+    """``forward_features`` / ``forward_head`` of the reference (models/vision_transformer_IN21K.py:343-380), which raised until round 5:
+    the block stack's output through DYT_F_TOKENS_OUT + the final LayerNorm and the head through the C ABI's unit entries.  Their
+    composition is ``forward``: same eval decisions, logits to fp32 round-off (the 16-bit mode: to its own -- the cls-only tail of
+    ``forward`` and the all-token last block of ``forward_features`` take different GEMM launch shapes); the returned tokens are
+    LayerNorm-ed (zero mean, unit variance per token under the test's norm weights)."""
+    import synth
+    from test_gpu_round2 import _bench_model
+    B = 5
+    m, sd = _bench_model(precision, "compact", B, 0.85, kind="test")
+    m.eval()
+    x, _ = synth.make_batch(B, 100, seed=9)
+    x = x.cuda()
+    with torch.no_grad():
+        logits, aux = m(x)
+        lc, _ = m(x, complete_model=True)
+    feats, aux2 = m.forward_features(x)
+    assert feats.shape == (B, 197, 768) and aux2["token_select"].shape == (B, 12, 196, 1) and aux2["token_logits"].shape == (B, 12, 196, 1)
+    assert torch.equal(aux["token_select"], aux2["token_select"])
+    via = m.forward_head(feats)
+    tol = 2e-5 if precision == "fp32" else 5e-3
+    assert via.shape == logits.shape and float((via - logits).abs().max()) < tol, float((via - logits).abs().max())
+    fc, _ = m.forward_features(x, complete_model=True)
+    assert float((m.forward_head(fc) - lc).abs().max()) < tol
+    assert torch.equal(m.forward_head(feats, pre_logits=True), feats[:, 0])
+    # the tokens are the final norm's output: x_hat * w + b with the model's norm parameters
+    w, b = m.norm.weight.detach(), m.norm.bias.detach()
+    xh = (feats - b) / w
+    assert float(xh.mean(-1).abs().max()) < 1e-3 and float((xh.var(-1, unbiased=False) - 1).abs().max()) < 1e-2
