@@ -291,6 +291,8 @@ struct TokBwdArgs {
     // hop -- the copy each kernel writes for the GEMM behind it anyway (ln_bwd's g_at, this kernel's du_at) -- instead of also as an fp32
     // [M,768] stream: du_in_at = the incoming gradient in that form (du is then not read), du == null: no fp32 copy is written
     const void* du_in_at = nullptr;
+    // (u from the forward's 16-bit copy instead of the fp32 row was measured too: 23.23 / 23.26 vs 23.23 / 23.10 ms per step same-box -- no gain, not kept:
+    // profiles/round6/r6_u16_ab.txt)
 };
 int launch_tok_bwd(int precision, const TokBwdArgs& a, int* nblocks_out, hipStream_t s);
 // stochastic depth (timm DropPath): scales[branch][l][b] for branch 0 (attention) / 1 (MLP), blocks l < depth, images b < batch: 1 with

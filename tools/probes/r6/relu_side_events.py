@@ -25,6 +25,8 @@ m, _ = _bench_model(prec, mode, B, 0.85, classes=C, r=r, kind="test")
 m.train()
 eng = m.engine(B, torch.device("cuda", 0))
 layers_per_step, events_per_step, worst_pre = Counter(), Counter(), 0.0
+over_per_step = Counter()   # layers whose down_proj weight or bias gradient exceeds the 16-bit-backward bound (= where the tests would invoke the rule)
+BOUND = 3e-3
 for i in range(SEEDS):
     seed = 31 + 10 * i
     x, y = synth.make_batch(B, C, seed=seed)
@@ -53,6 +55,18 @@ for i in range(SEEDS):
                 layers.add(l)
     layers_per_step[len(layers)] += 1
     events_per_step[len(ev)] += 1
-    print("seed %3d: %d event(s) in %d layer(s)%s" % (seed, len(ev), len(layers), ("  -- " + "; ".join(ev)) if ev else ""), flush=True)
+    _, g_ref, _ = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode, token_target_ratio=0.5)
+    over = {}
+    for n, gr in g_ref.items():
+        if "down_proj" not in n:
+            continue
+        e = float((eng.trainable_view(n, gr.shape, eng.grad).cpu() - gr).norm() / (gr.norm() + 1e-20))
+        if e > BOUND:
+            over.setdefault(int(n.split(".")[1]), []).append("%s %.1e" % (n.split(".")[-1], e))
+    over_per_step[len(over)] += 1
+    print("seed %3d: %d event(s) in %d layer(s); down_proj gradients over %.0e in %d layer(s) %s%s" % (
+        seed, len(ev), len(layers), BOUND, len(over), over if over else "", ("  -- " + "; ".join(ev)) if ev else ""), flush=True)
+print("%s, B=%d, %d seeds: LAYERS WHOSE down_proj GRADIENT EXCEEDS %.0e PER STEP (what the ReLU-side rule's budget must cover): %s" % (
+    prec, B, SEEDS, BOUND, dict(sorted(over_per_step.items()))))
 print("%s, B=%d, %d seeds: layers with a ReLU-side difference per step: %s; events per step: %s; largest |reference pre-activation| of a differing unit %.1e" % (
     prec, B, SEEDS, dict(sorted(layers_per_step.items())), dict(sorted(events_per_step.items())), worst_pre))
