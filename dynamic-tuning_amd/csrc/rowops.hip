@@ -1123,7 +1123,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
     const float xscale = src.p[blockIdx.z].xscale, yscale = src.p[blockIdx.z].yscale;
     float* __restrict__ partial = src.p[blockIdx.z].partial;
     constexpr int TS = 64;        // tokens per step
-    constexpr int LDT = TS + 8;   // bf16 per LDS row (144 B: 16-B aligned rows)
+    // LDS rows of 64 tokens (128 B) with the eight 16-B chunks of row r XOR-swizzled by s(r) = ((r >> 3) ^ r) & 7.  Round 6: the round 1-5 layout
+    // (144-B rows, no swizzle) kept the ds_read_b128 fragment reads conflict-free but put all 16 channel-chunk lanes of a ds_write_b32
+    // lane group on ONE bank (8 rows = 288 words = 0 mod 32): 16-way conflicts on the 24 transposing writes of every step, i.e. the kernel
+    // ran on LDS-write cycles (37 us for 84 MB).  With the swizzle the reads stay conflict-free and the writes are 2-way (X) / conflict-free
+    // (Y); enumerated for every lane group of both instructions in tools/probes/r6/wgrad_swizzle.py.
+    constexpr int LDT = TS;
+    auto swz = [](int r) { return ((r >> 3) ^ r) & 7; };
     __shared__ __attribute__((aligned(16))) bf16 Xt[128 * LDT];
     __shared__ __attribute__((aligned(16))) bf16 Yt[64 * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1167,12 +1173,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 bf16x2 pv = {xr[h][0][i], xr[h][1][i]};
-                *reinterpret_cast<bf16x2*>(&Xt[(xc * 8 + i) * LDT + 2 * (xp0 + 16 * h)]) = pv;
+                const int tk = 2 * (xp0 + 16 * h);   // token (pair) column of row xc * 8 + i: chunk tk / 8 goes to slot (tk / 8) ^ s(row), s = (xc ^ i) & 7
+                *reinterpret_cast<bf16x2*>(&Xt[(xc * 8 + i) * LDT + ((((tk >> 3) ^ xc ^ i) & 7) << 3) + (tk & 7)]) = pv;
             }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             bf16x2 pv = {yr[0][i], yr[1][i]};
-            *reinterpret_cast<bf16x2*>(&Yt[(yc * 8 + i) * LDT + 2 * yp]) = pv;
+            const int tk = 2 * yp;
+            *reinterpret_cast<bf16x2*>(&Yt[(yc * 8 + i) * LDT + ((((tk >> 3) ^ yc ^ i) & 7) << 3) + (tk & 7)]) = pv;
         }
         __syncthreads();
         if (tb + TS < mend) load_step(tb + TS);  // in flight during the reads + MFMAs below
@@ -1194,10 +1202,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgPair src, int M, i
         };
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {  // four 16-token k blocks; lane = (row lr, tokens kk*16 + lk*8 .. +7)
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&Xt[(wave * 32 + lr) * LDT + kk * 16 + lk * 8]);
+            const int xrow = wave * 32 + lr;
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&Xt[xrow * LDT + (((kk * 2 + lk) ^ swz(xrow)) << 3)]);
             bf16x8 yf[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 32 + lr) * LDT + kk * 16 + lk * 8]);
+            for (int j = 0; j < 2; ++j) yf[j] = *reinterpret_cast<const bf16x8*>(&Yt[(j * 32 + lr) * LDT + (((kk * 2 + lk) ^ swz(j * 32 + lr)) << 3)]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = DYT_MFMA_32x32x16(xf, yf[j], acc[j]);
             xs += sum8(xf);
