@@ -153,3 +153,79 @@ def test_driver_surface_fixture_is_current():
     import make_driver_surface as mk
     for name in mk.DRIVERS:
         assert mk.scan(os.path.join(REF, name)) == SURFACE[name], name
+
+
+MISC_VS_REF = r'''
+import os, sys, io, logging, math, types, importlib.util
+sys.path.insert(0, %(tests)r)
+import driver_stubs
+driver_stubs.install()
+import torch
+def load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); return m
+ref = load(os.path.join(%(ref)r, "misc.py"), "ref_misc")
+ours = load(os.path.join(%(pkg)r, "misc.py"), "our_misc")
+# SmoothedValue: same statistics and the same rendered strings for the format strings the loops use
+g = torch.Generator().manual_seed(0)
+vals = torch.rand(57, generator=g).tolist()
+for win, fmt in ((20, None), (1, "{value:.6f}"), (10, "{avg:.4f}"), (5, "{median:.3f} / {max:.3f} / {global_avg:.5f}")):
+    a, b = ref.SmoothedValue(window_size=win, fmt=fmt), ours.SmoothedValue(window_size=win, fmt=fmt)
+    for i, v in enumerate(vals):
+        a.update(v, n=1 + i %% 3); b.update(v, n=1 + i %% 3)
+        assert str(a) == str(b), (win, fmt, i, str(a), str(b))
+        assert (a.median, a.avg, a.global_avg, a.max, a.value, a.count, a.total) == (b.median, b.avg, b.global_avg, b.max, b.value, b.count, b.total)
+# MetricLogger: update / add_meter / attribute access / str, and the lines log_every emits (timings masked)
+def run(mod):
+    buf = io.StringIO()
+    lg = logging.getLogger("t_" + mod.__name__); lg.handlers[:] = [logging.StreamHandler(buf)]; lg.setLevel(logging.INFO); lg.propagate = False
+    ml = mod.MetricLogger(delimiter="  ", logger=lg)
+    ml.add_meter("lr", mod.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    seen = []
+    for i, x in enumerate(ml.log_every(list(range(7)), 3, "Epoch: [0]")):
+        ml.update(loss=0.5 * x, lr=1e-3 * (x + 1), skip=None, t=torch.tensor(2.0 * x))
+        seen.append(x)
+    assert seen == list(range(7)) and ml.loss.count == 7 and abs(ml.t.global_avg - 6.0) < 1e-9
+    try:
+        ml.nothing
+        raise SystemExit("missing meter must raise AttributeError")
+    except AttributeError:
+        pass
+    import re
+    lines = [re.sub(r"(eta|time|data|Total time): \S+( \(\S+ s / it\))?", r"\1: _", l) for l in buf.getvalue().splitlines()]
+    return lines, str(ml)
+la, sa = run(ref); lb, sb = run(ours)
+assert la == lb and sa == sb, ("\n".join(la), "\n".join(lb), sa, sb)
+# get_grad_norm_: 2-norm, inf-norm, parameters without a gradient, a bare tensor
+ps = [torch.nn.Parameter(torch.randn(3, 4, generator=g)) for _ in range(4)]
+for p in ps[:3]:
+    p.grad = torch.randn(3, 4, generator=g)
+for nt in (2.0, 1.0, float("inf")):
+    assert torch.allclose(ref.get_grad_norm_(ps, nt), ours.get_grad_norm_(ps, nt)), nt
+assert float(ours.get_grad_norm_([ps[3]])) == 0.0 == float(ref.get_grad_norm_([ps[3]]))
+assert torch.allclose(ref.get_grad_norm_(ps[0]), ours.get_grad_norm_(ps[0]))
+# process-group helpers without a group, all_reduce_mean, init_distributed_mode's single-process branch
+for m in (ref, ours):
+    assert m.get_world_size() == 1 and m.get_rank() == 0 and m.is_main_process() and not m.is_dist_avail_and_initialized()
+    assert m.all_reduce_mean(3.5) == 3.5
+    import builtins
+    keep = builtins.print
+    a = types.SimpleNamespace(dist_on_itp=False, dist_url="env://")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID"):
+        os.environ.pop(k, None)
+    m.init_distributed_mode(a)
+    assert a.distributed is False
+    builtins.print = keep
+assert ours.NativeScalerWithGradNormCount.state_dict_key == ref.NativeScalerWithGradNormCount.state_dict_key
+print("misc vs reference ok")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+def test_misc_helpers_equal_the_references_on_the_same_inputs():
+    """``SmoothedValue`` / ``MetricLogger`` (statistics, rendered strings, the lines ``log_every`` emits), ``get_grad_norm_`` and the
+    single-process branches of the process-group helpers of this package's ``misc.py`` against the REFERENCE's ``misc.py`` loaded from
+    /root/reference, on the same inputs (reference misc.py:24-168,188-214,281-293,355-363)."""
+    code = textwrap.dedent(MISC_VS_REF) % dict(pkg=PKG, ref=REF, tests=HERE)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "misc vs reference ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
