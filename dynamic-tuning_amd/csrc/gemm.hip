@@ -1190,6 +1190,10 @@ static int run_f8(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     if (a.K % 256 != 0 || a.M <= 0 || a.N % 128 != 0 || a.f8_begin * 128 != a.K) { set_error("gemm f8 form: K=%d N=%d M=%d", a.K, a.N, a.M); return -1; }
     if (LEAD && (!a.A2 || !a.W2)) { set_error("gemm f8 form: leading tiles need A2 and W2"); return -1; }
     if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 2048 && !a.a_map) return launch_bf16_cfg<256, 256, 2, 4, 0, Epi, false, true, LEAD>(a, epi, s);
+    // logical K <= 768, N = 768 (proj forward of the split modes): like the 16-bit modes' proj (run_bf16: shortk_n768) -- one launch of 128x128 tiles,
+    // two workgroups per CU, instead of a 256x256 body + a 128x128 row tail.  DYT_F8_SHORTK_SMALL=0: the body + tail scheme
+    static const int f8_shortk_small = getenv("DYT_F8_SHORTK_SMALL") ? atoi(getenv("DYT_F8_SHORTK_SMALL")) : 1;
+    if (f8_shortk_small && (a.K <= 2 * D || f8_shortk_small == 2) && a.N % 128 == 0 && a.N < 2304) return launch_bf16_cfg<128, 128, 2, 2, 0, Epi, false, true, LEAD>(a, epi, s);
     if (a.N % 256 == 0 && !a.a_map) {   // (the 256x256 fp8 kernel takes no row gather)
         constexpr int NCU = 256;
         const int tn = a.N / 256, t256 = ((a.M + 255) / 256) * tn, rounds = t256 / NCU, rem = t256 - rounds * NCU;

@@ -163,13 +163,14 @@ def test_native_scaler_called_like_the_reference_loop_calls_it():
     assert set(loss_scaler.state_dict()) >= {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
 
 
-@pytest.mark.parametrize("B,steps", [(16, 7), (2, 31)])
-def test_prefetched_host_batches_give_the_resident_data_loss_sequence(B, steps, monkeypatch):
+@pytest.mark.parametrize("B,steps,graph", [(16, 7, False), (2, 31, False), (16, 7, True)])
+def test_prefetched_host_batches_give_the_resident_data_loss_sequence(B, steps, graph, monkeypatch):
     """Input feeding (reference engine_finetune.py:34-42): train_one_epoch over DISTINCT pinned host batches --
     every batch copied on the copy stream into one of two device buffers, handed over by events -- produces, step for step, the
     loss components of the same batches resident on the device, and of the reference's placement of the copy (compute stream,
     DYT_PREFETCH=0); the parameters after the epoch are bit-identical.  B=2 x 31 steps: steps much shorter than a copy, so every
-    hand-over (ready / free events, both buffers, the ragged last batch) is exercised many times."""
+    hand-over (ready / free events, both buffers, the ragged last batch) is exercised many times.  graph=True: the step replayed from a
+    captured hipGraph (``args.hip_graph``; the prefetched buffer is copied into the graph's static input on the compute stream)."""
     import engine_finetune as E
     import synth
     C = 10
@@ -192,6 +193,7 @@ def test_prefetched_host_batches_give_the_resident_data_loss_sequence(B, steps, 
             return out
         monkeypatch.setattr(E, "train_step", spy)
         args = _args("/tmp", C, 1e-3)
+        args.hip_graph = graph
         stats = E.train_one_epoch(model, criterion, loader, optimizer, device, 0, loss_scaler, max_norm=None, log_writer=None, args=args, logger=None)
         monkeypatch.setattr(E, "train_step", real)
         torch.cuda.synchronize()
