@@ -516,9 +516,14 @@ def measure(args, precision, mode, steps, warmup, device, world, rank, host_batc
         res["rccl_ranks"] = _lib.rccl_comm_ranks(comm) if comm is not None else None
         res["comm_stream_concurrent"] = bool(eng.streams_concurrent(torch.cuda.current_stream(device), eng.comm_stream()))
     if host_batches > 0:
-        res["host_fed"] = host_fed(args, model, opt, steps, warmup, device, world, dt / steps * 1e3)
-        log("[%s/%s] host-fed loop: %.2f ms/step prefetched, %.2f with the copy on the compute stream (resident %.2f)" % (
-            precision, mode, res["host_fed"]["ms_per_step"], res["host_fed"]["copy_on_compute_stream_ms_per_step"], dt / steps * 1e3))
+        try:   # a side measurement: it must never take the headline down with it (pinned allocations can be refused by a container's memlock limit)
+            res["host_fed"] = host_fed(args, model, opt, steps, warmup, device, world, dt / steps * 1e3)
+            log("[%s/%s] host-fed loop: %.2f ms/step prefetched, %.2f with the copy on the compute stream (resident %.2f)" % (
+                precision, mode, res["host_fed"]["ms_per_step"], res["host_fed"]["copy_on_compute_stream_ms_per_step"], dt / steps * 1e3))
+        except Exception as e:   # noqa: BLE001
+            res["host_fed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            log("[%s/%s] host-fed loop failed: %s" % (precision, mode, res["host_fed"]["error"]))
+            torch.cuda.synchronize()
     del opt, model, eng
     torch.cuda.empty_cache()
     return res
