@@ -33,7 +33,7 @@ OPT_STREAM_OVERLAP, OPT_CLS_TAIL, OPT_SHARE_BLOCK0, OPT_COUNT_FLOPS_TOKENS, OPT_
  P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_NORM_W, P_NORM_B, P_AD_DOWN_W, P_AD_DOWN_B, P_AD_UP_W, P_AD_UP_B,
  P_GATE_W, P_GATE_B, P_HEAD_W, P_HEAD_B,
  P_POOL_QUERY, P_POOL_NQ_W, P_POOL_NQ_B, P_POOL_NK_W, P_POOL_NK_B, P_POOL_NV_W, P_POOL_NV_B, P_POOL_Q_W, P_POOL_K_W,
- P_POOL_V_W, P_POOL_Q_BIAS, P_POOL_V_BIAS, P_POOL_PROJ_W, P_POOL_PROJ_B, P_AD_SCALE, P_COUNT) = range(42)
+ P_POOL_V_W, P_POOL_Q_BIAS, P_POOL_V_BIAS, P_POOL_PROJ_W, P_POOL_PROJ_B, P_AD_SCALE, P_AD_LN_W, P_AD_LN_B, P_COUNT) = range(44)
 
 # reference state_dict key suffix -> param id  
 GLOBAL_KEYS = {
@@ -60,6 +60,8 @@ BLOCK_KEYS = {
     "adaptmlp.up_proj.weight": P_AD_UP_W, "adaptmlp.up_proj.bias": P_AD_UP_B,
     "mlp_token_select.mlp_head.weight": P_GATE_W, "mlp_token_select.mlp_head.bias": P_GATE_B,
     "adaptmlp.scale": P_AD_SCALE,   # only with ffn_adapter_scalar == "learnable_scalar"
+    "adaptmlp.adapter_layer_norm_before.weight": P_AD_LN_W,   # only with ffn_adapter_layernorm_option "in" / "out" (dyt_config.adapter_ln)
+    "adaptmlp.adapter_layer_norm_before.bias": P_AD_LN_B,
 }
 
 
@@ -82,7 +84,7 @@ class Config(ctypes.Structure):
     _fields_ = [("num_classes", ctypes.c_int32), ("ffn_num", ctypes.c_int32), ("depth", ctypes.c_int32),
                 ("precision", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("slots", ctypes.c_int32),
                 ("adapter_scale", ctypes.c_float), ("adapter_dropout", ctypes.c_float), ("tau", ctypes.c_float),
-                ("threshold", ctypes.c_float), ("frames", ctypes.c_int32)]
+                ("threshold", ctypes.c_float), ("frames", ctypes.c_int32), ("adapter_ln", ctypes.c_int32)]
 
 
 class DyTError(RuntimeError):

@@ -151,6 +151,14 @@ int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* s
                   float* dx_out, int rows, void* g_at, const void* h_next, const int* dst_of_next, float* dmask_next,
                   float gs, hipStream_t s, void* out3 = nullptr, float s3 = 1.0f, int out3_hi_only = 0, const void* base_at = nullptr);   // base_at: the stream as a 16-bit gs-scaled operand copy instead of `base` (dx_out may then be null)   // out3: + dx * s3 as a [rows][3*768] split operand (fp32 mode)   // gs: factor carried by the 16-bit gradient operands dy (in) and g_at (out)
 
+// the adapter's own LayerNorm (dyt_config::adapter_ln; reference models/dynamic_adapter.py:95-98,121-122,132-133; eps 1e-5): out = LN(x) w + b (+ resid),
+// out of the 16-bit operand type (out_at_precision != 0) or fp32; stats[row] = (mean, rstd)
+int launch_adapter_ln_fwd(int out_at_precision, const float* x, const float* w, const float* b, void* out, float2* stats, const float* resid,
+                          int rows, hipStream_t s);
+// out[0:768] += sum_t dy[t] xhat[t] (dgamma), out[768:1536] += sum_t dy[t] (dbeta); dy of the operand type (x gs) when precision != 0; fixed order
+int launch_ln_param_grad(int precision, const void* dy, const float* x, const float2* stats, float* partial, float* out, int rows, float gs, hipStream_t s);
+int64_t ln_param_grad_scratch_floats(int rows);
+
 struct GateArgs {
     const float* u;          // [B*197,768] residual stream after attention
     const float* w;          // [768]

@@ -44,7 +44,7 @@ template <class AT>
 __global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t layer_stride, int64_t off_dw, int64_t off_db,
                                      int64_t off_uw, int r, AT* __restrict__ down_w, AT* __restrict__ down_wT,
                                      AT* __restrict__ up_w, AT* __restrict__ up_wT, float* __restrict__ down_b,
-                                     AT* __restrict__ up_ws, float scale, int64_t off_sc, int64_t off_ub, float* __restrict__ up_bp) {
+                                     AT* __restrict__ up_ws, float scale, int64_t off_sc, int64_t off_ub, float* __restrict__ up_bp, float bias_scale) {
     // off_sc >= 0 ("learnable_scalar", DYT_OPT_LEARNABLE_SCALE): the up-projection copies and up_bp [depth][768] carry the block's trainable
     // scale s = flat[off_sc] (W' = s W_up, b' = s b_up), and every kernel downstream runs with scale 1
     const int l = blockIdx.y;
@@ -69,7 +69,7 @@ __global__ void prep_adapters_kernel(const float* __restrict__ flat, int64_t lay
         if (up_ws) up_ws[(size_t)l * SZ + idx] = from_f32<AT>(scale * uw);
     }
     if (idx < RP) down_b[l * RP + idx] = idx < r ? base[off_db + idx] : 0.f;
-    if (up_bp && idx < D) up_bp[l * D + idx] = ls * base[off_ub + idx];
+    if (up_bp && idx < D) up_bp[l * D + idx] = bias_scale * ls * base[off_ub + idx];   // bias_scale: the adapter's LayerNorm "out" form takes s b_up here
 }
 
 // "learnable_scalar": the backward has left G' = dL/dW', gb' = dL/db' of the PRIMED up-projection (W' = s W_up, b' = s b_up) of every block
@@ -150,6 +150,8 @@ struct LayerS {  // saved activations of one pass
     void* h;
     int *keep_local, *offsets, *total, *row_src, *dst_of;
     float2* ln_part = nullptr;    // dyt_ctx::ln_fold: the proj epilogue's per-row LayerNorm partials of u ([M][LN_PARTS])
+    float2* st_a = nullptr;       // dyt_ctx::ad_ln: (mean, rstd) of the adapter's LayerNorm input, [M]
+    float* up32 = nullptr;        // dyt_ctx::ad_ln == 2: the LayerNorm's input s (d_act W_up^T + b_up), fp32 [M,768] (its backward needs x_hat)
     bool h_has_adapter = false;   // h = mlp(x) + s up(d_act) + s b_up (fc2 carried the up-projection, DYT_OPT_FC2_CAT)
     // dyt_ctx::bwd16: what the backward pass reads, in the 16-bit operand type (written by the exact forward next to / instead of
     // the fp32 tensors above: q16 / k16 / v16 / o16 by the split attention kernel, u16 by the proj epilogue, z16 = gelu'(z) by the
@@ -169,6 +171,9 @@ struct Transients {  // scratch of one pass (per slot, so two passes can run on 
     int* drop_src = nullptr;        // dyt_ctx::ln_fold: token rows of the DROPPED tokens of the block in flight (gather_index -> their up-projection launch)
     float2* st_compact = nullptr;   // dyt_ctx::ln_fold: scratch for LN2's (mean, rstd) in logical-row order (GemmArgs::ln_scratch)
     void* dad16 = nullptr;   // dyt_ctx::bwd16: the adapter dgrad as a 16-bit [M,768] operand of tok_bwd (T.dad of the 16-bit modes)
+    // dyt_ctx::ad_ln: fp32-sized [M,768] scratch each -- xa: LayerNorm_a(u) in the operand type of the pass that reads it ("in"; recomputed by the backward);
+    // dup: the gradient behind the adapter's LayerNorm ("out") / the fp32 adapter dgrad of an fp32 backward ("in"); ln_part: parameter-gradient partials
+    float *xa = nullptr, *dup = nullptr, *aln_part = nullptr;
 };
 struct PoolS {  // video pooling head: saved activations of one pass (pool.hip)
     float *xf = nullptr, *P = nullptr, *o = nullptr, *y = nullptr, *qn = nullptr, *qhat = nullptr, *qs = nullptr, *st_q = nullptr;
@@ -283,6 +288,10 @@ struct dyt_ctx {
     // value), so round-off accumulates over the 23 hops of a pass (fp16 mode, five seeds: up_proj 1.1e-3 -> 1.3e-3, head unchanged): not used by the
     // bfloat16 build (8 bits).  DYT_G16=0: the fp32 stream.
     bool g16 = false;
+    // dyt_config::adapter_ln (tuning_config.ffn_adapter_layernorm_option): 0 none, 1 "in", 2 "out"; gamma / beta of block l at l * layer_stride + off_alw / off_alb
+    int ad_ln = 0;
+    int64_t off_alw = 0, off_alb = 0;
+    void* ad_up_ws = nullptr;   // "out": [depth][768][RP] adapter_scale * up_proj.weight in the forward's operand type (the LayerNorm input is s (d_act W^T + b))
     bool pass_ran = false;       // a forward pass has run in this context: DYT_OPT_LEARNABLE_SCALE may no longer change
     float* ad_up_bp = nullptr;   // [depth][768] s * up_proj.bias (prep_adapters_kernel)
     float drop_path_rate = 0.f;  // timm DropPath rate of the LAST block (block l: rate * l / (depth - 1)); training forward passes only
@@ -360,6 +369,8 @@ static void layout(dyt_ctx* c, bool dry) {
         for (size_t l = 0; l < depth; ++l) {
             LayerS& L = S.L[l];
             L.st1 = carve<float2>(c, M, dry); L.st2 = carve<float2>(c, M, dry);
+            if (c->ad_ln) L.st_a = carve<float2>(c, M, dry);
+            if (c->ad_ln == 2) L.up32 = carve<float>(c, M * D, dry);
             L.q = carve_at(c, M * D, dry); L.k = carve_at(c, M * D, dry); L.v = carve_at(c, M * D, dry);
             L.attn_o = carve_at(c, M * D, dry);
             L.lse = carve<float>(c, B * NH * NT, dry);
@@ -413,6 +424,10 @@ static void layout(dyt_ctx* c, bool dry) {
         T.g = carve<float>(c, M * D, dry);
         T.delta = carve<float>(c, B * NH * NT, dry);
         T.dmask = carve<float>(c, M, dry);
+        if (c->ad_ln) {
+            T.xa = carve<float>(c, M * D, dry); T.dup = carve<float>(c, M * D, dry);
+            T.aln_part = carve<float>(c, (size_t)ln_param_grad_scratch_floats((int)M), dry);
+        }
         T.tok_partial = carve<float>(c, ((M + 31) / 32) * (D + 1), dry);
         T.wg_partial = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
         T.wg_partial2 = carve<float>(c, ((M + 511) / 512) * (size_t)(D + 8) * 80, dry);
@@ -428,6 +443,7 @@ static void layout(dyt_ctx* c, bool dry) {
     }
     c->grad2 = carve<float>(c, (size_t)c->n_train, dry);
     c->ad_up_bp = carve<float>(c, depth * D, dry);
+    if (c->ad_ln == 2) c->ad_up_ws = carve_at(c, depth * RP * D, dry);
     c->cls_rows = carve<int>(c, B, dry);
     c->seed_dev = carve<uint64_t>(c, 2, dry);
     c->clip_scratch = carve<float>(c, 256, dry);
@@ -538,6 +554,7 @@ static void trainable_layout(dyt_ctx* c) {
     c->off_ub = o; o = a4(o + D);
     c->off_gw = o; o += D;       // gate weight and bias stay adjacent (one 769-wide reduction)
     c->off_gb = o; c->off_sc = o + 1; o = a4(o + 2);   // + the adapter's learnable scale (used under DYT_OPT_LEARNABLE_SCALE; a zero padding word otherwise)
+    if (c->cfg.adapter_ln) { c->off_alw = o; o += D; c->off_alb = o; o += D; }   // the adapter's LayerNorm: gamma and beta adjacent (one 1536-wide reduction)
     c->layer_stride = o;
     o = c->layer_stride * c->cfg.depth;
     c->off_hw = o; o = a4(o + C * D);
@@ -558,7 +575,7 @@ static void trainable_layout(dyt_ctx* c) {
 }
 
 extern "C" const char* dyt_last_error(void) { return g_err; }
-extern "C" int dyt_version(void) { return 1; }
+extern "C" int dyt_version(void) { return 2; }   // 2: dyt_config::adapter_ln appended (round 6)
 // 16-bit operand type of this build: 0 = bfloat16 (libdyt_hip.so), 1 = IEEE half (libdyt_hip_f16.so)
 extern "C" int dyt_operand_type(void) {
 #ifdef DYT_FP16
@@ -584,11 +601,17 @@ extern "C" int dyt_ctx_create(const dyt_config* cfg, dyt_ctx** out) {
         set_error("video model: max_batch %d must be a multiple of frames %d (and frames <= 38)", cfg->max_batch, cfg->frames);
         return DYT_ERR_ARG;
     }
+    if (cfg->adapter_ln < 0 || cfg->adapter_ln > 2 || (cfg->adapter_ln && cfg->frames > 1)) {
+        set_error("adapter_ln=%d: 0 (none), 1 (in) or 2 (out); image model only", cfg->adapter_ln);
+        return DYT_ERR_ARG;
+    }
     dyt_ctx* c = new dyt_ctx();
     c->cfg = *cfg;
     c->prec = cfg->precision;
     c->frames = cfg->frames > 1 ? cfg->frames : 1;
+    c->ad_ln = cfg->adapter_ln;
     if (c->frames > 1) c->cls_tail = false;   // every token of the last block reaches the pooling head
+    if (c->ad_ln) c->cls_tail = false;        // (generic path: the adapter's LayerNorm runs over all rows of every block)
     c->at = at_size(c->prec);
 #ifdef DYT_FP16
     if (c->prec != DYT_PREC_FP32) c->gs = 4096.0f;
@@ -676,6 +699,10 @@ extern "C" int dyt_trainable_offset(const dyt_ctx* c, int param, int layer, int6
         case DYT_P_AD_SCALE:
             if (layer < 0 || layer >= c->cfg.depth) { set_error("layer %d out of range", layer); return DYT_ERR_ARG; }
             *off = base + c->off_sc; *numel = 1; break;
+        case DYT_P_AD_LN_W: case DYT_P_AD_LN_B:
+            if (!c->ad_ln) { set_error("param %d exists with dyt_config.adapter_ln != 0 only", param); return DYT_ERR_ARG; }
+            if (layer < 0 || layer >= c->cfg.depth) { set_error("layer %d out of range", layer); return DYT_ERR_ARG; }
+            *off = base + (param == DYT_P_AD_LN_W ? c->off_alw : c->off_alb); *numel = D; break;
         case DYT_P_HEAD_W: *off = c->off_hw; *numel = C * D; break;
         case DYT_P_HEAD_B: *off = c->off_hb; *numel = C; break;
         case DYT_P_POOL_QUERY: case DYT_P_POOL_NQ_W: case DYT_P_POOL_NQ_B: case DYT_P_POOL_NK_W: case DYT_P_POOL_NK_B:
@@ -860,7 +887,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             c->overlap = value != 0; c->ov_pass = value == 1 || value == 2 || value == 4; c->ov_branch = value == 2 || value == 3;
             c->ov_bwd_serial = value == 4;
             return DYT_OK;
-        case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0 && c->frames <= 1; for (auto& S : c->slots) S.valid = false; return DYT_OK;
+        case DYT_OPT_CLS_TAIL: c->cls_tail = value != 0 && c->frames <= 1 && !c->ad_ln; for (auto& S : c->slots) S.valid = false; return DYT_OK;
         case DYT_OPT_SHARE_BLOCK0: c->share_block0 = value != 0; return DYT_OK;
         case DYT_OPT_GRAD_SCALE_LOG2:   // 16-bit gradient operands carry 2^value (0 = none); fp32 mode ignores it
             if (value < 0 || value > 24) { set_error("grad scale log2 %d out of range 0..24", value); return DYT_ERR_ARG; }
@@ -920,6 +947,7 @@ extern "C" int dyt_ctx_set_option(dyt_ctx* c, int option, int value) {
             // The scale words are the CALLER's (DYT_P_AD_SCALE of the flat trainable buffer handed to every call): a padding word -- zero -- until
             // the caller writes the reference's initial value 1.0 (models/dynamic_adapter.py:102).  Switching the meaning of that word between
             // passes would silently turn the adapters off (s = 0) or rescale them, so the option is fixed once a pass has run.
+            if (value != 0 && c->ad_ln) { set_error("learnable adapter scale together with the adapter's LayerNorm option is not supported"); return DYT_ERR_ARG; }
             if ((value != 0) != c->learn_scale && c->pass_ran) {
                 set_error("DYT_OPT_LEARNABLE_SCALE must be set before the first forward pass of the context");
                 return DYT_ERR_STATE;
@@ -994,15 +1022,19 @@ extern "C" int dyt_profile_read(dyt_ctx* c, int category, double* ms, int64_t* l
 static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     const dim3 grid((RP * D + 255) / 256, c->cfg.depth);
     const int64_t sc_off = c->learn_scale ? c->off_sc : -1;
+    // "out" form of the adapter's LayerNorm: its input is s (d_act W_up^T + b_up) -- scaled weight copies + a scaled bias copy for that GEMM
+    const bool out_ln = c->ad_ln == 2;
+    float* up_bp = (c->learn_scale || out_ln) ? c->ad_up_bp : nullptr;
+    const float ws_scale = out_ln ? c->cfg.adapter_scale : 0.f, b_scale = out_ln ? c->cfg.adapter_scale : 1.0f;
     if (c->prec == 0) {
         hipLaunchKernelGGL(prep_adapters_kernel<float>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (float*)c->ad_down_w, (float*)c->ad_down_wT, (float*)c->ad_up_w,
-                           (float*)c->ad_up_wT, c->ad_down_b, (float*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
+                           (float*)c->ad_up_wT, c->ad_down_b, out_ln ? (float*)c->ad_up_ws : (float*)nullptr, ws_scale, sc_off, c->off_ub, up_bp, b_scale);
         if (c->bwd16) {   // + the 16-bit transposes the 16-bit backward's adapter dgrads multiply by
             bf16* scr = (bf16*)c->ad_scratch16;
             hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                                c->off_uw, c->cfg.ffn_num, scr, (bf16*)c->ad_down_wT16, scr + (size_t)c->cfg.depth * RP * D,
-                               (bf16*)c->ad_up_wT16, c->ad_down_b, (bf16*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
+                               (bf16*)c->ad_up_wT16, c->ad_down_b, (bf16*)nullptr, 0.f, sc_off, c->off_ub, up_bp, b_scale);
             if (c->ad_up_w3) {   // [hi | lo] image of the fp32 up-projection copies just written (all blocks: depth * 768 rows of 64)
                 int rc = launch_split3_w((const float*)c->ad_up_w, c->ad_up_w3, c->cfg.depth * D, RP, s);
                 if (rc) return rc;
@@ -1011,7 +1043,7 @@ static int prep_adapters(dyt_ctx* c, const float* trainable, hipStream_t s) {
     } else
         hipLaunchKernelGGL(prep_adapters_kernel<bf16>, grid, dim3(256), 0, s, trainable, c->layer_stride, c->off_dw, c->off_db,
                            c->off_uw, c->cfg.ffn_num, (bf16*)c->ad_down_w, (bf16*)c->ad_down_wT, (bf16*)c->ad_up_w,
-                           (bf16*)c->ad_up_wT, c->ad_down_b, (bf16*)nullptr, 0.f, sc_off, c->off_ub, c->learn_scale ? c->ad_up_bp : nullptr);
+                           (bf16*)c->ad_up_wT, c->ad_down_b, out_ln ? (bf16*)c->ad_up_ws : (bf16*)nullptr, ws_scale, sc_off, c->off_ub, up_bp, b_scale);
     DYT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1262,18 +1294,23 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         // adapter; the gate gradient <g, mlp(x)> is recovered in tok_bwd by subtracting <g, adapter(x)>, which the adapter's own
         // backward operands give for 128 B per token (TokBwdArgs::cat_*).  The masked mode keeps the two-launch form.
         const bool need_h = save && !complete && !tail;
-        const bool cat = c->fc2_cat && P != 0 && !masked_dense && !dp2;   // (a scaled MLP branch cannot share its accumulator with the adapter's)
+        // the adapter's own LayerNorm (dyt_config::adapter_ln; reference models/dynamic_adapter.py:121-122 "in": down_proj reads LN_a(u); :132-133
+        // "out": the scaled up-projection output goes through LN_a before it joins the residual stream).  Generic kernels, no fusion with fc2.
+        const bool ad_in = c->ad_ln == 1, ad_out = c->ad_ln == 2;
+        const float* aln_w = base + c->off_alw; const float* aln_b = base + c->off_alb;
+        const bool cat = c->fc2_cat && P != 0 && !masked_dense && !dp2 && !ad_out;   // (a scaled MLP branch cannot share its accumulator with the adapter's)
         // Split fp32 forms whose backward runs on 16-bit operands ("fp16x3h", "fp16f8", "fp16x3q"; round 6): the same fusion with the up-projection as a
         // THREE-part product -- s d_act leaves the down-projection epilogue as a [hi | lo] image, W_up is split once per step (prep_adapters) --
         // contracted by the fc2 kernel as three leading tiles in front of its main loop (gemm.hip: LEAD); the dropped tokens' up-projection launch
         // runs on the same two images.  Until round 5 these modes ran the up-projection on the exact-fp32 MFMA kernel: an fp32
         // read-modify-write of [M,768] per block and pass (47 us) in front of the fc2 epilogue's own.
         static const bool cat3_env = !(getenv("DYT_FC2_CAT3") && atoi(getenv("DYT_FC2_CAT3")) == 0);   // measurement switch: 0 = the round-5 two-launch form in the split modes only
-        const bool cat3 = cat3_env && c->fc2_cat && P == 0 && c->split16 && c->bwd16 && T.dact3 && c->ad_up_w3 && !masked_dense && !dp2;
+        const bool cat3 = cat3_env && !ad_out && c->fc2_cat && P == 0 && c->split16 && c->bwd16 && T.dact3 && c->ad_up_w3 && !masked_dense && !dp2;
         L.h_has_adapter = (cat || cat3) && need_h;   // the saved "MLP output" of this block then includes the adapter: tok_bwd corrects <g, h>
         FORK(sb);
+        if (ad_in) RUN_ON(sb, 2, 0, launch_adapter_ln_fwd(P, L.u, aln_w, aln_b, T.xa, L.st_a, nullptr, Mr, s));
         {
-            GemmArgs a; a.A = tail ? S.ucls_at : L.u_at; a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
+            GemmArgs a; a.A = ad_in ? (const void*)T.xa : (tail ? S.ucls_at : L.u_at); a.W = at_off(c, c->ad_down_w, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
             a.bias = c->ad_down_b + l * RP; a.out_at = L.d_act; a.r = r; a.drop_p = drop_p;
             a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
             a.keep = keep_mask ? keep_mask + (size_t)l * M * r : nullptr;
@@ -1287,7 +1324,12 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
         GemmArgs up; up.A = L.d_act; up.W = at_off(c, c->ad_up_w, (size_t)l * RP * D); up.M = Mr; up.N = D; up.K = RP;
         up.bias = up_bias; up.resid = L.u; up.out_f32 = xo; up.scale = ad_scale;
         up.row_map = tail ? c->cls_rows : nullptr;
-        if (!cat && !cat3) RUN_ON(sb, 0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
+        if (ad_out) {   // x_out = u + LN_a(s (d_act W_up^T + b_up)): the LayerNorm's input is kept (its backward needs x_hat), fc2 then adds in place
+            GemmArgs g; g.A = L.d_act; g.W = at_off(c, c->ad_up_ws, (size_t)l * RP * D); g.M = Mr; g.N = D; g.K = RP;
+            g.bias = c->ad_up_bp + (size_t)l * D; g.out_f32 = L.up32;
+            RUN_ON(sb, 0, g.flops(), launch_gemm(P, EPI_BIAS_F32, g, s));
+            RUN_ON(sb, 2, 0, launch_adapter_ln_fwd(0, L.up32, aln_w, aln_b, xo, L.st_a, L.u, Mr, s));
+        } else if (!cat && !cat3) RUN_ON(sb, 0, up.flops(), launch_gemm(P, EPI_AD_UP, up, s));
         const uint16_t* up_w3 = cat3 ? (const uint16_t*)c->ad_up_w3 + (size_t)l * SPLIT_A * RP * D : nullptr;
         int* counts = S.counts + (size_t)l * B;
         if (use_gate) {
@@ -1618,10 +1660,21 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         }
         const void* A_g = g_at ? g_at : (const void*)gin;
         const int* kdev = (dense || tail) ? nullptr : L.total;
+        // the adapter's own LayerNorm (dyt_config::adapter_ln).  "out": the adapter branch sees the gradient BEHIND the LayerNorm -- its parameter
+        // gradients (dy = g, x_hat from the saved input) and dup = LNbwd(g), which replaces g as the operand of the up-projection's dgrad / wgrad.
+        const bool ad_in = c->ad_ln == 1, ad_out = c->ad_ln == 2;
+        const void* A_ad = A_g;
+        if (ad_out) {
+            RUN(2, 0, launch_ln_param_grad(P, A_g, L.up32, L.st_a, T.aln_part, gbase + c->off_alw, Mr, gs, s));
+            RUN(2, 0, launch_ln_bwd(P, A_g, L.up32, L.st_a, base + c->off_alw, nullptr, P == 0 ? T.dup : nullptr, Mr, P != 0 ? (void*)T.dup : nullptr,
+                                    nullptr, nullptr, nullptr, gs, s));
+            A_ad = T.dup;
+        }
+        if (ad_in) RUN(2, 0, launch_adapter_ln_fwd(P, L.u, base + c->off_alw, base + c->off_alb, T.xa, nullptr, nullptr, Mr, s));   // down_proj's wgrad operand LN_a(u), recomputed
         // ---- 2. adapter branch on the side stream: dgrad through up_proj, both wgrads, bias grads ----
         FORK(sb);
         {
-            GemmArgs a; a.A = A_g; a.W = at_offb(ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
+            GemmArgs a; a.A = A_ad; a.W = at_offb(ad_up_wT, (size_t)l * RP * D); a.M = Mr; a.N = RP; a.K = D;
             a.aux_at = Ldact; a.out_at = T.ddz; a.scale = scale; a.inv_keep = inv_keep;
             POISON(64, T.ddz, (size_t)Mr * RP * atb);
             ISO(16, RUN_ON(sb, 0, a.flops(), launch_gemm(P, EPI_AD_DGRAD_UP, a, s)););
@@ -1630,11 +1683,11 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         {   // both weight gradients (+ the two bias gradients as ones columns / rows) in one launch
             WgradArgs w[2];
             WgradArgs& a = w[0];
-            a.X = A_g; a.Y = Ldact; a.M = Mr; a.r = r; a.partial = S.wg_part[l];
+            a.X = A_ad; a.Y = Ldact; a.M = Mr; a.r = r; a.partial = S.wg_part[l];
             a.out_w = ubase + c->off_uw; a.sc = r; a.sj = 1; a.alpha = scale * inv_gs;       // up_proj.weight [768, r]  (X = g_at carries gs)
             a.out_xsum = ubase + c->off_ub; a.alpha_x = scale * inv_gs;                      // up_proj.bias
             WgradArgs& b = w[1];
-            b.X = tail ? ucls : Luat; b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = S.wg_part2[l];
+            b.X = ad_in ? (const void*)T.xa : (tail ? ucls : Luat); b.Y = T.ddz; b.M = Mr; b.r = r; b.partial = S.wg_part2[l];
             b.out_w = gbase + c->off_dw; b.sc = 1; b.sj = D; b.alpha = inv_gs;      // down_proj.weight [r, 768]  (Y = ddz carries gs)
             b.out_xsum = nullptr; b.alpha_x = 0.f;
             b.out_ysum = gbase + c->off_db; b.alpha_y = inv_gs;                     // down_proj.bias
@@ -1670,7 +1723,19 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
         // adapter dgrad ddz Wdown.  fp32 mode / cls tail: accumulated into g in place (fp32 read-modify-write of [M,768]);
         // bf16 mode: stored as a bf16 [M,768] operand that tok_bwd adds (half the bytes of the in-place update)
         const bool dad_at = P != 0 && !tail && !first;
-        if (!first) {
+        if (ad_in) {
+            // "in": ddz W_down is the gradient w.r.t. LN_a(u): the LayerNorm's parameter gradients from it (block 0 included), then its input gradient --
+            // 16-bit backward: a 16-bit operand tok_bwd adds (T.dup); fp32 backward: accumulated into g
+            GemmArgs a; a.A = T.ddz; a.W = at_offb(ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
+            if (P != 0) { a.out_at = Tdad; ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
+            else { a.out_f32 = T.dup; a.accumulate = 0; a.scale = 1.0f; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
+            const void* dln = P != 0 ? (const void*)Tdad : (const void*)T.dup;
+            RUN(2, 0, launch_ln_param_grad(P, dln, L.u, L.st_a, T.aln_part, gbase + c->off_alw, Mr, gs, s));
+            if (!first) {
+                if (P != 0) RUN(2, 0, launch_ln_bwd(P, dln, L.u, L.st_a, base + c->off_alw, nullptr, nullptr, Mr, T.dup, nullptr, nullptr, nullptr, gs, s));
+                else RUN(2, 0, launch_ln_bwd(P, dln, L.u, L.st_a, base + c->off_alw, gin, gin, Mr, nullptr, nullptr, nullptr, nullptr, gs, s));
+            }
+        } else if (!first) {
             GemmArgs a; a.A = T.ddz; a.W = at_offb(ad_down_wT, (size_t)l * RP * D); a.M = Mr; a.N = D; a.K = RP;
             if (dad_at) { a.out_at = Tdad; POISON(4, Tdad, (size_t)Mr * D * atb); ISO(16, RUN_GEMM(EPI_STORE_AT, a);); }
             else { a.out_f32 = gin; a.accumulate = 1; a.scale = inv_gs; ISO(16, RUN_GEMM(EPI_STORE_F32, a);); }
@@ -1686,7 +1751,7 @@ static int backward_impl(dyt_ctx* c, int slot, const float* trainable, const flo
             a.ln2_w = W.ln2_w; a.gate_w = student ? base + c->off_gw : nullptr; a.soft = L.soft; a.maskf = L.maskf;
             a.dmask = tail ? nullptr : T.dmask;
             a.g_cls = tail ? S.gcls : nullptr;
-            a.dad = dad_at ? Tdad : nullptr;
+            a.dad = dad_at ? (ad_in ? (void*)T.dup : Tdad) : nullptr;
             a.gs = gs; a.inv_gs = inv_gs;
             if (L.h_has_adapter && student && !tail) {
                 a.cat_dact = Ldact; a.cat_ddz = T.ddz; a.cat_bup = base + c->off_ub;

@@ -157,6 +157,109 @@ int launch_ln_bwd(int precision, const void* dy, const float* x, const float2* s
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// The adapter's own LayerNorm (tuning_config.ffn_adapter_layernorm_option "in" / "out"; reference models/dynamic_adapter.py:95-98,
+// 121-122,132-133: nn.LayerNorm(768) with the default eps 1e-5, trainable, applied to the adapter's input or to its scaled output).
+// Round 6: generic row kernels behind dyt_config::adapter_ln -- no shipped script uses the option, so nothing is fused.
+//   adapter_ln_fwd:     out = LN(x) w + b (+ resid)   as OT (the 16-bit operand type: down-projection input; float: x_out = u + LN(up))
+//   ln_param_grad:      per 32-row block:  partial[blk][0:768] = sum_t dy[t] xhat[t],  partial[blk][768:1536] = sum_t dy[t]   (x inv_gs)
+//   ln_param_reduce:    out[i] += sum_blk partial[blk][i]   (fixed order)
+// ------------------------------------------------------------------------------------------
+constexpr float AD_LN_EPS = 1e-5f;
+template <class OT>
+__global__ __launch_bounds__(256) void adapter_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             OT* __restrict__ out, float2* __restrict__ stats, const float* __restrict__ resid, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row12 xr, wr, br, rr;
+    xr.load(x + (size_t)row * D, lane);
+    wr.load(w, lane);
+    br.load(b, lane);
+    if (resid) rr.load(resid + (size_t)row * D, lane);
+    xr.landed(); wr.landed(); br.landed();
+    if (resid) rr.landed();
+    const float mean = xr.sum() * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float d = xr.v[i] - mean; sq = fmaf(d, d, sq); }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / D) + AD_LN_EPS);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        xr.v[i] = (xr.v[i] - mean) * rstd * wr.v[i] + br.v[i];
+        if (resid) xr.v[i] += rr.v[i];
+    }
+    xr.store(out + (size_t)row * D, lane);
+    if (stats && lane == 0) stats[row] = make_float2(mean, rstd);
+}
+int launch_adapter_ln_fwd(int out_at_precision, const float* x, const float* w, const float* b, void* out, float2* stats, const float* resid,
+                          int rows, hipStream_t s) {
+    const int grid = (rows + 3) / 4;
+    if (out_at_precision == 0)
+        hipLaunchKernelGGL(adapter_ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, b, (float*)out, stats, resid, rows);
+    else
+        hipLaunchKernelGGL(adapter_ln_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, x, w, b, (bf16*)out, stats, resid, rows);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+constexpr int LNPG_ROWS = 32;   // rows per workgroup
+template <class AT>
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const AT* __restrict__ dy, const float* __restrict__ x, const float2* __restrict__ stats,
+                                                            float* __restrict__ partial, int rows, float inv_gs) {
+    __shared__ float red[4][2 * D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Row12 dg, db;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { dg.v[i] = 0.f; db.v[i] = 0.f; }
+    const int r0 = blockIdx.x * LNPG_ROWS;
+    for (int k = wave; k < LNPG_ROWS; k += 4) {
+        const int r = r0 + k;
+        if (r >= rows) break;
+        Row12 g, xr;
+        g.load_at(dy + (size_t)r * D, lane);
+        xr.load(x + (size_t)r * D, lane);
+        float2 st = stats[r];
+        g.landed(); xr.landed();
+        DYT_PIN2(st.x, st.y);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const float gv = g.v[i] * inv_gs;
+            db.v[i] += gv;
+            dg.v[i] = fmaf(gv, (xr.v[i] - st.x) * st.y, dg.v[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][i * 256 + lane * 4 + e] = dg.v[4 * i + e];
+            red[wave][D + i * 256 + lane * 4 + e] = db.v[4 * i + e];
+        }
+    __syncthreads();
+    for (int c = tid; c < 2 * D; c += 256)
+        partial[(size_t)blockIdx.x * (2 * D) + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * D) return;
+    float t = 0.f;
+    for (int p = 0; p < nparts; ++p) t += partial[(size_t)p * (2 * D) + i];
+    out[i] += t;
+}
+// dgamma -> out[0:768], dbeta -> out[768:1536] (+=); dy carries the 16-bit gradient factor gs when precision != 0
+int launch_ln_param_grad(int precision, const void* dy, const float* x, const float2* stats, float* partial, float* out, int rows, float gs, hipStream_t s) {
+    const int nblk = (rows + LNPG_ROWS - 1) / LNPG_ROWS;
+    if (precision == 0)
+        hipLaunchKernelGGL(ln_param_grad_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)dy, x, stats, partial, rows, 1.0f);
+    else
+        hipLaunchKernelGGL(ln_param_grad_kernel<bf16>, dim3(nblk), dim3(256), 0, s, (const bf16*)dy, x, stats, partial, rows, 1.0f / gs);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, partial, nblk, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+int64_t ln_param_grad_scratch_floats(int rows) { return (int64_t)((rows + LNPG_ROWS - 1) / LNPG_ROWS) * 2 * D; }
+
 // the folded LayerNorm form's weight side (GemmArgs::ln_part), one wave per output feature n, from the fp32 weight (one rounding, like the
 // plain 16-bit copy): Wf[n,:] = AT(gamma * W[n,:]), cs[n] = sum of the ROUNDED Wf[n,:] (what the matrix cores contract), bf[n] = bias[n] + <W[n,:], beta>
 template <class AT>

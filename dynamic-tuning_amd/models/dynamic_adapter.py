@@ -52,6 +52,16 @@ class _LinearParams(nn.Module):
         return "in_features=%d, out_features=%d, bias=%s" % (self.in_features, self.out_features, self.bias is not None)
 
 
+class _AdapterLayerNormParams(nn.Module):
+    """nn.LayerNorm(dim)'s parameter surface (``weight`` ones, ``bias`` zeros; eps 1e-5)."""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
 class TokenSelect(nn.Module):
     """Reference models/dynamic_adapter.py:58-77."""
 
@@ -102,10 +112,14 @@ class Adapter(nn.Module):
         self.n_embd = config.d_model if d_model is None else d_model
         self.down_size = config.attn_bn if bottleneck is None else bottleneck
         self.adapter_layernorm_option = adapter_layernorm_option
-        if adapter_layernorm_option in ("in", "out"):
-            raise NotImplementedError("adapter_layernorm_option=%r: the reference's entry points only use 'none' "
-                                      "(main_image.py:190, main_vtab.py:183)" % adapter_layernorm_option)
+        if adapter_layernorm_option not in ("none", "in", "out"):
+            raise ValueError("adapter_layernorm_option=%r" % (adapter_layernorm_option,))
+        # reference :95-98: nn.LayerNorm(n_embd) (default eps 1e-5, trainable: an "adaptmlp." tensor) for "in" (applied to the adapter's input,
+        # :121-122) and "out" (applied to its scaled output, :132-133); the shipped scripts pass "none".  Inside a VisionTransformer it runs in
+        # the HIP path (dyt_config.adapter_ln, round 6)
         self.adapter_layer_norm_before = None
+        if adapter_layernorm_option in ("in", "out"):
+            self.adapter_layer_norm_before = _AdapterLayerNormParams(self.n_embd)
         if adapter_scalar == "learnable_scalar":   # reference :101-102: trainable (the freeze rule keeps every "adaptmlp." tensor), DYT_OPT_LEARNABLE_SCALE
             self.scale = nn.Parameter(torch.ones(1))
         else:
@@ -113,6 +127,11 @@ class Adapter(nn.Module):
         self.down_proj = _LinearParams(self.n_embd, self.down_size)
         self.up_proj = _LinearParams(self.down_size, self.n_embd)
         self.dropout = dropout
+
+    @property
+    def adapter_ln_code(self):
+        """dyt_config.adapter_ln: 0 "none", 1 "in", 2 "out"."""
+        return {"none": 0, "in": 1, "out": 2}[self.adapter_layernorm_option]
 
     def _init_weights(self):
         with torch.no_grad():  # reference :112-117
@@ -128,6 +147,9 @@ class Adapter(nn.Module):
         dropout draw, otherwise Philox(``seed``) in training mode."""
         if not x.is_cuda:
             raise DyTError("Adapter runs on the HIP device only")
+        if self.adapter_layer_norm_before is not None:
+            raise NotImplementedError("the stand-alone Adapter.forward runs the 'none' option; 'in' / 'out' run inside a VisionTransformer "
+                                      "(dyt_config.adapter_ln)")
         shape = x.shape
         xf = x.detach().float().reshape(-1, self.n_embd).contiguous()
         res = None

@@ -103,7 +103,7 @@ class Block(nn.Module):
             self._engine = None
             eng = DyTEngine(1, self.adaptmlp.down_size, self.adaptmlp.scale, device, precision=self.precision, max_batch=batch, depth=1,
                             slots=1, adapter_dropout=self.adaptmlp.dropout, tau=self.mlp_token_select.tau,
-                            threshold=self.mlp_token_select.threshold)
+                            threshold=self.mlp_token_select.threshold, adapter_ln=self.adaptmlp.adapter_ln_code)
             self._engine, self._engine_state = eng, None
         state = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if state != self._engine_state:
@@ -280,7 +280,8 @@ class VisionTransformer(nn.Module):
             eng = DyTEngine(self.num_classes, self.tuning_config.ffn_num, self.blocks[0].adaptmlp.scale, device,
                             precision=self.precision, max_batch=mb, depth=self.depth,
                             adapter_dropout=self.blocks[0].adaptmlp.dropout, tau=self.blocks[0].mlp_token_select.tau,
-                            threshold=self.blocks[0].mlp_token_select.threshold, frames=self._frames or 1)
+                            threshold=self.blocks[0].mlp_token_select.threshold, frames=self._frames or 1,
+                            adapter_ln=self.blocks[0].adaptmlp.adapter_ln_code)
             self._engine = eng
             self._sync_state = None
         if getattr(eng, "drop_path_rate", 0.0) != self.drop_path_rate:

@@ -41,7 +41,7 @@ def parse_precision(p):
 
 class DyTEngine:
     def __init__(self, num_classes, ffn_num, adapter_scale, device, precision=PREC_BF16, max_batch=128, depth=12,
-                 slots=2, adapter_dropout=0.1, tau=5.0, threshold=0.5, frames=1):
+                 slots=2, adapter_dropout=0.1, tau=5.0, threshold=0.5, frames=1, adapter_ln=0):
         if torch.device(device).type != "cuda":
             raise DyTError("the DyT path runs on a HIP device only (got %s); there is no CPU path" % (device,))
         self.device = torch.device(device)
@@ -58,7 +58,8 @@ class DyTEngine:
         self.learnable_scale = isinstance(adapter_scale, torch.Tensor)
         self.cfg = Config(int(num_classes), int(ffn_num), int(depth), lib_prec,
                           int(max_batch), int(slots), 1.0 if self.learnable_scale else float(adapter_scale), float(adapter_dropout), float(tau),
-                          float(threshold), int(frames))
+                          float(threshold), int(frames), int(adapter_ln))   # adapter_ln: 0 none / 1 "in" / 2 "out" (tuning_config.ffn_adapter_layernorm_option)
+        self.adapter_ln = int(adapter_ln)
         self.frames = max(1, int(frames))   # > 1: video model, every batch is clips * frames images
         self.L = lib(fp16=self.precision == PREC_FP16 or split != 0)
         h = ctypes.c_void_p()

@@ -140,6 +140,18 @@ def add_learnable_scales(sd, seed=0, depth=DEPTH):
     return sd
 
 
+def add_adapter_layernorm(sd, seed=0, depth=DEPTH):
+    """``blocks.i.adaptmlp.adapter_layer_norm_before.{weight,bias}`` [768] for ``ffn_adapter_layernorm_option`` "in" / "out" (reference
+    init: ones / zeros, models/dynamic_adapter.py:97; here distinct values so that the parameters and their gradients are tested).  The keys
+    sit right behind the block's gate (registration order of the reference's Adapter: layer norm first) -- order is irrelevant to the tests."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    out = dict(sd)
+    for i in range(depth):
+        out["blocks.%d.adaptmlp.adapter_layer_norm_before.weight" % i] = 0.7 + 0.6 * torch.rand(DIM, generator=g)
+        out["blocks.%d.adaptmlp.adapter_layer_norm_before.bias" % i] = 0.2 * torch.randn(DIM, generator=g)
+    return out
+
+
 def make_batch(batch, num_classes=100, seed=0):
     """Images ``N(0,1)`` [B,3,224,224] fp32 and int64 targets."""
     x = _normal("images", (batch, 3, 224, 224), seed, 1.0)

@@ -97,6 +97,7 @@ enum dyt_param {
     DYT_P_POOL_Q_BIAS, DYT_P_POOL_V_BIAS,             /* T attentive_blocks.cross_attn.{q_bias,v_bias} [768] */
     DYT_P_POOL_PROJ_W, DYT_P_POOL_PROJ_B,             /* T attentive_blocks.cross_attn.proj [768,768] */
     DYT_P_AD_SCALE,     /* T blocks.i.adaptmlp.scale [1] -- only with tuning_config.ffn_adapter_scalar == "learnable_scalar" (DYT_OPT_LEARNABLE_SCALE) */
+    DYT_P_AD_LN_W, DYT_P_AD_LN_B,   /* T blocks.i.adaptmlp.adapter_layer_norm_before.{weight,bias} [768] -- only with dyt_config::adapter_ln != 0 */
     DYT_P_COUNT
 };
 
@@ -119,6 +120,11 @@ typedef struct dyt_config {
                                 ("b c t h w -> (b t) c h w"), batch % t == 0; logits / targets have b = batch/t rows;
                                 the cls-pooling head is replaced by the attentive pooling head over the t*197
                                 final-norm tokens of a clip (one query, 12 heads) */
+    int32_t adapter_ln;      /* tuning_config.ffn_adapter_layernorm_option (models/dynamic_adapter.py:88,95-98,121-122,132-133): 0 = "none" (every
+                                shipped script), 1 = "in": the adapter reads LayerNorm(u) (its own trainable nn.LayerNorm(768), eps 1e-5), 2 = "out":
+                                the scaled adapter output goes through that LayerNorm before it joins the residual stream.  Adds the two
+                                [768] tensors DYT_P_AD_LN_W / _B per block to the flat trainable layout.  Generic row kernels (no fusion, no
+                                cls-only tail); image model only.  (ABI v2: the field was appended in round 6.) */
 } dyt_config;
 
 typedef struct dyt_ctx dyt_ctx;

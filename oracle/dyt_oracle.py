@@ -82,17 +82,28 @@ def token_select(sd, p, x, g1, g2, training, tau=5.0, threshold=0.5):
     return sel, logits
 
 
+ADAPTER_LN_KEY = "oracle.adapter_layernorm_option"   # int tensor in the state dict handed to the oracle: 1 = "in", 2 = "out" (absent: "none")
+
+
 def adapter(sd, p, x, scale, keep_mask=None, drop_p=0.1):
-    """Adapter.forward with layernorm option "none" and add_residual=False,
-    models/dynamic_adapter.py:120-140.  ``keep_mask`` (0/1, same shape as the bottleneck
-    activation) replaces the Bernoulli draw of F.dropout (:127); None = eval / p=0."""
+    """Adapter.forward with add_residual=False, models/dynamic_adapter.py:120-140.  ``keep_mask`` (0/1, same shape as the bottleneck
+    activation) replaces the Bernoulli draw of F.dropout (:127); None = eval / p=0.  Layernorm option "none" unless the state dict
+    carries ``ADAPTER_LN_KEY`` and the block's ``adaptmlp.adapter_layer_norm_before.{weight,bias}`` (nn.LayerNorm(768), default eps 1e-5,
+    :95-98): "in" normalises the adapter's input (:121-122), "out" its scaled output (:132-133)."""
+    ln = int(sd[ADAPTER_LN_KEY]) if ADAPTER_LN_KEY in sd else 0
+    lw, lb = sd.get(p + "adaptmlp.adapter_layer_norm_before.weight"), sd.get(p + "adaptmlp.adapter_layer_norm_before.bias")
+    if ln == 1:
+        x = F.layer_norm(x, (x.shape[-1],), lw, lb, 1e-5)
     down = F.relu(F.linear(x, sd[p + "adaptmlp.down_proj.weight"], sd[p + "adaptmlp.down_proj.bias"]))
     if keep_mask is not None:
         down = down * keep_mask.to(down.dtype) * (1.0 / (1.0 - drop_p))
     up = F.linear(down, sd[p + "adaptmlp.up_proj.weight"], sd[p + "adaptmlp.up_proj.bias"])
     if p + "adaptmlp.scale" in sd:   # adapter_scalar == "learnable_scalar": nn.Parameter(torch.ones(1)), :101-102 (trainable: an "adaptmlp." tensor)
         scale = sd[p + "adaptmlp.scale"]
-    return up * scale  # :130
+    up = up * scale  # :130
+    if ln == 2:
+        up = F.layer_norm(up, (up.shape[-1],), lw, lb, 1e-5)
+    return up
 
 
 def mlp(sd, p, x):

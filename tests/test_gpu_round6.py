@@ -273,3 +273,110 @@ def test_forward_features_and_forward_head_compose_to_forward(precision):
     w, b = m.norm.weight.detach(), m.norm.bias.detach()
     xh = (feats - b) / w
     assert float(xh.mean(-1).abs().max()) < 1e-3 and float((xh.var(-1, unbiased=False) - 1).abs().max()) < 1e-2
+
+
+# ---- tuning_config.ffn_adapter_layernorm_option = "in" / "out" (dyt_config.adapter_ln; reference models/dynamic_adapter.py:88,95-98,121-122,132-133) ----
+@pytest.mark.parametrize("option", ["in", "out"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16", "bf16"])
+def test_adapter_layernorm_step_vs_reference_golden(precision, option):
+    """The reference model with the adapter's own trainable LayerNorm on its input ("in", the Adapter class's default) or on its scaled
+    output ("out"), stepped through its own train_one_epoch (tests/golden/adapter_ln_{in,out}_step.npz, distinct gamma / beta per block):
+    logits, masks, losses and all 98 gradients -- the 24 d(gamma) / d(beta) included -- of the fused step, masked mode against the
+    reference's values and compact mode against the oracle's; fp32 also the LayerNorm parameters after one AdamW update."""
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "adapter_ln_%s_step.npz" % option)))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    sd = synth.add_adapter_layernorm(synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3), seed=seed)
+    sd_oracle = dict(sd)
+    sd_oracle[O.ADAPTER_LN_KEY] = torch.tensor({"in": 1, "out": 2}[option])
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option=option, ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+    tol = D.TOL[precision]
+    for mode in ("masked", "compact"):
+        model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                           precision=precision, train_mode=mode)
+        msg = model.load_state_dict(sd, strict=True)
+        assert not msg.missing_keys and not msg.unexpected_keys
+        for n, p in model.named_parameters():
+            p.requires_grad = synth.is_trainable(n)
+        model = model.cuda()
+        assert sum(p.requires_grad for p in model.parameters()) == 98
+        model.train()
+        eng = model.engine(B, torch.device("cuda", 0))
+        assert eng.adapter_ln == {"in": 1, "out": 2}[option]
+        ls, lt = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        ts = torch.zeros(B, 12, 196, device="cuda")
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                  g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+        es = float(np.abs(ls.cpu().numpy() - g["logits_student"]).max())
+        et = float(np.abs(lt.cpu().numpy() - g["logits_teacher"]).max())
+        flips = int((ts.cpu().numpy().astype(np.uint8) != g["token_select"][..., 0]).sum())
+        el = max(abs(float(losses[i]) - float(g["stat_" + k])) / max(1.0, abs(float(g["stat_" + k])))
+                 for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")))
+        if mode == "masked":
+            gref = {n[len("grad/"):]: torch.from_numpy(v) for n, v in g.items() if n.startswith("grad/")}
+        else:
+            _, gref, _ = O.step_grads(sd_oracle, x, y, g1, g2, keep, scale=0.1, mode="compact")
+        items = [(n, eng.trainable_view(n, gr.shape, eng.grad).cpu(), gr) for n, gr in gref.items()]
+        lnp = [it for it in items if "adapter_layer_norm_before" in it[0]]
+        assert len(lnp) >= 6
+        e_ln = max(float((a - b).norm() / max(float(b.norm()), 1e-20)) for _, a, b in lnp)
+        items = [it for it in items if "adapter_layer_norm_before" not in it[0]]
+        if precision != "fp32":
+            sc1 = [it for it in items if it[2].numel() == 1]
+            items = [it for it in items if it[2].numel() > 1]
+            if sc1:
+                items.append(("mlp_token_select.mlp_head.bias (12 blocks)", torch.stack([a.reshape(()) for _, a, _ in sc1]), torch.stack([b.reshape(()) for _, _, b in sc1])))
+        worst = {}
+        for n, got, ref in items:
+            e = float((got - ref).norm() / max(float(ref.norm()), 1e-20))
+            k = D.grad_kind(n) if precision in ("fp16", "bf16") else "all"
+            if e > worst.get(k, (0.0, ""))[0]:
+                worst[k] = (e, n)
+        print("adapter LayerNorm %r %s/%s: logits %.2e / %.2e, %d decisions differ, losses %.1e, d(gamma) / d(beta) %.1e, gradients %s" %
+              (option, precision, mode, es, et, flips, el, e_ln, {k: "%.1e" % v[0] for k, v in worst.items()}))
+        assert es <= tol["logits"] and et <= tol["logits"] and flips <= tol["step_flips"] and el <= tol["loss"]
+        # the 16-bit modes at this small batch: d(gamma) / d(beta) sit upstream of down_proj ("in") or between up_proj and the residual ("out"),
+        # so they take the adapter classes' bounds; bf16 flips 1-2 of the 4704 gate decisions here, and a flipped token changes every adapter
+        # gradient of its block by a whole token's contribution (measured: "in" d(gamma) 0.19, "out" up_proj.bias 0.086) -> twice the class
+        # bound when decisions differ.  fp32 / the split modes / fp16 flip none and keep the suite's bounds
+        slack = 2.0 if (precision == "bf16" and flips) else 1.0
+        small_b = D.FP16_GRAD_TOL_SMALL_B if precision == "fp16" else D.BF16_GRAD_TOL_SMALL_B
+        assert e_ln <= (2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else slack * small_b["adaptmlp.down_proj"]))
+        for k, (e, n) in worst.items():
+            bound = 2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else slack * small_b[k])
+            assert e <= bound, (mode, k, n, e, bound)
+        if precision == "fp32" and mode == "masked":
+            D.D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
+            for key in g:
+                if key.startswith("param_after/"):
+                    n = key.split("/", 1)[1]
+                    got = eng.trainable_view(n, g[key].shape).cpu().numpy()
+                    # the first AdamW update is lr * g / (|g| + 1e-8): where the reference's |g| is within 100x of Adam's eps (a few of the 768
+                    # d(beta) / d(gamma) elements are ~1e-8), fp32 summation-order noise in g moves the update by a few % of lr
+                    gg = np.abs(g["grad/" + n])
+                    err = np.abs(got - g[key])
+                    assert err[gg > 1e-6].max(initial=0.0) < 2e-5 and err.max() < 0.1 * float(g["meta_lr"]), n
+        if mode == "compact":
+            # inference (deterministic gate, no dropout): the dynamic pass and complete_model against the oracle, forward_features too
+            model.eval()
+            with torch.no_grad():
+                le, aux = model(x.cuda())
+                lc, _ = model(x.cuda(), complete_model=True)
+            oe, oaux = O.forward(sd_oracle, x, training=False, mode="compact")
+            oc, _ = O.forward(sd_oracle, x, training=False, complete_model=True)
+            ee, ec = float((le.cpu() - oe).abs().max()), float((lc.cpu() - oc).abs().max())
+            ef = int((aux["token_select"].cpu() != oaux["token_select"]).sum())
+            print("adapter LayerNorm %r %s eval: logits %.2e / %.2e, %d decisions differ" % (option, precision, ee, ec, ef))
+            assert ee <= tol["logits"] and ec <= tol["logits"] and ef <= tol["eval_flips"]
+            feats, _ = model.forward_features(x.cuda())
+            assert float((model.forward_head(feats) - le).abs().max()) < (2e-5 if precision == "fp32" else 5e-3)
+        del model, eng
+        torch.cuda.empty_cache()

@@ -84,8 +84,12 @@ def test_unsupported_configs_are_rejected():
         VisionTransformer(drop_path_rate=1.0, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0))
     assert VisionTransformer(drop_path_rate=0.1, tuning_config=tuning, select_config=Cfg(open=True, keep_layers=0)).drop_path_rate == 0.1   # (round 5: supported)
     from models.dynamic_adapter import Adapter
-    with pytest.raises(NotImplementedError):
-        Adapter(d_model=768, bottleneck=8, adapter_layernorm_option="in")
+    a = Adapter(d_model=768, bottleneck=8)   # the class default is "in" (reference models/dynamic_adapter.py:88): supported since round 6
+    assert a.adapter_layernorm_option == "in" and a.adapter_ln_code == 1 and tuple(a.adapter_layer_norm_before.weight.shape) == (768,)
+    assert [k for k, _ in a.named_parameters()][:2] == ["adapter_layer_norm_before.weight", "adapter_layer_norm_before.bias"]   # the reference's registration order
+    assert Adapter(d_model=768, bottleneck=8, adapter_layernorm_option="none").adapter_layer_norm_before is None
+    with pytest.raises(ValueError):
+        Adapter(d_model=768, bottleneck=8, adapter_layernorm_option="both")
     # select_config.keep_layers / open: the reference hands them to Block as `select`, which Block.__init__ never reads
     # (models/vision_transformer_IN21K.py:106,138,311) -- every value builds the same model there, and here
     a = VisionTransformer(tuning_config=tuning, select_config=Cfg(open=True, keep_layers=4))
@@ -110,7 +114,12 @@ def test_key_mapping_covers_state_dict():
     assert seen == set(range(_lib.P_AD_SCALE))
     # "learnable_scalar": one more trainable word per block
     pid, layer = _lib.key_to_param("blocks.7.adaptmlp.scale")
-    assert pid == _lib.P_AD_SCALE == _lib.P_COUNT - 1 and layer == 7 and _lib.is_trainable_param(pid) and synth.is_trainable("blocks.7.adaptmlp.scale")
+    assert pid == _lib.P_AD_SCALE == _lib.P_COUNT - 3 and layer == 7 and _lib.is_trainable_param(pid) and synth.is_trainable("blocks.7.adaptmlp.scale")
+    # ffn_adapter_layernorm_option "in" / "out" (round 6): the adapter's own LayerNorm, two more trainable tensors per block
+    for k, want in (("blocks.3.adaptmlp.adapter_layer_norm_before.weight", _lib.P_AD_LN_W), ("blocks.3.adaptmlp.adapter_layer_norm_before.bias", _lib.P_AD_LN_B)):
+        pid, layer = _lib.key_to_param(k)
+        assert pid == want and layer == 3 and _lib.is_trainable_param(pid) and synth.is_trainable(k)
+    assert _lib.P_AD_LN_B == _lib.P_COUNT - 1
 
 
 def test_video_module_parameter_surface():

@@ -302,3 +302,29 @@ def test_learnable_scalar_step_vs_reference(golden_dir):
         assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-8, n
         if "grad/" + n in g:
             assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-8, n
+
+
+@pytest.mark.parametrize("option", ["in", "out"])
+def test_adapter_layernorm_step_vs_reference(golden_dir, option):
+    """ffn_adapter_layernorm_option "in" / "out" (the Adapter class's default is "in", models/dynamic_adapter.py:88,95-98,121-122,132-133):
+    the reference model stepped through its own train_one_epoch with distinct LayerNorm parameters (tests/golden/make_golden_adapter_ln.py)
+    against the oracle: logits, masks, losses, all 98 gradients incl. the 24 d(gamma) / d(beta)."""
+    g = load(golden_dir, "adapter_ln_%s_step.npz" % option)
+    B, C, r = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = synth.add_adapter_layernorm(state(g), seed=int(g["meta_seed"]))
+    sd[O.ADAPTER_LN_KEY] = torch.tensor(int(g["meta_option"]))
+    assert int(g["meta_option"]) == {"in": 1, "out": 2}[option]
+    x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    keep = synth.make_dropout_masks(B, r, seed=int(g["meta_seed"]) + 3)
+    d, grads, outs = O.step_grads(sd, x, y, torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"]), keep, scale=0.1, mode="masked")
+    assert np.abs(outs[0].detach().numpy() - g["logits_student"]).max() < 2e-5
+    assert np.abs(outs[1].detach().numpy() - g["logits_teacher"]).max() < 2e-5
+    assert np.array_equal(outs[2]["token_select"].detach().numpy().astype(np.uint8), g["token_select"])
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(float(d[k]) - float(g["stat_" + k])) < 1e-5 * max(1.0, abs(float(g["stat_" + k]))), k
+    assert len(grads) == 98 and sum("adapter_layer_norm_before" in n for n in grads) == 24
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-8, n
+        if "grad/" + n in g:
+            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-8, n
