@@ -1233,6 +1233,9 @@ static int run_bf16(const GemmArgs& a, const Epi& epi, hipStream_t s) {
     }
     if constexpr (CAT) {
         if (!a.A2 || !a.W2 || a.N % 128 != 0) { set_error("gemm_bf16: K-concatenated form needs A2, W2 and N %% 128 == 0 (N=%d)", a.N); return -1; }
+        // (Round 6: this form through the pre-shuffled-weight kernel -- the leading tile in its prologue's DMA round, bit-identical results -- measured
+        // 175 us serial against 123 + 28 us here and 23.4 vs 23.2 ms in the step: the fp32 read-modify-write epilogue of a 128x256 tile does not fit
+        // beside 128 accumulators -- 20-37 spilled registers.  Not kept; profiles/round6/r6_fc2_bpre_ab.txt.)
     } else if constexpr (LEAD > 0) {
         if (!a.A2 || !a.W2 || a.N % 128 != 0 || !a.a_fold) { set_error("gemm_bf16: leading three-part tiles need A2, W2, the split form and N %% 128 == 0 (N=%d)", a.N); return -1; }
     } else {
@@ -1433,7 +1436,7 @@ static int dispatch(EpiKind kind, const GemmArgs& a, hipStream_t s) {
             }
             return run<AT, SPLIT>(a, EpiAdDown<AT>{a.bias, (AT*)a.out_at, a.keep, a.r, a.inv_keep, a.drop_p, a.seed, a.subseq, a.row_map, a.seed_dev, (AT*)a.out_at2, a.scale, (bf16*)a.out3, a.out3_scale}, s);
         case EPI_AD_UP:
-            if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr, a.row_scale}, s);
+            if (a.row_map) return run<AT, SPLIT>(a, EpiAdUp<true>{a.bias, a.resid, a.out_f32, a.scale, a.row_map, nullptr, a.row_scale, a.bias_scale}, s);
             return run<AT, SPLIT>(a, EpiAdUp<false>{a.bias, a.resid, a.out_f32, a.scale, nullptr, a.row_mask, nullptr, a.bias_scale}, s);
         case EPI_AD_DGRAD_UP:
             return run<AT, SPLIT>(a, EpiAdDgradUp<AT>{(const AT*)a.aux_at, (AT*)a.out_at, a.scale, a.inv_keep}, s);

@@ -184,7 +184,8 @@ int launch_gate(const GateArgs& a, hipStream_t s);
 // also computes the row offsets (prefix of counts) itself and publishes total[0] = sum(counts)
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
-                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3 = nullptr, int out3_f8 = 0);
+                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3 = nullptr, int out3_f8 = 0,
+                     int* drop_src = nullptr);   // drop_src: + the dropped tokens' rows, ascending, and total[1] = their number (as launch_gather_index)
 
 // the index half of launch_ln_gather alone (dense forward that is followed by a compacted backward): row_src, dst_of, total
 int launch_gather_index(const int* keep_local, const int* counts, int* total, const float* maskf, int* row_src, int* dst_of,

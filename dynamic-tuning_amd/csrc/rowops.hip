@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
                                                         const int* __restrict__ counts, int* __restrict__ total,
                                                         const float* __restrict__ maskf, AT* __restrict__ out,
                                                         float2* __restrict__ stats, int* __restrict__ row_src,
-                                                        int* __restrict__ dst_of, int batch, bf16* __restrict__ out3, int f8) {
+                                                        int* __restrict__ dst_of, int batch, bf16* __restrict__ out3, int f8,
+                                                        int* __restrict__ drop_src) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= batch * NT) return;
@@ -383,11 +384,20 @@ __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict_
         for (int i = lane; i < lim; i += 64) part += counts[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if (slot == 0) { if (lane == 0) total[0] = part; }
+        if (slot == 0) { if (lane == 0) { total[0] = part; if (drop_src) total[1] = batch * NT - part; } }
         else off = part;
     }
     // role 1: this wave owns TOKEN `slot`: a dropped token has no compact row
-    if (lane == 0 && maskf[slot] == 0.f) dst_of[slot] = -1;
+    if (maskf[slot] == 0.f) {
+        if (lane == 0) dst_of[slot] = -1;
+        if (drop_src) {   // ... and is entry (tokens before it - kept tokens before it) of the ascending list of dropped rows (gather_index_kernel's)
+            int kept = 0;
+            for (int i = lane; i < j; i += 64) kept += maskf[b * NT + i] != 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
+            if (lane == 0) drop_src[slot - off - kept] = slot;
+        }
+    }
     // role 2: this wave owns COMPACT slot j of image b
     if (j >= cnt) return;
     const int src = b * NT + keep_local[(size_t)b * NT + j];
@@ -463,14 +473,14 @@ int launch_gather_index(const int* keep_local, const int* counts, int* total, co
 
 int launch_ln_gather(int precision, const float* u, const float* w, const float* b, const int* keep_local,
                      const int* counts, int* total, const float* maskf, void* out, float2* stats,
-                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3, int out3_f8) {
+                     int* row_src, int* dst_of, int batch, hipStream_t s, void* out3, int out3_f8, int* drop_src) {
     const int grid = (batch * NT + 3) / 4;
     if (precision == 0)
         hipLaunchKernelGGL(ln_gather_kernel<float>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, total,
-                           maskf, (float*)out, stats, row_src, dst_of, batch, (bf16*)out3, out3_f8);
+                           maskf, (float*)out, stats, row_src, dst_of, batch, (bf16*)out3, out3_f8, drop_src);
     else
         hipLaunchKernelGGL(ln_gather_kernel<bf16>, dim3(grid), dim3(256), 0, s, u, w, b, keep_local, counts, total,
-                           maskf, (bf16*)out, stats, row_src, dst_of, batch, (bf16*)nullptr, 0);
+                           maskf, (bf16*)out, stats, row_src, dst_of, batch, (bf16*)nullptr, 0, drop_src);
     LAUNCH_CHECK();
     return 0;
 }
