@@ -243,6 +243,7 @@ struct dyt_ctx {
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     int split_bwd_parts = 3;    // ... products of the GRADIENT GEMMs' contraction (DYT_SPLIT_BWD_PARTS: 3 full, 2 = dY_hi * (W_hi + W_lo), 1 = dY_hi * W_hi)
     int split_bwd_attn_parts = 3;   // ... and of the split attention backward's dP / dQ / dK / dV products (3 or 1; the score recomputation keeps three)
+    int one_part_complete = 0;  // ... classes of a complete_model (teacher) pass contracted as hi * hi alone (SPLIT_F)
     int split_fwd_parts[4] = {3, 3, 3, 3};   // ... products of the FORWARD GEMMs per class (qkv, proj, fc1, fc2): measurement knob
     bool split_wgrad16 = true;  // ... adapter weight gradients as one-part products too (DYT_SPLIT_WGRAD16=0: the exact-fp32 kernel)
     bool split16 = false;       // fp32 mode: frozen-weight GEMMs as three 16-bit MFMA products (DYT_OPT_F32_SPLIT16)
@@ -1079,7 +1080,11 @@ static inline void* at_off(const dyt_ctx* c, void* base, size_t elems) { return 
 #define SPLIT(a, w3) do { if (c->split16) { (a).W3 = (w3); (a).a3 = T.a3; } } while (0)
 // forward GEMM class g (0 qkv, 1 proj, 2 fc1, 3 fc2): products of its contraction (measurement knob DYT_SPLIT_FWD_PARTS="qkv,proj,fc1,fc2")
 // (w3b: the class's second image, used by the pass whose form differs from the student's)
-#define SPLIT_F(a, w3, w3b, g) do { SPLIT(a, (((fm ^ c->f8_mask) >> (g)) & 1) ? (w3b) : (w3)); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; if ((fm >> (g)) & 1) { (a).f8 = true; (a).w_exp = W.w_exp + (g); } } while (0)
+// one_part (bit g; complete_model passes only): the class's GEMM as the hi * hi product alone -- both operand images carry the IEEE-half hi part in
+// front of either form's second part (same row stride), so the image the pass would read anyway serves
+#define SPLIT_F(a, w3, w3b, g) do { SPLIT(a, (((fm ^ c->f8_mask) >> (g)) & 1) ? (w3b) : (w3)); if (c->split16) (a).a3_parts = c->split_fwd_parts[g]; \
+        if (c->split16 && ((one_part >> (g)) & 1)) (a).a3_parts = 1; \
+        else if ((fm >> (g)) & 1) { (a).f8 = true; (a).w_exp = W.w_exp + (g); } } while (0)
 // gradient operands: scaled by 2^12 before the split so that the lo parts stay fp16 normals (the loss scale of the fp16 mode)
 // the producing kernel already wrote the split operand into `buf`
 #define SPLIT_READY(a, buf) do { if (c->split16) { (a).a3 = (buf); (a).a3_ready = true; } } while (0)
@@ -1193,6 +1198,8 @@ static int forward_impl(dyt_ctx* c, int slot, const float* images, int B, int fl
     const bool use_gate = !complete || (flags & DYT_F_GATE_ALWAYS);
     const float drop_p = training ? c->cfg.adapter_dropout : 0.f;
     const uint64_t* seed_dev = (flags & DYT_F_DEVICE_SEED) ? c->seed_dev : nullptr;
+    static const int one_part_env = getenv("DYT_ONE_PART_COMPLETE") ? atoi(getenv("DYT_ONE_PART_COMPLETE")) : -1;   // measurement knob (bit per class: qkv 1, proj 2, fc1 4, fc2 8)
+    const int one_part = (c->split16 && complete) ? (one_part_env >= 0 ? one_part_env : c->one_part_complete) : 0;
     const int fm = c->split16 ? (complete ? c->f8_mask_complete : c->f8_mask) : 0;   // classes (qkv 1, proj 2, fc1 4, fc2 8, embed 16) whose split operands are in the hi16 / fp8 form
     const bool planes = c->bwd16 && c->split16 && c->split_attn;   // q / k / v as 16-bit hi + lo planes (QKV epilogue -> split attention kernel; hi = what a 16-bit backward reads)
     const bool save16 = save && planes;   // "fp16x3h": what the backward reads is saved in the 16-bit operand type
