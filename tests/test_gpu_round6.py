@@ -380,3 +380,90 @@ def test_adapter_layernorm_step_vs_reference_golden(precision, option):
             assert float((model.forward_head(feats) - le).abs().max()) < (2e-5 if precision == "fp32" else 5e-3)
         del model, eng
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("option", ["in", "out"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q"])
+def test_adapter_layernorm_with_stochastic_depth_vs_oracle(precision, option):
+    """The adapter's LayerNorm together with drop_path_rate = 0.3 (reference vision_transformer_IN21K.py:157-163: drop_path2 scales the MLP
+    branch only, the adapter branch -- LayerNorm-ed or not -- joins the residual unscaled): both passes' logits, decisions, losses and the 98
+    gradients of a step with injected per-sample factors against the oracle, masked and compact."""
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    # (the 16-bit backward at the five-seed test's batch: its gate-gradient bound is a B = 16 figure -- at B = 6 with a third of the branch
+    # instances dropped the same absolute noise is 6e-3 of a smaller sum)
+    B, C, r, seed, rate = (6 if precision == "fp32" else 16), 10, 8, 23, 0.3
+    x, y = synth.make_batch(B, C, seed=seed)
+    g1, g2 = synth.make_noise(B, seed=seed + 1)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 2)
+    gen = torch.Generator().manual_seed(seed + 3)
+    dpr = torch.linspace(0, rate, 12)
+    scales = torch.ones(2, 2, 12, B)   # [pass][branch][block][sample]: 0 or 1 / keep_l, block 0 never dropped
+    for l in range(1, 12):
+        kp = 1.0 - float(dpr[l])
+        scales[:, :, l] = (torch.rand(2, 2, B, generator=gen) < kp).float() / kp
+    sd = synth.add_adapter_layernorm(synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3), seed=seed)
+    sd_oracle = dict(sd)
+    sd_oracle[O.ADAPTER_LN_KEY] = torch.tensor({"in": 1, "out": 2}[option])
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option=option, ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+    tol = D.TOL[precision]
+    for mode in ("masked", "compact"):
+        model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=rate, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                           precision=precision, train_mode=mode)
+        model.load_state_dict(sd, strict=True)
+        for n, p in model.named_parameters():
+            p.requires_grad = synth.is_trainable(n)
+        model = model.cuda().train()
+        eng = model.engine(B, torch.device("cuda", 0))
+        eng.set_drop_path_scales(0, scales[0].cuda().contiguous())
+        eng.set_drop_path_scales(1, scales[1].cuda().contiguous())
+        ls, lt = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        ts = torch.zeros(B, 12, 196, device="cuda")
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                  g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+        d_ref, gref, (out_s, out_t, tok) = O.step_grads(sd_oracle, x, y, g1, g2, keep, scale=0.1, mode=mode, drop_scales=scales)
+        es = float((ls.cpu() - out_s.detach()).abs().max())
+        et = float((lt.cpu() - out_t.detach()).abs().max())
+        flips = int((ts.cpu() != tok["token_select"].detach()[..., 0]).sum())
+        el = max(abs(float(losses[i]) - float(d_ref[k])) / max(1.0, abs(float(d_ref[k])))
+                 for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")))
+        worst, wn = 0.0, ""
+        items = [(n, eng.trainable_view(n, gr.shape, eng.grad).cpu(), gr) for n, gr in gref.items()]
+        if precision != "fp32":   # the 12 one-number gate bias gradients as one vector (gpu_diag.report_grads)
+            sc1 = [it for it in items if it[2].numel() == 1]
+            items = [it for it in items if it[2].numel() > 1]
+            items.append(("mlp_token_select.mlp_head.bias (12 blocks)", torch.stack([a.reshape(()) for _, a, _ in sc1]), torch.stack([b.reshape(()) for _, _, b in sc1])))
+        for n, got, gr in items:
+            e = float((got - gr).norm() / max(float(gr.norm()), 1e-20))
+            if e > worst:
+                worst, wn = e, n
+        print("adapter LayerNorm %r + drop_path %s/%s: logits %.2e / %.2e, %d decisions differ, losses %.1e, worst gradient %.1e (%s)" %
+              (option, precision, mode, es, et, flips, el, worst, wn))
+        assert len(gref) == 98
+        assert es <= tol["logits"] and et <= tol["logits"] and flips <= tol["step_flips"] and el <= tol["loss"]
+        assert worst <= (2e-3 if precision == "fp32" else tol["grad"]), (wn, worst)
+        del model, eng
+        torch.cuda.empty_cache()
+
+
+def test_adapter_layernorm_rejected_configurations():
+    """What dyt_config.adapter_ln does not combine with fails loudly at the boundary: the video model (dyt_ctx_create), the learnable adapter
+    scale (dyt_set_option), a value outside 0..2; the LayerNorm's parameters do not exist in a context created without the option."""
+    import _lib
+    from runtime import DyTEngine
+    from _lib import DyTError
+    dev = torch.device("cuda", 0)
+    with pytest.raises(DyTError, match="adapter_ln"):
+        DyTEngine(10, 8, 0.1, dev, max_batch=8, frames=4, adapter_ln=1)
+    with pytest.raises(DyTError, match="adapter_ln"):
+        DyTEngine(10, 8, 0.1, dev, max_batch=4, adapter_ln=3)
+    e = DyTEngine(10, 8, 0.1, dev, max_batch=4, adapter_ln=2)
+    with pytest.raises(DyTError, match="LayerNorm"):
+        e.set_option(_lib.OPT_LEARNABLE_SCALE, 1)
+    e0 = DyTEngine(10, 8, 0.1, dev, max_batch=4)
+    with pytest.raises(DyTError, match="adapter_ln"):
+        e0.trainable_slice("blocks.0.adaptmlp.adapter_layer_norm_before.weight")
