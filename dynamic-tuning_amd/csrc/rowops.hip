@@ -996,6 +996,16 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
     if (a.gate_w) { wg.load(a.gate_w, lane); TK_ROWPIN(wg); }
     if (a.dA2) { ln2w.load(a.ln2_w, lane); TK_ROWPIN(ln2w); }
     const int t0 = blockIdx.x * TOK_PER_BLOCK;
+    // compact rows of this wave's tokens, one per lane, loaded up front: the dA2 row of a token then goes out WITH its other rows instead of
+    // behind the drain that delivers its index (round 6: one memory latency per token instead of two)
+    int rv = -1;
+    if (a.dA2 && a.write_du) {
+        const int tt = t0 + wave + 4 * lane;
+        if (lane < TOK_PER_BLOCK / 4 && tt < a.M) {
+            if (a.g_cls) { const int bb = tt / NT; rv = (tt - bb * NT == 0) ? bb : -1; }
+            else rv = a.dst_of ? a.dst_of[tt] : tt;
+        }
+    }
     for (int k = wave; k < TOK_PER_BLOCK; k += 4) {
         const int t = t0 + k;
         if (t >= a.M) break;
@@ -1016,8 +1026,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
             for (int i = 0; i < 12; ++i) du.v[i] = 0.f;
         }
         if (a.dad) e.load_at(reinterpret_cast<const AT*>(a.dad) + (size_t)t * D, lane);
-        int r = -1;
-        if (a.dA2 && a.write_du) r = a.g_cls ? (n == 0 ? b : -1) : (a.dst_of ? a.dst_of[t] : t);
+        const int r = __builtin_amdgcn_readlane(rv, k >> 2);   // (k >> 2 is wave-uniform: k = wave + 4 j)
+        if (r >= 0) dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
         float2 st2 = make_float2(0.f, 1.f);
         if (a.dA2 && a.write_du) st2 = a.stats2[t];
         float ext = 0.f, sf = 0.f, dmk = 0.f, dlg = 0.f;
@@ -1037,7 +1047,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         if (need_u) TK_ROWPIN(ur);
         TK_ROWPIN(du);
         if (a.dad) TK_ROWPIN(e);
-        TK_SCALPIN4(r, st2.x, st2.y, ext);
+        if (r >= 0) TK_ROWPIN(dy);
+        TK_SCALPIN3(st2.x, st2.y, ext);
         TK_SCALPIN3(sf, dmk, dlg);
         if (cat) {
             DYT_PIN2(cd, cz);
@@ -1055,8 +1066,6 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwdArgs a) {
         }
         if (a.dA2 && a.write_du) {
             if (r >= 0) {
-                dy.load_at(reinterpret_cast<const AT*>(a.dA2) + (size_t)r * D, lane);
-                TK_ROWPIN(dy);
                 ln_bwd_row(dy, ur, ln2w, st2);
                 const float ds = a.inv_gs * bs;
 #pragma unroll
