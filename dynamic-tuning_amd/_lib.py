@@ -107,6 +107,7 @@ SYMBOLS = {
     "dyt_set_global_option": (_i, [_i, _i]),
     "dyt_set_drop_path": (_i, [_vp, _f]),
     "dyt_set_drop_path_scales": (_i, [_vp, _i, _vp]),
+    "dyt_set_soft_targets": (_i, [_vp, _vp, _i]),
     "dyt_set_frozen": (_i, [_vp, _i, _i, _vp, _vp]),
     "dyt_trainable_numel": (_i, [_vp, ctypes.POINTER(_i64)]),
     "dyt_trainable_offset": (_i, [_vp, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),

@@ -223,6 +223,9 @@ struct LossArgs {
     float target_ratio, loss_ratio, token_minimal, token_minimal_weight;
     float* dlogits_s; float* dlogits_t; float* out_losses; float* dtok;
     float* scratch = nullptr;   // [4*B] per-image partial terms
+    // class-probability targets [B, C] (timm Mixup's output through the reference's engine_finetune.py:44-45 into nn.CrossEntropyLoss): CE = -sum_c t_c log p_c
+    // for both passes, d logits = p sum(t) - t; null = the integer labels in `targets`
+    const float* soft = nullptr;
 };
 int launch_loss(const LossArgs& a, hipStream_t s);
 

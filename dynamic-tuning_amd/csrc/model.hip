@@ -243,6 +243,7 @@ struct dyt_ctx {
     float split_gs = 4096.0f;   // ... their gradient operands are multiplied by this power of two before the split (DYT_SPLIT_GS_LOG2)
     int split_bwd_parts = 3;    // ... products of the GRADIENT GEMMs' contraction (DYT_SPLIT_BWD_PARTS: 3 full, 2 = dY_hi * (W_hi + W_lo), 1 = dY_hi * W_hi)
     int split_bwd_attn_parts = 3;   // ... and of the split attention backward's dP / dQ / dK / dV products (3 or 1; the score recomputation keeps three)
+    const float* soft_targets = nullptr; int soft_batch = 0;   // dyt_set_soft_targets: class-probability targets of the next loss evaluations
     int one_part_complete = 0;  // ... classes of a complete_model (teacher) pass contracted as hi * hi alone (SPLIT_F)
     int split_fwd_parts[4] = {3, 3, 3, 3};   // ... products of the FORWARD GEMMs per class (qkv, proj, fc1, fc2): measurement knob
     bool split_wgrad16 = true;  // ... adapter weight gradients as one-part products too (DYT_SPLIT_WGRAD16=0: the exact-fp32 kernel)
@@ -973,6 +974,13 @@ extern "C" int dyt_set_drop_path_scales(dyt_ctx* c, int slot, const float* scale
     if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
     if (slot < 0 || slot >= c->cfg.slots) { set_error("slot %d out of range", slot); return DYT_ERR_ARG; }
     c->slots[slot].dp_inject = scales;
+    return DYT_OK;
+}
+
+extern "C" int dyt_set_soft_targets(dyt_ctx* c, const float* targets, int rows) {
+    if (!c) { set_error("null ctx"); return DYT_ERR_ARG; }
+    if (targets && rows < 1) { set_error("soft targets: rows = %d", rows); return DYT_ERR_ARG; }
+    c->soft_targets = targets; c->soft_batch = targets ? rows : 0;
     return DYT_OK;
 }
 
@@ -1868,6 +1876,10 @@ extern "C" int dyt_loss(dyt_ctx* c, int slot_student, const float* logits_s, con
     a.dlogits_s = dlogits_s; a.dlogits_t = dlogits_t; a.out_losses = out_losses; a.dtok = dtok;
     a.scratch = c->loss_part;
     if (batch * c->frames > c->cfg.max_batch) { set_error("batch %d exceeds max_batch", batch); return DYT_ERR_ARG; }
+    if (c->soft_targets) {
+        if (c->soft_batch != batch) { set_error("soft targets were set for %d rows, this loss has %d", c->soft_batch, batch); return DYT_ERR_STATE; }
+        a.soft = c->soft_targets;
+    }
     return launch_loss(a, s);
 }
 

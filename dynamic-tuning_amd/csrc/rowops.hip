@@ -745,6 +745,24 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, float* __res
     float ss = 0.f, st = 0.f;
     for (int c = lane; c < C; c += 64) { ss += expf(ls[c] - ms); st += expf(lt[c] - mt); }
     const float lse_s = ms + logf(wave_sum(ss)), lse_t = mt + logf(wave_sum(st));
+    if (a.soft) {   // class-probability targets (LossArgs::soft): same form with the one-hot row replaced by t
+        const float* tg = a.soft + (size_t)b * C;
+        float tsum = 0.f;
+        for (int c = lane; c < C; c += 64) tsum += tg[c];
+        tsum = wave_sum(tsum);
+        float klb = 0.f, ces = 0.f, cet = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float lps = ls[c] - lse_s, lpt = lt[c] - lse_t;
+            const float ps = expf(lps), pt = expf(lpt), t = tg[c];
+            klb += pt * (lpt - lps);
+            ces -= t * lps; cet -= t * lpt;
+            a.dlogits_s[(size_t)b * C + c] = ((ps * tsum - t) + (ps - pt)) * invB;
+            a.dlogits_t[(size_t)b * C + c] = (pt * tsum - t) * invB;
+        }
+        klb = wave_sum(klb); ces = wave_sum(ces); cet = wave_sum(cet);
+        if (lane == 0) { part[b * 4 + 0] = ces; part[b * 4 + 1] = cet; part[b * 4 + 2] = klb; }
+        return;
+    }
     const int y = (int)a.targets[b];
     float klb = 0.f;
     for (int c = lane; c < C; c += 64) {

@@ -388,10 +388,19 @@ def train_step(model, samples, targets, optimizer, criterion=None, losses_out=No
                accum_iter=1, max_norm=0.0, graph=False):
     """One fused step (reference engine_finetune.py:47-79) on device tensors; returns the device
     tensor of loss components [loss, base, token, teacher, distillation, keep ratio, kept, 0].
-    graph=True replays the forward+backward from a captured hipGraph (on-device noise only)."""
+    graph=True replays the forward+backward from a captured hipGraph (on-device noise only).
+    ``targets``: integer labels [b], or class probabilities [b, num_classes] (a ``mixup_fn``'s output, reference :44-45) -- both
+    CrossEntropyLoss terms then take the soft form (C ABI dyt_set_soft_targets)."""
     m = getattr(model, "module", model)
     samples = m.fold_input(samples.float()).contiguous()   # video: [b,c,t,h,w] -> [(b t),c,h,w]
     eng = m.engine(samples.shape[0], samples.device)
+    if targets.dim() == 2 and targets.is_floating_point():
+        soft = targets.float().contiguous()
+        eng.set_soft_targets(soft)
+        targets = soft.argmax(dim=1)   # (ignored by the loss while soft targets are set)
+        graph = False                  # a captured step would carry this batch's pointer
+    else:
+        eng.set_soft_targets(None)
     optimizer.sync_parameters(eng)
     tr = criterion.token_target_ratio if target_ratio is None else target_ratio
     ratio = criterion.token_loss_ratio if criterion is not None else 2.0
@@ -545,8 +554,6 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     optimizer = as_fused(optimizer, model)
     if loss_scaler is not None and hasattr(loss_scaler, "bind"):
         loss_scaler.bind(optimizer)
-    if mixup_fn is not None:
-        raise NotImplementedError("mixup is not used by train_IN21K.sh / train_vtab.sh / train_video.sh")
     accum_iter = max(1, int(getattr(args, "accum_iter", 1) or 1)) if args is not None else 1
     use_graph = bool(getattr(args, "hip_graph", False)) if args is not None else False
     model.train(True)
@@ -567,6 +574,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         keep_mask = extra[1].to(device).contiguous() if len(extra) > 1 and extra[1] is not None else None
         if it % accum_iter == 0:   # per-iteration schedule, reference :43-46
             lr = lr_sched.adjust_learning_rate(optimizer, it / nsteps + epoch, args)
+        if mixup_fn is not None:   # reference :44-45 (timm.data.Mixup or any callable of that shape): mixed samples, class-probability targets
+            samples, targets = mixup_fn(samples, targets)
         train_step(model, samples, targets, optimizer, criterion, losses_out=step_losses, seed=step_seed(epoch, it),
                    gumbel=gumbel, keep_mask=keep_mask, accumulate=(it % accum_iter != 0), update=((it + 1) % accum_iter == 0),
                    accum_iter=accum_iter, max_norm=max_norm or 0.0, graph=use_graph)
@@ -593,6 +602,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             pending = 0
     stats = {k: v / max(count, 1) for k, v in sums.items()}
     stats["lr"] = lr
+    if mixup_fn is not None and getattr(m, "_engine", None) is not None:
+        m._engine.set_soft_targets(None)   # evaluation / the next caller's steps use their integer labels
     optimizer.publish_torch_state()   # an adopted torch.optim.AdamW now reports this epoch's moments / step count (misc.save_model)
     if is_dist_avail_and_initialized():  # metric_logger.synchronize_between_processes(), reference :104
         t = torch.tensor([stats[k] for k in LOSS_KEYS], device=device, dtype=torch.float64)

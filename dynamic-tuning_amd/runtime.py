@@ -487,6 +487,18 @@ class DyTEngine:
         self._graphs = {}   # a captured step carries the old pointer in its kernel arguments
         self._ck(self.L.dyt_set_drop_path_scales(self.h, int(slot), ptr(scales)))
 
+    def set_soft_targets(self, targets):
+        """Class-probability targets [rows, num_classes] (what a ``mixup_fn`` returns, reference engine_finetune.py:44-45) for the loss evaluations
+        that follow, instead of their integer labels; None restores the labels.  The tensor is kept alive here; a captured step carries its pointer."""
+        if targets is not None:
+            if not (targets.is_cuda and targets.dtype == torch.float32 and targets.is_contiguous() and targets.dim() == 2 and targets.shape[1] == self.num_classes):
+                raise DyTError("soft targets: a contiguous fp32 [rows, %d] tensor on the HIP device" % self.num_classes)
+        if targets is None and getattr(self, "_soft_keep", None) is None:
+            return
+        self._soft_keep = targets
+        self._graphs = {}
+        self._ck(self.L.dyt_set_soft_targets(self.h, ptr(targets), 0 if targets is None else int(targets.shape[0])))
+
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on):
         self._ck(self.L.dyt_profile_enable(self.h, 1 if on else 0))

@@ -159,6 +159,17 @@ def make_batch(batch, num_classes=100, seed=0):
     return x, torch.from_numpy(y.astype(np.int64))
 
 
+def mixup_batch(x, y, num_classes, lam=0.7, smoothing=0.1):
+    """What timm.data.Mixup(mixup_alpha > 0, label_smoothing) hands the training loop (reference engine_finetune.py:44-45), with a fixed mixing
+    weight instead of a Beta draw: samples lam x + (1 - lam) x.flip(0), class-probability targets lam t(y) + (1 - lam) t(y.flip(0)) with
+    t(y) = one_hot (1 - smoothing) + smoothing / C.  Deterministic, so the golden recipe and the tests apply the same function."""
+    import torch
+    xm = lam * x + (1.0 - lam) * x.flip(0)
+    off = smoothing / num_classes
+    t = torch.full((y.shape[0], num_classes), off, dtype=torch.float32, device=y.device).scatter_(1, y.view(-1, 1), 1.0 - smoothing + off)
+    return xm, lam * t + (1.0 - lam) * t.flip(0)
+
+
 def make_noise(batch, depth=DEPTH, seed=2, passes=2):
     """Gumbel draws ``g1, g2 = -log(Exp(1))`` shaped [passes, depth, B, 196] each
     (what ``dynamic_adapter.py:30-39`` draws per block and per pass)."""

@@ -305,6 +305,12 @@ int dyt_loss(dyt_ctx* ctx, int slot_student, const float* logits_s, const float*
              float token_minimal, float token_minimal_weight,
              float* dlogits_s, float* dlogits_t, float* out_losses, float* dtok, void* stream);
 
+/* Mixup / soft labels (reference engine_finetune.py:44-45,60-62: `samples, targets = mixup_fn(samples, targets)` hands class-probability
+ * targets [rows, num_classes] to nn.CrossEntropyLoss for the student and the teacher pass alike): the loss evaluations that follow -- dyt_loss,
+ * dyt_step_fwd_bwd -- read `targets` (device fp32; the pointer is kept, not copied; rows = the logits' rows) instead of their integer labels,
+ * which are then ignored: CE = -sum_c t_c log p_c, d logits = p sum_c t_c - t.  NULL restores the integer labels. */
+int dyt_set_soft_targets(dyt_ctx* ctx, const float* targets, int rows);
+
 /* torch.optim.AdamW over the flat trainable buffer -- main_image.py:285; the gradient is first
  * multiplied by grad_scale (1/world_size after a SUM all-reduce).  `step` is 1-based. */
 int dyt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,

@@ -28,7 +28,7 @@ def test_golden_recipe_imports_the_reference(recipe):
 
 def test_every_fixture_has_a_recipe():
     made = {"step_r64.npz", "step_r8.npz", "eval_r64.npz", "eval_acc.npz", "count_flops.npz", "video_step.npz", "drop_path_step.npz", "learnable_scalar_step.npz",
-            "adapter_ln_in_step.npz", "adapter_ln_out_step.npz"}
+            "adapter_ln_in_step.npz", "adapter_ln_out_step.npz", "mixup_step.npz"}
     have = {os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "*.npz"))}
     assert have == made, (have, made)
     assert len(RECIPES) >= 4, RECIPES

@@ -467,3 +467,143 @@ def test_adapter_layernorm_rejected_configurations():
     e0 = DyTEngine(10, 8, 0.1, dev, max_batch=4)
     with pytest.raises(DyTError, match="adapter_ln"):
         e0.trainable_slice("blocks.0.adaptmlp.adapter_layer_norm_before.weight")
+
+
+# ---- mixup_fn / class-probability targets (reference engine_finetune.py:44-45; C ABI dyt_set_soft_targets) ----
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16", "bf16"])
+def test_mixup_step_vs_reference_golden(precision):
+    """The reference's train_one_epoch WITH a mixup_fn (tests/golden/mixup_step.npz: the real model, AdaLoss and loop; synth.mixup_batch as the
+    callable): logits, masks, the five loss components and the 74 gradients of the fused step fed the same mixed samples and class-probability
+    targets, masked mode against the reference's values and compact mode against the oracle's; fp32 also the head after one AdamW update.  Then
+    the same through OUR train_one_epoch(mixup_fn=...) -- the loop calls the callable on the device tensors and hands the targets to the
+    library -- and back to integer labels afterwards."""
+    import numpy as np
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mixup_step.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    lam, sm = float(g["meta_lam"]), float(g["meta_smoothing"])
+    x, y = synth.make_batch(B, C, seed=seed)
+    xm, t = synth.mixup_batch(x, y, C, lam=lam, smoothing=sm)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    sd = synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3)
+    tol = D.TOL[precision]
+    for mode in ("masked", "compact"):
+        from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+        tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                       ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+        model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                           precision=precision, train_mode=mode)
+        model.load_state_dict(sd, strict=True)
+        for n, p in model.named_parameters():
+            p.requires_grad = synth.is_trainable(n)
+        model = model.cuda()
+        model.train()
+        eng = model.engine(B, torch.device("cuda", 0))
+        td = t.cuda().contiguous()
+        eng.set_soft_targets(td)
+        ls, lt = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        ts = torch.zeros(B, 12, 196, device="cuda")
+        wrong_labels = torch.zeros(B, dtype=torch.int64, device="cuda")   # ignored while soft targets are set
+        losses = eng.step_fwd_bwd(xm.cuda(), wrong_labels, 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                  g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+        es = float(np.abs(ls.cpu().numpy() - g["logits_student"]).max())
+        et = float(np.abs(lt.cpu().numpy() - g["logits_teacher"]).max())
+        flips = int((ts.cpu().numpy().astype(np.uint8) != g["token_select"][..., 0]).sum())
+        el = max(abs(float(losses[i]) - float(g["stat_" + k])) / max(1.0, abs(float(g["stat_" + k])))
+                 for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")))
+        if mode == "masked":
+            gref = {n[len("grad/"):]: torch.from_numpy(v) for n, v in g.items() if n.startswith("grad/")}
+        else:
+            _, gref, _ = O.step_grads(sd, xm, t, g1, g2, keep, scale=0.1, mode="compact")
+        items = [(n, eng.trainable_view(n, gr.shape, eng.grad).cpu(), gr) for n, gr in gref.items()]
+        if precision != "fp32":
+            sc1 = [it for it in items if it[2].numel() == 1]
+            items = [it for it in items if it[2].numel() > 1]
+            if sc1:
+                items.append(("mlp_token_select.mlp_head.bias (12 blocks)", torch.stack([a.reshape(()) for _, a, _ in sc1]), torch.stack([b.reshape(()) for _, _, b in sc1])))
+        worst = {}
+        for n, got, ref in items:
+            e = float((got - ref).norm() / max(float(ref.norm()), 1e-20))
+            k = D.grad_kind(n) if precision in ("fp16", "bf16") else "all"
+            if e > worst.get(k, (0.0, ""))[0]:
+                worst[k] = (e, n)
+        print("mixup %s/%s: logits %.2e / %.2e, %d decisions differ, losses %.1e, gradients %s" %
+              (precision, mode, es, et, flips, el, {k: "%.1e" % v[0] for k, v in worst.items()}))
+        assert es <= tol["logits"] and et <= tol["logits"] and flips <= tol["step_flips"] and el <= tol["loss"]
+        for k, (e, n) in worst.items():
+            bound = 2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else
+                                                     (D.FP16_GRAD_TOL_SMALL_B if precision == "fp16" else D.BF16_GRAD_TOL_SMALL_B)[k])
+            assert e <= bound, (mode, k, n, e, bound)
+        if precision == "fp32" and mode == "masked":
+            D.D_adamw(eng, float(g["meta_lr"]), float(g["meta_wd"]))
+            for key in g:
+                if key.startswith("param_after/"):
+                    n = key.split("/", 1)[1]
+                    assert np.abs(eng.trainable_view(n, g[key].shape).cpu().numpy() - g[key]).max() < 2e-5, n
+        # a wrong row count fails loudly; NULL restores the integer labels
+        eng.set_soft_targets(torch.full((B + 1, C), 1.0 / C, device="cuda"))
+        with pytest.raises(Exception, match="soft targets"):
+            eng.step_fwd_bwd(xm.cuda(), wrong_labels, 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"))
+        eng.set_soft_targets(None)
+        hard = eng.step_fwd_bwd(xm.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous()).cpu()
+        assert abs(float(hard[1]) - float(losses[1])) > 1e-3   # base_loss against the integer labels is another number
+        del model, eng
+        torch.cuda.empty_cache()
+
+
+def test_train_one_epoch_with_mixup_fn_vs_reference_golden():
+    """OUR train_one_epoch driven like the reference's (same positional call as tests/golden/make_golden_mixup.py) with a mixup_fn: the epoch
+    statistics equal the reference's, evaluation afterwards runs on integer labels again."""
+    import logging
+    import types
+    import numpy as np
+    import synth
+    import engine_finetune as E
+    import misc
+    from models.losses import AdaLoss
+    import gpu_diag as D
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mixup_step.npz")))
+    B, C, r, seed = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"]), int(g["meta_seed"])
+    lam, sm = float(g["meta_lam"]), float(g["meta_smoothing"])
+    sd = synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3)
+    tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="none", ffn_adapter_init_option="lora",
+                   ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+    model = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                       precision="fp32", train_mode="masked")
+    model.load_state_dict(sd, strict=True)
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    model = model.cuda()
+    lr, wd = float(g["meta_lr"]), float(g["meta_wd"])
+    optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=wd)
+    criterion = AdaLoss(base_criterion=torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0)
+    scaler = misc.NativeScalerWithGradNormCount()
+    args = types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=0.0, warmup_epochs=0, epochs=10, metric="accuracy", nb_classes=C)
+    x, y = synth.make_batch(B, C, seed=seed)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 3)
+    g1, g2 = torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"])
+    calls = []
+
+    def mixup_fn(samples, targets):
+        assert samples.is_cuda and targets.is_cuda   # the loop calls it on the device tensors, like the reference's
+        calls.append(1)
+        return synth.mixup_batch(samples, targets, C, lam=lam, smoothing=sm)
+
+    stats = E.train_one_epoch(model, criterion, [(x, y, (g1, g2), keep)], optimizer, torch.device("cuda", 0), 0, scaler, None, mixup_fn, None,
+                              args=args, logger=logging.getLogger("t"))
+    assert len(calls) == 1
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(stats[k] - float(g["stat_" + k])) < 1e-4 * max(1.0, abs(float(g["stat_" + k]))), (k, stats[k], float(g["stat_" + k]))
+    head = dict(model.named_parameters())
+    for key in g:
+        if key.startswith("param_after/"):
+            n = key.split("/", 1)[1]
+            assert np.abs(head[n].detach().cpu().numpy() - g[key]).max() < 2e-5, n
+    # the next epoch without a mixup_fn: integer labels again (no stale soft-target pointer)
+    stats2 = E.train_one_epoch(model, criterion, [(x, y)], optimizer, torch.device("cuda", 0), 1, scaler, None, None, None, args=args, logger=logging.getLogger("t"))
+    assert np.isfinite(stats2["loss"]) and model._engine._soft_keep is None

@@ -328,3 +328,26 @@ def test_adapter_layernorm_step_vs_reference(golden_dir, option):
         assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-8, n
         if "grad/" + n in g:
             assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-8, n
+
+
+def test_mixup_step_vs_reference(golden_dir):
+    """A ``mixup_fn`` in the reference's train_one_epoch (engine_finetune.py:44-45): class-probability targets through nn.CrossEntropyLoss for
+    both passes (tests/golden/make_golden_mixup.py; the callable is synth.mixup_batch) against the oracle with the same targets."""
+    g = load(golden_dir, "mixup_step.npz")
+    B, C, r = int(g["meta_batch"]), int(g["meta_num_classes"]), int(g["meta_ffn_num"])
+    sd = state(g)
+    x, y = synth.make_batch(B, C, seed=int(g["meta_seed"]))
+    xm, t = synth.mixup_batch(x, y, C, lam=float(g["meta_lam"]), smoothing=float(g["meta_smoothing"]))
+    assert np.array_equal(t.numpy(), g["soft_targets"]) and abs(float(t.sum()) - B) < 1e-5
+    keep = synth.make_dropout_masks(B, r, seed=int(g["meta_seed"]) + 3)
+    d, grads, outs = O.step_grads(sd, xm, t, torch.from_numpy(g["g1"]), torch.from_numpy(g["g2"]), keep, scale=0.1, mode="masked")
+    assert np.abs(outs[0].detach().numpy() - g["logits_student"]).max() < 2e-5
+    assert np.abs(outs[1].detach().numpy() - g["logits_teacher"]).max() < 2e-5
+    assert np.array_equal(outs[2]["token_select"].detach().numpy().astype(np.uint8), g["token_select"])
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(float(d[k]) - float(g["stat_" + k])) < 1e-5 * max(1.0, abs(float(g["stat_" + k]))), k
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-8, n
+        if "grad/" + n in g:
+            assert np.abs(gr.numpy() - g["grad/" + n]).max() <= 1e-4 * np.abs(g["grad/" + n]).max() + 1e-8, n
