@@ -372,6 +372,10 @@ def host_fed(args, model, opt, steps, warmup, device, world, resident_ms):
     lr = opt.param_groups[0]["lr"]
     la = types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=lr, warmup_epochs=0, epochs=10 ** 6, hip_graph=bool(args.hip_graph))
     out = {}
+    # one timed EPOCH: its fixed costs (first batch copied ahead of the first step, optimizer state published for the checkpoint, the closing
+    # sync) belong to the loop, but over 20 steps they weigh 20x what they do in the shortest epoch of the reference's scripts (CIFAR-100 at
+    # B = 128 per GPU: 390 steps) -- the epoch here is 4 x the headline's step count, at least 80
+    steps = max(4 * steps, 80)
     resident = [(x.to(device), y.to(device)) for x, y in batches[:2]]
     for name, env in (("prefetched", "1"), ("copy_on_compute_stream", "0"), ("loop_on_resident_batches", "1")):
         os.environ["DYT_PREFETCH"] = env
@@ -397,7 +401,7 @@ def host_fed(args, model, opt, steps, warmup, device, world, resident_ms):
             "loop_on_resident_batches_ms_per_step": round(out["loop_on_resident_batches"], 3),
             "copy_stream_probe": getattr(model._engine, "_copy_stream_probe", (None, None))[1],
             "loop": "engine_finetune.train_one_epoch (reference engine_finetune.py:16-106): lr schedule per iteration, H2D of every batch on a copy "
-                    "stream into the other of two device buffers (event hand-over), fused step, one host sync per 20 steps; "
+                    "stream into the other of two device buffers (event hand-over), fused step, one host sync per 20 steps; one timed epoch of `steps` steps; "
                     "`copy_on_compute_stream` = the reference's placement of the copy (DYT_PREFETCH=0)"}
 
 
