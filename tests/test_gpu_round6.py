@@ -607,3 +607,58 @@ def test_train_one_epoch_with_mixup_fn_vs_reference_golden():
     # the next epoch without a mixup_fn: integer labels again (no stale soft-target pointer)
     stats2 = E.train_one_epoch(model, criterion, [(x, y)], optimizer, torch.device("cuda", 0), 1, scaler, None, None, None, args=args, logger=logging.getLogger("t"))
     assert np.isfinite(stats2["loss"]) and model._engine._soft_keep is None
+
+
+@pytest.mark.parametrize("gate_bias", [-60.0, 60.0])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3q", "fp16"])
+def test_extreme_keep_ratios_vs_oracle(precision, gate_bias):
+    """The dispatcher's corner cases: a gate bias of -60 drops EVERY patch token of every block (the compacted MLP runs on the B cls rows alone: one
+    partial tile per GEMM, every other row takes the dropped-token path), +60 keeps every token (compaction is the identity).  Training step
+    (masked and compact) and inference against the oracle; decisions must be all-0 / all-1."""
+    import gpu_diag as D
+    import synth
+    from oracle import dyt_oracle as O
+    from test_gpu_round2 import _bench_model
+    B, C, r, seed = 3, 10, 8, 37
+    x, y = synth.make_batch(B, C, seed=seed)
+    g1, g2 = synth.make_noise(B, seed=seed + 1)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 2)
+    tol = D.TOL[precision]
+    for mode in ("masked", "compact"):
+        m, sd = _bench_model(precision, mode, B, gate_bias, classes=C, r=r, kind="test", seed=seed)
+        m.train()
+        eng = m.engine(B, torch.device("cuda", 0))
+        ls, lt = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        ts = torch.full((B, 12, 196), 0.5, device="cuda")
+        losses = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, masked_dense=(mode == "masked"), g1=g1.cuda().contiguous(),
+                                  g2=g2.cuda().contiguous(), keep_mask=keep.cuda().contiguous(), logits_s=ls, logits_t=lt, token_select=ts).cpu()
+        want = 1.0 if gate_bias > 0 else 0.0
+        assert bool((ts == want).all()), "decisions"
+        assert abs(float(losses[5]) - want) < 1e-6   # mean keep ratio
+        d_ref, gref, (out_s, out_t, tok) = O.step_grads(sd, x, y, g1, g2, keep, scale=0.1, mode=mode)
+        assert bool((tok["token_select"] == want).all())
+        es, et = float((ls.cpu() - out_s.detach()).abs().max()), float((lt.cpu() - out_t.detach()).abs().max())
+        el = max(abs(float(losses[i]) - float(d_ref[k])) / max(1.0, abs(float(d_ref[k])))
+                 for i, k in enumerate(("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss")))
+        worst, wn = 0.0, ""
+        for n, gr in gref.items():
+            if float(gr.norm()) < 1e-12:   # (saturated gates: d sigmoid = 0 -- both sides must then be zero)
+                assert float(eng.trainable_view(n, gr.shape, eng.grad).abs().max()) < 1e-10, n
+                continue
+            got = eng.trainable_view(n, gr.shape, eng.grad).cpu()
+            e = float((got - gr).norm() / float(gr.norm()))
+            if "mlp_token_select" in n and float(gr.norm()) < 1e-6:
+                continue   # gate gradients through a saturated sigmoid (e^-60 scale): relative error of numbers at the fp32 underflow edge is not parity
+            if e > worst:
+                worst, wn = e, n
+        bound = 2e-3 if precision == "fp32" else (tol["grad"] if precision in D.SPLIT_MODES else 0.25)
+        print("gate bias %+.0f %s/%s: logits %.2e / %.2e, losses %.1e, worst gradient %.1e (%s)" % (gate_bias, precision, mode, es, et, el, worst, wn))
+        assert es <= tol["logits"] and et <= tol["logits"] and el <= tol["loss"]
+        assert worst <= bound, (wn, worst)
+        m.eval()
+        with torch.no_grad():
+            le, aux = m(x.cuda())
+        oe, oaux = O.forward(sd, x, training=False, mode="compact")
+        assert bool((aux["token_select"].cpu() == want).all()) and float((le.cpu() - oe).abs().max()) <= tol["logits"]
+        del m, eng
+        torch.cuda.empty_cache()
