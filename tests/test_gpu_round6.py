@@ -662,3 +662,47 @@ def test_extreme_keep_ratios_vs_oracle(precision, gate_bias):
         assert bool((aux["token_select"].cpu() == want).all()) and float((le.cpu() - oe).abs().max()) <= tol["logits"]
         del m, eng
         torch.cuda.empty_cache()
+
+
+from test_gpu_round2 import rccl_one_rank  # noqa: E402,F401  (fixture)
+
+
+def test_adapter_layernorm_rccl_one_rank_path_equals_no_dist(rccl_one_rank):  # noqa: F811
+    """The 98-tensor flat layout (adapter LayerNorm "in") through the multi-rank machinery with one rank -- parameter broadcast, the early
+    all-reduce of the upper blocks' gradients on the communication stream, the lower part after the backward, AdamW -- reproduces the
+    single-process training bit for bit: the split point of the two all-reduce parts moves with the layout."""
+    import gpu_diag as D
+    import synth
+    from engine_finetune import FusedAdamW, train_step
+    from models.vision_transformer_IN21K import vit_base_patch16_224_in21k
+    B, C, r, seed = 4, 10, 8, 41
+
+    def three_steps():
+        sd = synth.add_adapter_layernorm(synth.make_state_dict(C, r, seed=seed, kind="test", gate_bias=0.3), seed=seed)
+        tuning = D.Cfg(ffn_adapt=True, ffn_option="parallel", ffn_adapter_layernorm_option="in", ffn_adapter_init_option="lora",
+                       ffn_adapter_scalar="0.1", ffn_num=r, d_model=768)
+        m = vit_base_patch16_224_in21k(num_classes=C, drop_path_rate=0.0, tuning_config=tuning, select_config=D.Cfg(open=True, keep_layers=0),
+                                       precision="fp16", train_mode="compact", max_batch=B)
+        m.load_state_dict(sd, strict=True)
+        for n, p in m.named_parameters():
+            p.requires_grad = synth.is_trainable(n)
+        m = m.cuda().train()
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+        x, y = synth.make_batch(B, C, seed=seed + 1)
+        x, y = x.cuda(), y.cuda()
+        losses = []
+        for i in range(3):
+            losses.append(train_step(m, x, y, opt, seed=700 + i, target_ratio=0.5, token_minimal=0.0, token_minimal_weight=0.0).clone())
+        torch.cuda.synchronize()
+        assert m._engine.adapter_ln == 1
+        return m._engine.flat.clone(), torch.stack(losses), m._engine.grad.clone()
+
+    with_dist = three_steps()
+    rccl_one_rank.destroy_process_group()
+    try:
+        without = three_steps()
+    finally:
+        rccl_one_rank.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    for a, b in zip(with_dist, without):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    assert float(with_dist[1][:, 0].min()) > 0 and bool(torch.isfinite(with_dist[0]).all())
