@@ -1182,7 +1182,8 @@ int get_gemm_splitk() {
 }
 static int g_big_tile_min_n = 2304;
 static int g_use_bpre = 1;        // wide-N GEMMs with a pre-shuffled frozen weight: 128x256 tiles, 2 workgroups / CU (gemm_bpre.h)
-static int g_split_rows = 1;      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
+static int g_split_rows = getenv("DYT_SPLIT_ROWS") ? atoi(getenv("DYT_SPLIT_ROWS")) : 1;   // (0: 128x128 tiles for every row -- measurement knob)
+//      // narrow-N GEMMs: 256x256 tiles for whole rounds of rows + 128x128 tiles for the rest  // N >= this (and % 256 == 0): 256x256 tiles with the half-stage pipeline
 
 // the "fp16f8" split contraction (a.K = 2 x the logical K: K / 64 f16 tiles + K / 64 fp8 tiles): tile shapes as for the three-part form
 template <class Epi, int LEAD = 0>
