@@ -394,8 +394,14 @@ def train_step(model, samples, targets, optimizer, criterion=None, losses_out=No
     m = getattr(model, "module", model)
     samples = m.fold_input(samples.float()).contiguous()   # video: [b,c,t,h,w] -> [(b t),c,h,w]
     eng = m.engine(samples.shape[0], samples.device)
+    # nn.CrossEntropyLoss(label_smoothing = e) is the soft form with t (1 - e) + e / C (torch applies the same map to class-probability targets)
+    smooth = float(getattr(getattr(criterion, "base_criterion", None), "label_smoothing", 0.0) or 0.0)
+    if smooth > 0.0 and not (targets.dim() == 2 and targets.is_floating_point()):
+        targets = torch.nn.functional.one_hot(targets.long(), eng.num_classes).float()
     if targets.dim() == 2 and targets.is_floating_point():
         soft = targets.float().contiguous()
+        if smooth > 0.0:
+            soft = soft * (1.0 - smooth) + smooth / soft.shape[1]
         eng.set_soft_targets(soft)
         targets = soft.argmax(dim=1)   # (ignored by the loss while soft targets are set)
         graph = False                  # a captured step would carry this batch's pointer
@@ -427,9 +433,10 @@ def _check_supported(model, criterion):
     """The fused step hard-wires what every reference entry point uses; anything else must fail loudly."""
     from _lib import is_trainable_param, key_to_param
     base = getattr(criterion, "base_criterion", None)
-    if base is not None and not (isinstance(base, torch.nn.CrossEntropyLoss) and getattr(base, "label_smoothing", 0.0) == 0.0
-                                 and base.weight is None):
-        raise NotImplementedError("the fused step computes plain CrossEntropyLoss (main_image.py:292); got %r" % (base,))
+    if base is not None and not (isinstance(base, torch.nn.CrossEntropyLoss) and 0.0 <= float(getattr(base, "label_smoothing", 0.0)) < 1.0
+                                 and base.weight is None and base.reduction == "mean" and base.ignore_index == -100):
+        raise NotImplementedError("the fused step computes nn.CrossEntropyLoss (main_image.py:292; mean reduction, no class weights, "
+                                  "label_smoothing through the soft-target form); got %r" % (base,))
     for n, p in model.named_parameters():
         tr = is_trainable_param(key_to_param(n)[0])
         if tr != bool(p.requires_grad):

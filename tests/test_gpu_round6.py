@@ -706,3 +706,38 @@ def test_adapter_layernorm_rccl_one_rank_path_equals_no_dist(rccl_one_rank):  # 
     for a, b in zip(with_dist, without):
         assert torch.equal(a, b), float((a - b).abs().max())
     assert float(with_dist[1][:, 0].min()) > 0 and bool(torch.isfinite(with_dist[0]).all())
+
+
+def test_label_smoothing_criterion_through_the_soft_target_form():
+    """criterion.base_criterion = nn.CrossEntropyLoss(label_smoothing = 0.1): train_one_epoch hands t = one_hot (1 - e) + e / C to the library's
+    soft-target loss (torch's own definition: F.cross_entropy(x, y, label_smoothing=e) == F.cross_entropy(x, t)); epoch statistics against the
+    oracle evaluated with the same targets; class weights still raise."""
+    import logging
+    import types
+    import synth
+    import engine_finetune as E
+    import misc
+    import gpu_diag as D
+    from oracle import dyt_oracle as O
+    from models.losses import AdaLoss
+    from test_gpu_round2 import _bench_model
+    B, C, r, seed, eps = 4, 10, 8, 43, 0.1
+    m, sd = _bench_model("fp32", "masked", B, 0.3, classes=C, r=r, kind="test", seed=seed)
+    x, y = synth.make_batch(B, C, seed=seed)
+    g1, g2 = synth.make_noise(B, seed=seed + 1)
+    keep = synth.make_dropout_masks(B, r, seed=seed + 2)
+    lr = 1e-3
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=lr, weight_decay=0.0)
+    crit = AdaLoss(base_criterion=torch.nn.CrossEntropyLoss(label_smoothing=eps), token_target_ratio=0.5, token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0)
+    args = types.SimpleNamespace(accum_iter=1, lr=lr, min_lr=0.0, warmup_epochs=0, epochs=10, metric="accuracy", nb_classes=C)
+    stats = E.train_one_epoch(m, crit, [(x, y, (g1, g2), keep)], opt, torch.device("cuda", 0), 0, misc.NativeScalerWithGradNormCount(), None, None, None,
+                              args=args, logger=logging.getLogger("t"))
+    t = torch.nn.functional.one_hot(y, C).float() * (1.0 - eps) + eps / C
+    _, d, _ = O.step_loss(sd, x, t, g1, g2, keep, scale=0.1, mode="masked")
+    for k in ("loss", "base_loss", "token_loss", "teacher_loss", "distillation_loss"):
+        assert abs(stats[k] - float(d[k])) < 1e-4 * max(1.0, abs(float(d[k]))), (k, stats[k], float(d[k]))
+    _, d0, _ = O.step_loss(sd, x, y, g1, g2, keep, scale=0.1, mode="masked")
+    assert abs(float(d0["base_loss"]) - float(d["base_loss"])) > 1e-3   # (the smoothed loss is another number)
+    bad = AdaLoss(base_criterion=torch.nn.CrossEntropyLoss(weight=torch.ones(C)), token_target_ratio=0.5, token_loss_ratio=2.0)
+    with pytest.raises(NotImplementedError):
+        E.train_one_epoch(m, bad, [(x, y)], opt, torch.device("cuda", 0), 1, None, None, None, None, args=args, logger=logging.getLogger("t"))
