@@ -1929,7 +1929,16 @@ extern "C" int dyt_step_fwd_bwd(dyt_ctx* c, const float* images, const int64_t* 
             for (int i = 0; i < 8; ++i) words[i] = dbg_mask[0] == 'c' ? 0xFF00FF00u : (dbg_mask[0] == 'x' ? 0xF0F0F0F0u : (dbg_mask[0] == 'a' ? 0xF8F8F8F8u : 0x00FFFFFFu));   // a: five XCDs for the (heavier) teacher pass
             DYT_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->side, 8, words));
         } else
+        {   // measurement knob DYT_SIDE_PRIORITY: the teacher pass's stream at another priority (-1 = higher than the caller's stream, 1 = lower)
+            const char* pr = getenv("DYT_SIDE_PRIORITY");
+            if (pr) {
+                int lo = 0, hi = 0;
+                DYT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent (numerically greatest), hi = most urgent
+                const int want = atoi(pr) < 0 ? hi : (atoi(pr) > 0 ? lo : 0);
+                DYT_HIP_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, want));
+            } else
         DYT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        }
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         DYT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
