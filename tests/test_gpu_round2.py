@@ -630,9 +630,10 @@ def test_unsupported_training_configurations_fail_loudly():
     x, y = synth.make_batch(2, 100, seed=91)
     dev = torch.device("cuda", 0)
     args = types.SimpleNamespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=1)
-    smooth = AdaLoss(torch.nn.CrossEntropyLoss(label_smoothing=0.1), token_target_ratio=0.5, token_loss_ratio=2.0)
-    with pytest.raises(NotImplementedError, match="CrossEntropyLoss"):
-        train_one_epoch(m, smooth, [(x, y)], opt, dev, 0, args=args)
+    # (label_smoothing runs through the soft-target form since round 6: test_gpu_round6.py; class weights, another reduction or another loss do not)
+    for base in (torch.nn.CrossEntropyLoss(weight=torch.ones(100)), torch.nn.CrossEntropyLoss(reduction="sum"), torch.nn.MSELoss()):
+        with pytest.raises(NotImplementedError, match="CrossEntropyLoss"):
+            train_one_epoch(m, AdaLoss(base, token_target_ratio=0.5, token_loss_ratio=2.0), [(x, y)], opt, dev, 0, args=args)
     crit = AdaLoss(torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0)
     m.blocks[3].adaptmlp.up_proj.weight.requires_grad = False
     with pytest.raises(NotImplementedError, match="freeze rule"):
