@@ -778,3 +778,56 @@ def test_adapter_layernorm_model_trains_in_the_fast_mode(option):
     g0 = sd[name]
     g1 = m._engine.trainable_view(name, g0.shape).cpu()
     assert float((g1 - g0).abs().max()) > 1e-3
+
+
+def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
+    """The multi-rank path with TWO real processes (tests/dp2_worker.py; both on cuda:0, torch.distributed over gloo, the torch.distributed form
+    of the gradient all-reduce -- RCCL refuses two ranks on one device): ranks that start from different trainables and see different shards
+    end two steps with IDENTICAL parameters, and those equal, bit for bit, what one process gets by stepping the two shards one after the other
+    from rank 0's parameters, adding the gradients, and updating once with grad_scale 1/2 (DDP's mean of per-rank gradients, main_image.py:280-282)."""
+    import subprocess
+    import sys
+    import dp2_worker as W
+    from engine_finetune import FusedAdamW
+    from test_gpu_round2 import _free_port
+    port = _free_port()
+    outs = [str(tmp_path / ("rank%d.pt" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "dp2_worker.py"), str(r), "2", str(port), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-2000:])
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [torch.load(o) for o in outs]
+    for precision in ("fp32", "fp16"):
+        a, b = res[0][precision], res[1][precision]
+        assert torch.equal(a["flat"], b["flat"]), precision                       # both ranks hold the same parameters
+        assert not torch.equal(a["losses"], b["losses"])                          # ... after different shards
+        # one process: rank 0's model, the two shards in turn, gradients summed, one update per step with grad_scale 1 / 2
+        m = W.build(0, precision)
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+        eng = m.engine(W.B, torch.device("cuda", 0))
+        want_losses = [[], []]
+        for i in range(2):
+            opt.sync_parameters(eng)
+            total = torch.zeros_like(eng.grad)
+            for r in range(2):
+                x, y, g1, g2, keep = W.shard(r)
+                out = eng.step_fwd_bwd(x.cuda(), y.cuda(), 0.5, 2.0, 0.0, 0.0, g1=g1.cuda().contiguous(), g2=g2.cuda().contiguous(),
+                                       keep_mask=keep.cuda().contiguous())
+                want_losses[r].append(out.clone().cpu())
+                total += eng.grad
+            eng.grad.copy_(total)
+            opt.step(grad_scale=0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.flat.cpu(), a["flat"]), (precision, float((eng.flat.cpu() - a["flat"]).abs().max()))
+        for r in range(2):
+            assert torch.equal(torch.stack(want_losses[r]), res[r][precision]["losses"]), (precision, r)
+        del m, opt, eng
+        torch.cuda.empty_cache()
