@@ -185,6 +185,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DYT_BENCH_SHARE_GPU=1 (test rig, 1-GPU boxes): every rank on cuda:0, torch.distributed over gloo, the torch.distributed form of the gradient
+    # all-reduce (RCCL refuses two ranks on one device).  Exercises the N > 1 launch line, barriers, broadcast, all-reduce, max-over-ranks timing
+    # and the rank-0 JSON line with real processes; the number it prints is NOT a multi-GPU measurement and says so (`config.parallelism`).
+    share_gpu = bool(os.environ.get("DYT_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
+        os.environ["DYT_NATIVE_RCCL"] = "0"
+        if os.environ.get("DYT_BENCH_WATCHDOG"):   # dump every thread's stack and exit if the rig hangs
+            import faulthandler
+            faulthandler.dump_traceback_later(int(os.environ["DYT_BENCH_WATCHDOG"]), exit=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the DyT path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -194,7 +204,10 @@ def main():
     if world > 1 or os.environ.get("DYT_BENCH_FORCE_DIST"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     head = measure(args, args.precision, args.mode, args.steps, args.warmup, device, world, rank, host_batches=args.host_batches)
@@ -321,7 +334,7 @@ def main():
                        ("NOT the headline config: video DyT ViT-B/16 (BASELINE.json configs[4] shape), %d clips x %d frames per GPU, "
                         "%d classes; `value` counts frames/s" % (args.batch // args.video_frames, args.video_frames, args.classes)),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "ffn_num": args.ffn_num,
-                       "num_classes": args.classes, "train_mode": args.mode, "parallelism": "dp%d" % world,
+                       "num_classes": args.classes, "train_mode": args.mode, "parallelism": ("dp%d" % world) + (" (TEST RIG: all ranks share ONE GPU over gloo, DYT_BENCH_SHARE_GPU)" if os.environ.get("DYT_BENCH_SHARE_GPU") else ""),
                        "keep_ratio_measured": head["keep_ratio_measured"], "keep_ratio_calibrated": head["keep_ratio_calibrated"],
                        "hip_graph": head["hip_graph"]},
             "images_per_s_per_gpu": round(head["value"] / world, 2),
@@ -431,9 +444,9 @@ def measure(args, precision, mode, steps, warmup, device, world, rank, host_batc
     losses = torch.zeros(8, device=device)
     acc = torch.zeros(8, device=device)
 
-    def one_step(i):
+    def one_step(i, update=True):
         train_step(model, x, y, opt, losses_out=losses, seed=1000 + i, target_ratio=args.keep, token_minimal=0.0,
-                   token_minimal_weight=0.0, graph=use_graph)
+                   token_minimal_weight=0.0, graph=use_graph, update=update)
 
     for i in range(warmup):
         one_step(i)
@@ -476,7 +489,9 @@ def measure(args, precision, mode, steps, warmup, device, world, rank, host_batc
     if rank == 0:
         use_graph = False   # the event-profiled step runs eagerly, one stream
         eng.profile(True)
-        one_step(10 ** 6)
+        # N > 1: forward + backward only -- this step runs on rank 0 ALONE, and the update leg holds the gradient all-reduce -- a collective the other
+        # ranks would never join (found with two real processes, DYT_BENCH_SHARE_GPU: rank 0 waited in all_reduce, rank 1 in all_gather_object)
+        one_step(10 ** 6, update=(world == 1))
         ms, n, fl = eng.profile_read(0)
         ms_a, n_a, fl_a = eng.profile_read(1)
         ms_o, n_o, _ = eng.profile_read(2)
