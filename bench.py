@@ -191,7 +191,8 @@ def main():
     share_gpu = bool(os.environ.get("DYT_BENCH_SHARE_GPU"))
     if share_gpu:
         local_rank = 0
-        os.environ["DYT_NATIVE_RCCL"] = "0"
+        if os.environ["DYT_BENCH_SHARE_GPU"] != "native":   # "native": let the ranks TRY the library's own RCCL communicator (it cannot exist on a shared
+            os.environ["DYT_NATIVE_RCCL"] = "0"             # device) and fall back by the collective agreement of engine_finetune.allreduce_grads
         if os.environ.get("DYT_BENCH_WATCHDOG"):   # dump every thread's stack and exit if the rig hangs
             import faulthandler
             faulthandler.dump_traceback_later(int(os.environ["DYT_BENCH_WATCHDOG"]), exit=True)

@@ -831,3 +831,25 @@ def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
             assert torch.equal(torch.stack(want_losses[r]), res[r][precision]["losses"]), (precision, r)
         del m, opt, eng
         torch.cuda.empty_cache()
+
+
+def test_bench_launch_line_with_two_real_ranks(tmp_path):
+    """The driver's N > 1 command (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...`) with real processes on this
+    box's one GPU (bench.py's DYT_BENCH_SHARE_GPU test rig: every rank on cuda:0, gloo): it must finish and print exactly ONE JSON line, from rank
+    0, with the whole-job figures.  (Round 6 found a deadlock here: rank 0's event-profiled extra step ran the gradient all-reduce alone.)"""
+    import json
+    import subprocess
+    import sys
+    from test_gpu_round2 import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DYT_BENCH_SHARE_GPU="1", DYT_BENCH_WATCHDOG="400")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 64
+    assert d["distributed"]["torch_world_size"] == 2 and "TEST RIG" in d["config"]["parallelism"]
+    assert abs(d["value"] - 64 / d["ms_per_step"] * 1e3) < 0.01 * d["value"] and d["roofline"]["frac"] > 0
