@@ -64,6 +64,33 @@ def main():
         res[precision] = dict(flat=m._engine.flat.cpu(), losses=torch.stack(losses).cpu())
         del m, opt
         torch.cuda.empty_cache()
+    # the epoch loop and the evaluation with two ranks: train_one_epoch over three batches whose last one is ragged (the engine of the smaller batch
+    # is a re-created context on BOTH ranks), its end-of-epoch statistics all-reduce, then evaluate() over shards of DIFFERENT lengths (rank r: 5 + r
+    # samples -> the ragged all_gather_concat, reference engine_finetune.py:446-480).  Both ranks must return the same epoch statistics and metrics.
+    import logging
+    import types
+    import synth
+    import engine_finetune as E
+    import misc
+    from models.losses import AdaLoss
+    m = build(rank, "fp16")
+    optimizer = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)   # (the drivers' optimizer, adopted)
+    crit = AdaLoss(base_criterion=torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0)
+    args = types.SimpleNamespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=4, metric="accuracy", nb_classes=C)
+    loader = []
+    for i, b in enumerate((B, B, 2)):
+        xb, yb = synth.make_batch(b, C, seed=SEED + 1000 + 10 * rank + i)
+        loader.append((xb, yb))
+    stats = E.train_one_epoch(m, crit, loader, optimizer, torch.device("cuda", 0), 0, misc.NativeScalerWithGradNormCount(), None, None, None,
+                              args=args, logger=logging.getLogger("dp2"))
+    ev = []
+    n_eval = 5 + rank
+    xe, ye = synth.make_batch(n_eval, C, seed=SEED + 2000 + rank)
+    for i in range(0, n_eval, 3):
+        ev.append((xe[i:i + 3], ye[i:i + 3]))
+    status = E.evaluate(ev, m, torch.device("cuda", 0), args=args)
+    res["epoch"] = dict(stats={k: float(v) for k, v in stats.items()}, status={k: float(v) for k, v in status.items()},
+                        flat=m._engine.flat.cpu() if hasattr(m, "_engine") else None, n_eval=n_eval)
     dist.barrier()
     torch.save(res, out)
     dist.destroy_process_group()

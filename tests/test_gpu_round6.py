@@ -831,6 +831,13 @@ def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
             assert torch.equal(torch.stack(want_losses[r]), res[r][precision]["losses"]), (precision, r)
         del m, opt, eng
         torch.cuda.empty_cache()
+    # the epoch loop + evaluation phase of the workers: the all-reduced epoch statistics and the gathered metrics are the same numbers on both
+    # ranks, the evaluation saw all 5 + 6 samples, and the replicas still hold identical parameters
+    e0, e1 = res[0]["epoch"], res[1]["epoch"]
+    assert e0["stats"] == e1["stats"] and e0["status"] == e1["status"], (e0, e1)
+    assert e0["n_eval"] + e1["n_eval"] == 11 and 0.0 <= e0["status"]["acc1"] <= 100.0 and 0.0 < e0["status"]["keep_ratio"] < 1.0
+    assert abs(e0["status"]["acc1"] * 11 / 100.0 - round(e0["status"]["acc1"] * 11 / 100.0)) < 1e-3   # acc1 is k / 11: the gather was ragged (5 + 6)
+    assert all(v == v and abs(v) < 1e6 for v in e0["stats"].values())
 
 
 def test_bench_launch_line_with_two_real_ranks(tmp_path):
