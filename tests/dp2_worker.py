@@ -74,6 +74,8 @@ def main():
     import misc
     from models.losses import AdaLoss
     m = build(rank, "fp16")
+    m_plain = m
+    m = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0])     # main_image.py:280-282: the drivers wrap the model, then build the optimizer
     optimizer = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)   # (the drivers' optimizer, adopted)
     crit = AdaLoss(base_criterion=torch.nn.CrossEntropyLoss(), token_target_ratio=0.5, token_loss_ratio=2.0, token_minimal=0.0, token_minimal_weight=0.0)
     args = types.SimpleNamespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=4, metric="accuracy", nb_classes=C)
@@ -90,7 +92,7 @@ def main():
         ev.append((xe[i:i + 3], ye[i:i + 3]))
     status = E.evaluate(ev, m, torch.device("cuda", 0), args=args)
     res["epoch"] = dict(stats={k: float(v) for k, v in stats.items()}, status={k: float(v) for k, v in status.items()},
-                        flat=m._engine.flat.cpu() if hasattr(m, "_engine") else None, n_eval=n_eval)
+                        flat=m_plain._engine.flat.cpu(), n_eval=n_eval)
     dist.barrier()
     torch.save(res, out)
     dist.destroy_process_group()

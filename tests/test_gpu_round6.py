@@ -838,6 +838,7 @@ def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
     assert e0["n_eval"] + e1["n_eval"] == 11 and 0.0 <= e0["status"]["acc1"] <= 100.0 and 0.0 < e0["status"]["keep_ratio"] < 1.0
     assert abs(e0["status"]["acc1"] * 11 / 100.0 - round(e0["status"]["acc1"] * 11 / 100.0)) < 1e-3   # acc1 is k / 11: the gather was ragged (5 + 6)
     assert all(v == v and abs(v) < 1e6 for v in e0["stats"].values())
+    assert torch.equal(e0["flat"], e1["flat"])   # (the workers wrap the model in DistributedDataParallel first, as main_image.py:280-282 does)
 
 
 def test_bench_launch_line_with_two_real_ranks(tmp_path):
